@@ -1,0 +1,392 @@
+"""cuda-flow3d_amd -- Python binding of the MI355X-native 3-D optical-flow solver.
+
+The product is native: libf3d_hip.so (hand-written gfx950 kernels behind the C ABI of include/f3d.h) and
+libf3d_host.so (the C++ driver / operator classes that mirror the reference's src/optical_flow and
+src/cuda_operations, C ABI in include/f3d_host.h).  This module only binds those two libraries with ctypes
+and moves numpy volumes ([z, y, x], float32, x fastest like the reference's Data3D) across the boundary.
+There is no Python or CPU implementation of any kernel here: if the libraries are missing, importing the
+native handles raises -- build them with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C cuda-flow3d_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+DEFAULT_PARAMS = dict(
+    warp_levels_count=40, warp_scale_factor=0.95, outer_iterations_count=40, inner_iterations_count=5,
+    equation_alpha=7.5, equation_smoothness=0.001, equation_data=0.001, median_radius=5, gaussian_sigma=2.0,
+)  # src/main.cpp:77-85
+
+
+class F3dError(RuntimeError):
+    pass
+
+
+class Size4(C.Structure):  # DataSize4 / f3d_size4
+    _fields_ = [("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t), ("pitch", C.c_size_t)]
+
+
+class Slab(C.Structure):  # f3d_slab
+    _fields_ = [("z_base", C.c_int), ("z_lo", C.c_int), ("z_hi", C.c_int)]
+
+
+class FlowParams(C.Structure):  # f3d_flow_params
+    _fields_ = [
+        ("warp_levels_count", C.c_size_t), ("warp_scale_factor", C.c_float),
+        ("outer_iterations_count", C.c_size_t), ("inner_iterations_count", C.c_size_t),
+        ("equation_alpha", C.c_float), ("equation_smoothness", C.c_float), ("equation_data", C.c_float),
+        ("median_radius", C.c_size_t), ("gaussian_sigma", C.c_float),
+    ]
+
+
+_hip = None
+_host = None
+_fp = C.POINTER(C.c_float)
+_dp = C.c_uint64
+_sz = C.c_size_t
+_slabp = C.POINTER(Slab)
+
+
+def _load(name):
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise F3dError(f"{path} is missing: the HIP extension has not been built (make -C {_HERE}); "
+                       "there is no fallback path")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def hip():
+    """Handle of libf3d_hip.so with argument types declared (include/f3d.h)."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    L = _load("libf3d_hip.so")
+    L.f3d_last_error.restype = C.c_char_p
+    sig = {
+        "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_device_count": [C.POINTER(C.c_int)],
+        "f3d_device_name": [C.c_char_p, _sz], "f3d_mem_info": [C.POINTER(_sz), C.POINTER(_sz)],
+        "f3d_lds_per_workgroup": [C.POINTER(C.c_int)],
+        "f3d_alloc_pitched": [C.POINTER(_dp), C.POINTER(_sz), _sz, _sz], "f3d_free": [_dp],
+        "f3d_memset2d": [_dp, _sz, C.c_int, _sz, _sz],
+        "f3d_copy3d_h2d": [_dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz],
+        "f3d_copy3d_d2h": [_fp, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
+        "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)],
+        "f3d_event_create": [C.POINTER(C.c_void_p)], "f3d_event_record": [C.c_void_p],
+        "f3d_event_sync": [C.c_void_p], "f3d_event_elapsed_ms": [_fp, C.c_void_p, C.c_void_p],
+        "f3d_event_destroy": [C.c_void_p], "f3d_stream_sync": [],
+        "f3d_phi_ksi": [_dp] * 8 + [_sz] * 3 + [C.c_float] * 5 + [_dp, _dp, _slabp],
+        "f3d_solve_sweep": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
+        "f3d_warp": [_dp] * 5 + [_sz] * 3 + [C.c_float] * 3 + [_dp, _slabp],
+        "f3d_resample_x": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_resample_y": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_resample_z": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp, _slabp],
+        "f3d_add": [_dp, _dp, _sz, _sz, _sz, _slabp],
+        "f3d_median": [_dp, _sz, _sz, _sz, _sz, _dp, _slabp],
+        "f3d_set_conv_taps": [_fp, _sz],
+        "f3d_conv_rows": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_conv_cols": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_conv_slices": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_prof_enable": [C.c_int], "f3d_prof_reset": [],
+        "f3d_prof_read": [C.c_int, _sz, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
+        "f3d_abs_max": [_dp, _sz, _sz, _sz, _slabp, _fp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _hip = L
+    return L
+
+
+def host():
+    """Handle of libf3d_host.so with argument types declared (include/f3d_host.h)."""
+    global _host
+    if _host is not None:
+        return _host
+    hip()
+    L = _load("libf3d_host.so")
+    pp = C.POINTER(FlowParams)
+    sig = {
+        "f3d_flow_create": [C.POINTER(C.c_void_p)], "f3d_flow_initialize": [C.c_void_p, _sz, _sz, _sz],
+        "f3d_flow_compute": [C.c_void_p, _fp, _fp, pp, C.c_int, _fp, _fp, _fp],
+        "f3d_flow_upload": [C.c_void_p, _fp, _fp],
+        "f3d_flow_compute_resident": [C.c_void_p, pp, C.c_int, _fp],
+        "f3d_flow_download": [C.c_void_p, _fp, _fp, _fp],
+        "f3d_flow_container": [C.c_void_p, C.POINTER(Size4)], "f3d_flow_destroy": [C.c_void_p],
+        "f3d_op_create": [C.POINTER(C.c_void_p), C.c_char_p], "f3d_op_initialize": [C.c_void_p, C.POINTER(Size4)],
+        "f3d_op_execute": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), _sz],
+        "f3d_op_set_slab": [C.c_void_p, _slabp], "f3d_op_destroy": [C.c_void_p],
+        "f3d_level_geometry": [_sz, _sz, _sz, C.c_float, C.c_int, C.POINTER(Size4), _fp, _fp, _fp],
+        "f3d_gaussian_taps": [C.c_float, _fp, _sz, C.POINTER(_sz)],
+        "f3d_raw_read_u8": [C.c_char_p, _sz, _sz, _sz, _fp], "f3d_raw_read_f32": [C.c_char_p, _sz, _sz, _sz, _fp],
+        "f3d_raw_write_u8": [C.c_char_p, _fp, _sz, _sz, _sz], "f3d_raw_write_f32": [C.c_char_p, _fp, _sz, _sz, _sz],
+        "f3d_vtk_write_flow": [C.c_char_p, _fp, _fp, _fp, _sz, _sz, _sz],
+        "f3d_synth_pair": [_sz, _sz, _sz, _fp, _fp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.f3d_flow_default_params.argtypes = [pp]
+    L.f3d_flow_default_params.restype = None
+    L.f3d_op_name.argtypes = [C.c_void_p]
+    L.f3d_op_name.restype = C.c_char_p
+    L.f3d_max_warp_level.argtypes = [_sz, _sz, _sz, C.c_float]
+    L.f3d_max_warp_level.restype = _sz
+    _host = L
+    return L
+
+
+def check(status, what="f3d call"):
+    if status != 0:
+        msg = hip().f3d_last_error()
+        raise F3dError(f"{what} failed: {msg.decode() if msg else 'status %d' % status}")
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+def make_params(**kw):
+    d = dict(DEFAULT_PARAMS)
+    unknown = set(kw) - set(d)
+    if unknown:
+        raise TypeError(f"unknown flow parameters: {sorted(unknown)}")
+    d.update(kw)
+    return FlowParams(**d)
+
+
+# ---- host-only helpers --------------------------------------------------------------------------------------
+
+def max_warp_level(width, height, depth, scale_factor):
+    return int(host().f3d_max_warp_level(width, height, depth, scale_factor))
+
+
+def level_geometry(width, height, depth, scale_factor, level):
+    size = Size4()
+    hx, hy, hz = C.c_float(), C.c_float(), C.c_float()
+    check(host().f3d_level_geometry(width, height, depth, scale_factor, level, C.byref(size), hx, hy, hz))
+    return (size.width, size.height, size.depth), (hx.value, hy.value, hz.value)
+
+
+def gaussian_taps(sigma):
+    taps = np.zeros(51, np.float32)
+    radius = _sz()
+    if host().f3d_gaussian_taps(sigma, taps.ctypes.data_as(_fp), 51, C.byref(radius)) != 0:
+        raise F3dError("sigma too large for the 51-tap limit")
+    return int(radius.value), taps[: 2 * radius.value + 1].copy()
+
+
+def read_raw(path, dims, u8=True):
+    w, h, d = dims
+    out = np.empty((d, h, w), np.float32)
+    fn = host().f3d_raw_read_u8 if u8 else host().f3d_raw_read_f32
+    if fn(os.fsencode(path), w, h, d, out.ctypes.data_as(_fp)) != 0:
+        raise F3dError(f"cannot read {path} as {w}x{h}x{d}")
+    return out
+
+
+def write_raw(path, vol, u8=False):
+    vol, p = _f32(vol)
+    d, h, w = vol.shape
+    fn = host().f3d_raw_write_u8 if u8 else host().f3d_raw_write_f32
+    if fn(os.fsencode(path), p, w, h, d) != 0:
+        raise F3dError(f"cannot write {path}")
+
+
+def write_vtk(path, u, v, w_):
+    u, pu = _f32(u)
+    v, pv = _f32(v)
+    w_, pw = _f32(w_)
+    d, h, w = u.shape
+    if host().f3d_vtk_write_flow(os.fsencode(path), pu, pv, pw, w, h, d) != 0:
+        raise F3dError(f"cannot write {path}")
+
+
+def synth_pair(width, height, depth):
+    f0 = np.empty((depth, height, width), np.float32)
+    f1 = np.empty_like(f0)
+    check(host().f3d_synth_pair(width, height, depth, f0.ctypes.data_as(_fp), f1.ctypes.data_as(_fp)))
+    return f0, f1
+
+
+# ---- device memory ---------------------------------------------------------------------------------------------
+
+class Containers:
+    """A set of equally sized pitched device containers (what OpticalFlowE::InitCudaMemory allocates)."""
+
+    def __init__(self, width, height, depth, device=-1):
+        check(hip().f3d_init(device), "f3d_init")
+        self.width, self.height, self.depth = width, height, depth
+        self.pitch = 0
+        self._ptrs = []
+
+    @property
+    def size4(self):
+        return Size4(self.width, self.height, self.depth, self.pitch)
+
+    def set_current(self):
+        s = self.size4
+        check(hip().f3d_set_container(C.byref(s)), "f3d_set_container")
+
+    def alloc(self, fill=None):
+        ptr, pitch = _dp(), _sz()
+        check(hip().f3d_alloc_pitched(C.byref(ptr), C.byref(pitch), self.width * 4, self.height * self.depth),
+              "f3d_alloc_pitched")
+        if self.pitch and pitch.value != self.pitch:
+            raise F3dError("containers came back with different pitches")
+        self.pitch = pitch.value
+        self._ptrs.append(ptr.value)
+        if fill is not None:
+            # byte pattern over the whole pitched allocation (0xFF.. = NaN poison)
+            check(hip().f3d_memset2d(ptr.value, self.pitch, fill, self.pitch, self.height * self.depth))
+        return ptr.value
+
+    def upload(self, ptr, vol, plane0=0):
+        vol, p = _f32(vol)
+        d, h, w = vol.shape
+        check(hip().f3d_copy3d_h2d(ptr, self.pitch, self.height, plane0, p, w, h, d), "f3d_copy3d_h2d")
+
+    def download(self, ptr, dims, plane0=0):
+        w, h, d = dims
+        out = np.empty((d, h, w), np.float32)
+        check(hip().f3d_copy3d_d2h(out.ctypes.data_as(_fp), w, h, d, ptr, self.pitch, self.height, plane0),
+              "f3d_copy3d_d2h")
+        return out
+
+    def new(self, vol=None, fill=0xFF):
+        """Allocate a NaN-poisoned container and optionally upload a [d, h, w] sub-box into its corner."""
+        p = self.alloc(fill=fill)
+        if vol is not None:
+            self.upload(p, vol)
+        return p
+
+    def free(self):
+        for p in self._ptrs:
+            hip().f3d_free(p)
+        self._ptrs = []
+
+
+def sync():
+    check(hip().f3d_stream_sync(), "f3d_stream_sync")
+
+
+# ---- operator layer (CudaOperation* through the string-keyed bag) -------------------------------------------------
+
+_PTR_KEYS = {
+    "dev_frame_0", "dev_frame_1", "dev_flow_u", "dev_flow_v", "dev_flow_w", "dev_phi", "dev_ksi", "dev_flow_du",
+    "dev_flow_dv", "dev_flow_dw", "dev_temp_du", "dev_temp_dv", "dev_temp_dw", "dev_input", "dev_output", "dev_temp",
+    "operand_0", "operand_1",
+}
+_SIZE_T_KEYS = {"outer_iterations_count", "inner_iterations_count", "radius", "warp_levels_count", "median_radius"}
+_FLOAT_KEYS = {"equation_alpha", "equation_smoothness", "equation_data", "hx", "hy", "hz", "gaussian_sigma",
+               "warp_scale_factor"}
+_SIZE4_KEYS = {"data_size", "resample_size", "container_size"}
+
+
+class Operation:
+    """One of the six operators, driven exactly like the reference drives them: Initialize({"container_size"}),
+    Execute(bag of pointers to caller variables).  After execute() the (possibly swapped) pointer values are
+    available in .values (the solver swaps dev_flow_d* / dev_temp_d* through the bag)."""
+
+    def __init__(self, name):
+        self._h = C.c_void_p()
+        if host().f3d_op_create(C.byref(self._h), name.encode()) != 0:
+            raise F3dError(f"unknown operation {name!r}")
+        self.values = {}
+
+    @property
+    def name(self):
+        return host().f3d_op_name(self._h).decode()
+
+    def initialize(self, containers=None):
+        if containers is None:
+            return host().f3d_op_initialize(self._h, None) == 0
+        s = containers.size4
+        return host().f3d_op_initialize(self._h, C.byref(s)) == 0
+
+    def set_slab(self, slab):
+        self._slab = slab
+        host().f3d_op_set_slab(self._h, C.byref(slab) if slab is not None else None)
+
+    def execute(self, **params):
+        store = {}
+        for k, v in params.items():
+            if k in _PTR_KEYS:
+                store[k] = _dp(v)
+            elif k in _SIZE_T_KEYS:
+                store[k] = _sz(v)
+            elif k in _FLOAT_KEYS:
+                store[k] = C.c_float(v)
+            elif k in _SIZE4_KEYS:
+                store[k] = Size4(v[0], v[1], v[2], 0) if not isinstance(v, Size4) else v
+            else:
+                raise TypeError(f"unknown parameter key {k!r}")
+        n = len(store)
+        keys = (C.c_char_p * n)(*[k.encode() for k in store])
+        ptrs = (C.c_void_p * n)(*[C.cast(C.byref(v), C.c_void_p) for v in store.values()])
+        check(host().f3d_op_execute(self._h, keys, ptrs, n), "f3d_op_execute")
+        self.values = {k: (v.value if hasattr(v, "value") else v) for k, v in store.items()}
+        return self.values
+
+    def destroy(self):
+        if self._h:
+            host().f3d_op_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+# ---- driver (OpticalFlowE) ----------------------------------------------------------------------------------------
+
+class OpticalFlow:
+    """OpticalFlowE: Initialize(DataSize4) / ComputeFlow(frame_0, frame_1 -> u, v, w) / Destroy()."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(host().f3d_flow_create(C.byref(self._h)), "f3d_flow_create")
+        self.dims = None
+
+    def initialize(self, width, height, depth):
+        if host().f3d_flow_initialize(self._h, width, height, depth) != 0:
+            raise F3dError("OpticalFlowE::Initialize failed: " + (hip().f3d_last_error() or b"").decode())
+        self.dims = (width, height, depth)
+        return True
+
+    def compute(self, frame_0, frame_1, silent=True, **kw):
+        f0, p0 = _f32(frame_0)
+        f1, p1 = _f32(frame_1)
+        w, h, d = self.dims
+        if f0.shape != (d, h, w) or f1.shape != (d, h, w):
+            raise ValueError(f"frames must be [z,y,x] = {(d, h, w)}")
+        u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
+        prm = make_params(**kw)
+        check(host().f3d_flow_compute(self._h, p0, p1, C.byref(prm), int(silent), u.ctypes.data_as(_fp),
+                                      v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)), "f3d_flow_compute")
+        return u, v, ww
+
+    def upload(self, frame_0, frame_1):
+        f0, p0 = _f32(frame_0)
+        f1, p1 = _f32(frame_1)
+        check(host().f3d_flow_upload(self._h, p0, p1), "f3d_flow_upload")
+
+    def compute_resident(self, silent=True, **kw):
+        prm = make_params(**kw)
+        secs = C.c_float()
+        check(host().f3d_flow_compute_resident(self._h, C.byref(prm), int(silent), C.byref(secs)),
+              "f3d_flow_compute_resident")
+        return secs.value
+
+    def download(self):
+        w, h, d = self.dims
+        u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
+        check(host().f3d_flow_download(self._h, u.ctypes.data_as(_fp), v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)))
+        return u, v, ww
+
+    def destroy(self):
+        if self._h:
+            host().f3d_flow_destroy(self._h)
+            self._h = C.c_void_p()

@@ -1,0 +1,143 @@
+// 3-D median filter of the flow components for gfx950 (window diameter 3, 5 or 7, mirror boundary).
+//
+// Replaces src/kernels/median_3d.cu:49-299 of the reference: the output is the
+// element of rank r^3/2 of the r^3 window gathered at mirrored indices.  The reference sorts a 343-float
+// per-thread local array by insertion; any exact selection gives the same value, so here
+//   r = 3, 5 : the window lives in VGPRs and goes through a Batcher odd-even merge network of
+//              compare-exchanges (v_min_f32 / v_max_f32); everything that does not feed rank r^3/2 is
+//              pruned at compile time by dead-code elimination (1184 of 1441 exchanges remain for r = 5),
+//   r = 7    : 343 values do not fit the register file; exact rank selection by bisection on the
+//              order-preserving integer image of the floats (32 counting passes over the window).
+// The only observable difference to a stable sort is the sign of a zero result when the window holds both
+// -0 and +0 (they compare equal); values are otherwise identical.
+#include "f3d_internal.h"
+
+namespace {
+
+constexpr int kBX = 64;
+constexpr int kBY = 4;
+
+__device__ __forceinline__ void cmp_exchange(float& a, float& b)
+{
+  const float lo = fminf(a, b);
+  const float hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+
+// Batcher's odd-even merge sort for arbitrary N, fully unrolled over a register array.
+template <int N>
+__device__ __forceinline__ float rank_middle(float (&v)[N])
+{
+#pragma unroll
+  for (int p = 1; p < N; p <<= 1) {
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1) {
+#pragma unroll
+      for (int j = k % p; j <= N - 1 - k; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); ++i) {
+          if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) cmp_exchange(v[i + j], v[i + j + k]);
+        }
+      }
+    }
+  }
+  return v[N / 2];
+}
+
+template <int R>
+__global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict__ in, float* __restrict__ out, F3dGeo g)
+{
+  constexpr int HALF = R / 2;
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  int xs[R];
+  size_t rows[R][R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) xs[i] = f3d_mir(x + i - HALF, g.W);
+#pragma unroll
+  for (int iz = 0; iz < R; ++iz)
+#pragma unroll
+    for (int iy = 0; iy < R; ++iy) rows[iz][iy] = f3d_row(g, f3d_mir(y + iy - HALF, g.H), f3d_mir(z + iz - HALF, g.D));
+  float v[R * R * R];
+#pragma unroll
+  for (int iz = 0; iz < R; ++iz)
+#pragma unroll
+    for (int iy = 0; iy < R; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < R; ++ix) v[(iz * R + iy) * R + ix] = in[rows[iz][iy] + xs[ix]];
+  out[f3d_row(g, y, z) + x] = rank_middle<R * R * R>(v);
+}
+
+__device__ __forceinline__ unsigned order_key(float f)
+{
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// Exact rank selection without holding the window: the answer is the largest T with #(key < T) <= rank.
+template <int R>
+__global__ __launch_bounds__(kBX* kBY) void k_median_bisect(const float* __restrict__ in, float* __restrict__ out, F3dGeo g)
+{
+  constexpr int HALF = R / 2;
+  constexpr int RANK = (R * R * R) / 2;
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  int xs[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) xs[i] = f3d_mir(x + i - HALF, g.W);
+  unsigned prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = prefix | (1u << bit);
+    int below = 0;
+    for (int iz = 0; iz < R; ++iz) {
+      const int zz = f3d_mir(z + iz - HALF, g.D);
+      for (int iy = 0; iy < R; ++iy) {
+        const size_t row = f3d_row(g, f3d_mir(y + iy - HALF, g.H), zz);
+#pragma unroll
+        for (int ix = 0; ix < R; ++ix) below += order_key(in[row + xs[ix]]) < cand ? 1 : 0;
+      }
+    }
+    if (below <= RANK) prefix = cand;
+  }
+  const unsigned b = (prefix >> 31) ? (prefix ^ 0x80000000u) : ~prefix;
+  out[f3d_row(g, y, z) + x] = __uint_as_float(b);
+}
+
+}  // namespace
+
+extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t depth, size_t radius, f3d_devptr output,
+                          const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_median");
+  if (input == output) return f3d::fail("f3d_median: input buffer cannot serve as output buffer");
+  if (radius != 3 && radius != 5 && radius != 7)
+    return f3d::fail("f3d_median: wrong median radius (%zu). Supported values: 3, 5, 7", radius);
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_median")) return 1;
+  const int half = static_cast<int>(radius) / 2;
+  if (g.W <= half || g.H <= half || g.D <= half)
+    return f3d::fail("f3d_median: every dimension must exceed radius/2 = %d for the mirror boundary", half);
+  if (g.z_lo == g.z_hi) return 0;
+  {
+    const int dc = static_cast<int>(f3d::container().depth);
+    int lo = g.z_lo - half < 0 ? 0 : g.z_lo - half;
+    int hi = g.z_hi + half > g.D ? g.D : g.z_hi + half;
+    if (g.z_lo - half < 0 && half + 1 > hi) hi = half + 1;
+    if (g.z_hi + half > g.D && g.D - 1 - half < lo) lo = g.D - 1 - half;
+    if (lo < g.z_base || hi - g.z_base > dc)
+      return f3d::fail("f3d_median: planes [%d,%d) needed but the container holds [%d,%d)", lo, hi, g.z_base, g.z_base + dc);
+  }
+  const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo), block(kBX, kBY, 1);
+  const float* in = f3d_ptr<const float>(input);
+  float* out = f3d_ptr<float>(output);
+  if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g);
+  if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g);
+  if (radius == 7) hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), in, out, g);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}

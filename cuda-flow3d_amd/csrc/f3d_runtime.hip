@@ -1,0 +1,385 @@
+// libf3d_hip.so runtime: context, stream, pitched memory, 3-D copies, events, per-kernel timing.
+// Replaces the CUDA driver-API uses listed in SURVEY.md 2c (cuInit ... cuEventElapsedTime); each entry
+// point cites its reference call site in include/f3d.h.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "f3d_internal.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+struct State {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  f3d_size4 container = {0, 0, 0, 0};
+  f3d::ConvTaps taps = {{0}, 0};
+  hipDeviceProp_t prop;
+} S;
+
+struct ProfRec {
+  int kernel;
+  size_t voxels;
+  hipEvent_t start, stop;
+};
+struct Prof {
+  bool enabled = false;
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[F3D_K_COUNT][2] = {{0, 0}, {0, 0}};  // [kernel][0 = all, 1 = filtered] is rebuilt on read
+  hipEvent_t open_start[F3D_K_COUNT] = {nullptr, nullptr};
+  size_t open_voxels[F3D_K_COUNT] = {0, 0};
+} P;
+
+hipEvent_t take_event()
+{
+  if (!P.pool.empty()) {
+    hipEvent_t e = P.pool.back();
+    P.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+}  // namespace
+
+namespace f3d {
+
+int fail(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+  return fail("HIP error %d (%s) in %s at %s:%d", static_cast<int>(e), hipGetErrorString(e), what, file, line);
+}
+
+hipStream_t stream() { return S.stream; }
+bool ready() { return S.ready; }
+const f3d_size4& container() { return S.container; }
+const ConvTaps& conv_taps() { return S.taps; }
+
+bool make_geo(F3dGeo* g, size_t w, size_t h, size_t d, const f3d_slab* slab, const char* who)
+{
+  const f3d_size4& c = S.container;
+  if (c.pitch == 0 || c.height == 0) {
+    fail("%s: f3d_set_container() has not been called", who);
+    return false;
+  }
+  if (w == 0 || h == 0 || d == 0 || w > c.width || h > c.height || w * sizeof(float) > c.pitch) {
+    fail("%s: level %zux%zux%zu does not fit the container %zux%zux%zu (pitch %zu B)", who, w, h, d, c.width,
+         c.height, c.depth, c.pitch);
+    return false;
+  }
+  g->W = static_cast<int>(w);
+  g->H = static_cast<int>(h);
+  g->D = static_cast<int>(d);
+  g->Hc = static_cast<int>(c.height);
+  g->pitch = static_cast<int>(c.pitch / sizeof(float));
+  if (slab) {
+    g->z_base = slab->z_base;
+    g->z_lo = slab->z_lo;
+    g->z_hi = slab->z_hi;
+    if (g->z_lo < 0 || g->z_hi > g->D || g->z_lo > g->z_hi || g->z_lo < g->z_base ||
+        static_cast<size_t>(g->z_hi - g->z_base) > c.depth) {
+      fail("%s: slab planes [%d,%d) base %d outside level depth %d / container depth %zu", who, g->z_lo, g->z_hi,
+           g->z_base, g->D, c.depth);
+      return false;
+    }
+  } else {
+    g->z_base = 0;
+    g->z_lo = 0;
+    g->z_hi = g->D;
+    if (d > c.depth) {
+      fail("%s: depth %zu exceeds container depth %zu", who, d, c.depth);
+      return false;
+    }
+  }
+  return true;
+}
+
+void prof_begin(int kernel, size_t voxels)
+{
+  if (!P.enabled) return;
+  hipEvent_t e = take_event();
+  if (!e) return;
+  (void)hipEventRecord(e, S.stream);
+  P.open_start[kernel] = e;
+  P.open_voxels[kernel] = voxels;
+}
+
+void prof_end(int kernel)
+{
+  if (!P.enabled || !P.open_start[kernel]) return;
+  hipEvent_t e = take_event();
+  if (!e) return;
+  (void)hipEventRecord(e, S.stream);
+  P.pending.push_back({kernel, P.open_voxels[kernel], P.open_start[kernel], e});
+  P.open_start[kernel] = nullptr;
+}
+
+}  // namespace f3d
+
+extern "C" {
+
+const char* f3d_last_error(void) { return g_error; }
+
+int f3d_device_count(int* count)
+{
+  if (!count) return f3d::fail("f3d_device_count: null argument");
+  F3D_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+
+int f3d_init(int device)
+{
+  if (S.ready) return 0;
+  int n = 0;
+  F3D_HIP(hipGetDeviceCount(&n));
+  if (n == 0) return f3d::fail("f3d_init: no HIP device is visible");
+  if (device < 0) {
+    const char* lr = std::getenv("LOCAL_RANK");
+    device = lr ? std::atoi(lr) % n : 0;
+  }
+  if (device >= n) return f3d::fail("f3d_init: device %d requested but only %d visible", device, n);
+  F3D_HIP(hipSetDevice(device));
+  F3D_HIP(hipGetDeviceProperties(&S.prop, device));
+  if (std::strncmp(S.prop.gcnArchName, "gfx950", 6) != 0) {
+    return f3d::fail("f3d_init: device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                     S.prop.gcnArchName);
+  }
+  F3D_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  S.device = device;
+  S.ready = true;
+  return 0;
+}
+
+int f3d_shutdown(void)
+{
+  if (!S.ready) return 0;
+  (void)hipStreamSynchronize(S.stream);
+  for (auto& r : P.pending) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  P.pending.clear();
+  for (auto e : P.pool) (void)hipEventDestroy(e);
+  P.pool.clear();
+  (void)hipStreamDestroy(S.stream);
+  S.stream = nullptr;
+  S.ready = false;
+  return 0;
+}
+
+int f3d_device_name(char* name, size_t capacity)
+{
+  F3D_REQUIRE_READY("f3d_device_name");
+  if (!name || capacity == 0) return f3d::fail("f3d_device_name: null argument");
+  std::snprintf(name, capacity, "%s (%s)", S.prop.name, S.prop.gcnArchName);
+  return 0;
+}
+
+int f3d_mem_info(size_t* free_bytes, size_t* total_bytes)
+{
+  F3D_REQUIRE_READY("f3d_mem_info");
+  F3D_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
+
+int f3d_lds_per_workgroup(int* bytes)
+{
+  F3D_REQUIRE_READY("f3d_lds_per_workgroup");
+  *bytes = static_cast<int>(S.prop.sharedMemPerBlock);
+  return 0;
+}
+
+int f3d_alloc_pitched(f3d_devptr* ptr, size_t* pitch, size_t width_bytes, size_t rows)
+{
+  F3D_REQUIRE_READY("f3d_alloc_pitched");
+  if (!ptr || !pitch || width_bytes == 0 || rows == 0) return f3d::fail("f3d_alloc_pitched: bad argument");
+  const size_t align = 256;  // whole 256-B wave rows; also keeps every row 16-B aligned for dwordx4 access
+  size_t p = (width_bytes + align - 1) / align * align;
+  void* d = nullptr;
+  F3D_HIP(hipMalloc(&d, p * rows + align));
+  *ptr = static_cast<f3d_devptr>(reinterpret_cast<uintptr_t>(d));
+  *pitch = p;
+  return 0;
+}
+
+int f3d_free(f3d_devptr ptr)
+{
+  F3D_REQUIRE_READY("f3d_free");
+  F3D_HIP(hipFree(f3d_ptr<void>(ptr)));
+  return 0;
+}
+
+int f3d_memset2d(f3d_devptr ptr, size_t pitch, int value, size_t width_bytes, size_t rows)
+{
+  F3D_REQUIRE_READY("f3d_memset2d");
+  F3D_HIP(hipMemset2DAsync(f3d_ptr<void>(ptr), pitch, value, width_bytes, rows, S.stream));
+  return 0;
+}
+
+int f3d_copy3d_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
+                   size_t width, size_t height, size_t depth)
+{
+  F3D_REQUIRE_READY("f3d_copy3d_h2d");
+  if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_h2d: volume exceeds container");
+  char* d = f3d_ptr<char>(dst) + dev_plane0 * dev_height * dev_pitch;
+  const size_t wb = width * sizeof(float);
+  if (height == dev_height) {
+    F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, wb, wb, height * depth, hipMemcpyHostToDevice, S.stream));
+  } else {
+    for (size_t z = 0; z < depth; ++z)
+      F3D_HIP(hipMemcpy2DAsync(d + z * dev_height * dev_pitch, dev_pitch, src + z * height * width, wb, wb, height,
+                               hipMemcpyHostToDevice, S.stream));
+  }
+  F3D_HIP(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_devptr src, size_t dev_pitch,
+                   size_t dev_height, size_t dev_plane0)
+{
+  F3D_REQUIRE_READY("f3d_copy3d_d2h");
+  if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_d2h: volume exceeds container");
+  const char* s = f3d_ptr<const char>(src) + dev_plane0 * dev_height * dev_pitch;
+  const size_t wb = width * sizeof(float);
+  if (height == dev_height) {
+    F3D_HIP(hipMemcpy2DAsync(dst, wb, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, S.stream));
+  } else {
+    for (size_t z = 0; z < depth; ++z)
+      F3D_HIP(hipMemcpy2DAsync(dst + z * height * width, wb, s + z * dev_height * dev_pitch, dev_pitch, wb, height,
+                               hipMemcpyDeviceToHost, S.stream));
+  }
+  F3D_HIP(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes)
+{
+  F3D_REQUIRE_READY("f3d_copy_d2d");
+  F3D_HIP(hipMemcpyAsync(f3d_ptr<void>(dst), f3d_ptr<const void>(src), bytes, hipMemcpyDeviceToDevice, S.stream));
+  return 0;
+}
+
+int f3d_set_container(const f3d_size4* c)
+{
+  if (!c || c->width == 0 || c->height == 0 || c->depth == 0 || c->pitch < c->width * sizeof(float) ||
+      c->pitch % sizeof(float) != 0)
+    return f3d::fail("f3d_set_container: invalid container size");
+  S.container = *c;
+  return 0;
+}
+
+int f3d_set_conv_taps(const float* taps, size_t count)
+{
+  if (!taps || count == 0 || count > 51 || count % 2 == 0)
+    return f3d::fail("f3d_set_conv_taps: need an odd tap count of at most 51, got %zu", count);
+  std::memcpy(S.taps.k, taps, count * sizeof(float));
+  S.taps.count = static_cast<int>(count);
+  return 0;
+}
+
+struct f3d_event_s {
+  hipEvent_t ev;
+};
+
+int f3d_event_create(f3d_event* ev)
+{
+  F3D_REQUIRE_READY("f3d_event_create");
+  f3d_event e = new f3d_event_s;
+  hipError_t r = hipEventCreate(&e->ev);
+  if (r != hipSuccess) {
+    delete e;
+    return f3d::hip_fail(r, "hipEventCreate", __FILE__, __LINE__);
+  }
+  *ev = e;
+  return 0;
+}
+
+int f3d_event_record(f3d_event ev)
+{
+  F3D_REQUIRE_READY("f3d_event_record");
+  F3D_HIP(hipEventRecord(ev->ev, S.stream));
+  return 0;
+}
+
+int f3d_event_sync(f3d_event ev)
+{
+  F3D_HIP(hipEventSynchronize(ev->ev));
+  return 0;
+}
+
+int f3d_event_elapsed_ms(float* ms, f3d_event start, f3d_event stop)
+{
+  F3D_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return 0;
+}
+
+int f3d_event_destroy(f3d_event ev)
+{
+  if (!ev) return 0;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return 0;
+}
+
+int f3d_stream_sync(void)
+{
+  F3D_REQUIRE_READY("f3d_stream_sync");
+  F3D_HIP(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int f3d_prof_enable(int enable)
+{
+  P.enabled = enable != 0;
+  return 0;
+}
+
+int f3d_prof_reset(void)
+{
+  F3D_REQUIRE_READY("f3d_prof_reset");
+  F3D_HIP(hipStreamSynchronize(S.stream));
+  for (auto& r : P.pending) {
+    P.pool.push_back(r.start);
+    P.pool.push_back(r.stop);
+  }
+  P.pending.clear();
+  return 0;
+}
+
+int f3d_prof_read(int kernel, size_t min_voxels, double* total_ms, uint64_t* launches, double* total_voxels)
+{
+  F3D_REQUIRE_READY("f3d_prof_read");
+  if (kernel < 0 || kernel >= F3D_K_COUNT) return f3d::fail("f3d_prof_read: bad kernel id %d", kernel);
+  F3D_HIP(hipStreamSynchronize(S.stream));
+  double ms = 0, vox = 0;
+  uint64_t n = 0;
+  for (auto& r : P.pending) {
+    if (r.kernel != kernel || r.voxels < min_voxels) continue;
+    float t = 0;
+    F3D_HIP(hipEventElapsedTime(&t, r.start, r.stop));
+    ms += t;
+    vox += static_cast<double>(r.voxels);
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (total_voxels) *total_voxels = vox;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,302 @@
+// Streaming / gather kernels of the pyramid loop for gfx950: trilinear backward warp, separable area
+// resampling, flow update, separable Gaussian pre-blur, |field| maximum.
+//
+// Replaces src/kernels/registration_3d.cu, resample_3d.cu, add_3d.cu and convolution_3d.cu of the reference
+// (SURVEY.md Appendix A.2, A.1, A.6).  Same expression trees, contraction off.  All of them are single-pass
+// HBM-bound maps: a wave64 covers 64 consecutive x of one row (256 B coalesced), a workgroup 4 rows; the
+// few neighbouring reads each output needs (<= 13 taps, <= 9 box cells, 8 trilinear corners) hit L1/L2.
+#include <cstring>
+
+#include "f3d_internal.h"
+
+namespace {
+
+constexpr int kBX = 64;
+constexpr int kBY = 4;
+
+inline dim3 grid_for(int w, int h, int planes) { return dim3((w + kBX - 1) / kBX, (h + kBY - 1) / kBY, planes); }
+
+// ---- A.2 warp: src/kernels/registration_3d.cu:28-82 ------------------------------------------------------
+__global__ __launch_bounds__(kBX* kBY) void k_warp(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                   const float* __restrict__ u, const float* __restrict__ v,
+                                                   const float* __restrict__ w, float* __restrict__ out, F3dGeo g,
+                                                   float hx, float hy, float hz)
+{
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  const size_t c = f3d_row(g, y, z) + x;
+  const float x_f = static_cast<float>(x) + (u[c] * (1.f / hx));
+  const float y_f = static_cast<float>(y) + (v[c] * (1.f / hy));
+  const float z_f = static_cast<float>(z) + (w[c] * (1.f / hz));
+  if ((x_f < 0.f) || (x_f > static_cast<float>(g.W - 1)) || (y_f < 0.f) || (y_f > static_cast<float>(g.H - 1)) ||
+      (z_f < 0.f) || (z_f > static_cast<float>(g.D - 1)) || isnan(x_f) || isnan(y_f) || isnan(z_f)) {
+    out[c] = f0[c];
+    return;
+  }
+  const int xi = static_cast<int>(floorf(x_f));
+  const int yi = static_cast<int>(floorf(y_f));
+  const int zi = static_cast<int>(floorf(z_f));
+  const float dx = x_f - static_cast<float>(xi);
+  const float dy = y_f - static_cast<float>(yi);
+  const float dz = z_f - static_cast<float>(zi);
+  const int x1 = min(g.W - 1, xi + 1);
+  const int y1 = min(g.H - 1, yi + 1);
+  const int z1 = min(g.D - 1, zi + 1);
+  const size_t r00 = f3d_row(g, yi, zi), r10 = f3d_row(g, y1, zi);
+  const size_t r01 = f3d_row(g, yi, z1), r11 = f3d_row(g, y1, z1);
+  const float v0 = (1.f - dx) * (1.f - dy) * f1[r00 + xi] + (dx) * (1.f - dy) * f1[r00 + x1] +
+                   (1.f - dx) * (dy)*f1[r10 + xi] + (dx) * (dy)*f1[r10 + x1];
+  const float v1 = (1.f - dx) * (1.f - dy) * f1[r01 + xi] + (dx) * (1.f - dy) * f1[r01 + x1] +
+                   (1.f - dx) * (dy)*f1[r11 + xi] + (dx) * (dy)*f1[r11 + x1];
+  out[c] = (1.f - dz) * v0 + dz * v1;
+}
+
+// ---- A.1 resample: src/kernels/resample_3d.cu:28-161 -------------------------------------------------------
+// AXIS 0/1/2 = x/y/z.  gi addresses the input container, g the output planes.
+template <int AXIS>
+__global__ __launch_bounds__(kBX* kBY) void k_resample(const float* __restrict__ in, float* __restrict__ out,
+                                                       F3dGeo gi, F3dGeo g, int in_n)
+{
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  const int out_n = AXIS == 0 ? g.W : (AXIS == 1 ? g.H : g.D);
+  const int i = AXIS == 0 ? x : (AXIS == 1 ? y : z);
+  const float delta = static_cast<float>(in_n) / static_cast<float>(out_n);
+  const float normalization = static_cast<float>(out_n) / static_cast<float>(in_n);
+  const float left_f = static_cast<float>(i) * delta;
+  const float right_f = static_cast<float>(i + 1) * delta;
+  const int left_i = static_cast<int>(floorf(left_f));
+  const int right_i = static_cast<int>(fminf(static_cast<float>(in_n), ceilf(right_f)));
+  const int cnt = right_i - left_i;
+  float value = 0.f;
+  for (int j = 0; j < cnt; ++j) {
+    float frac = 1.f;
+    if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+    if (j == cnt - 1) frac = right_f - static_cast<float>(left_i + j);
+    if (cnt == 1) frac = delta;
+    const int s = left_i + j;
+    const size_t a = AXIS == 0 ? f3d_row(gi, y, z) + s : (AXIS == 1 ? f3d_row(gi, s, z) + x : f3d_row(gi, y, s) + x);
+    value = value + in[a] * frac;
+  }
+  out[f3d_row(g, y, z) + x] = value * normalization;
+}
+
+// ---- add: src/kernels/add_3d.cu:26-41 ------------------------------------------------------------------------
+__global__ __launch_bounds__(kBX* kBY) void k_add(float* __restrict__ a, const float* __restrict__ b, F3dGeo g)
+{
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  const size_t c = f3d_row(g, y, z) + x;
+  a[c] = a[c] + b[c];
+}
+
+// ---- A.6 Gaussian passes: src/kernels/convolution_3d.cu:75-172,186-271,284-372 ---------------------------------
+// Clean spec: zero padding, sum = sum + k[R - j] * s[i + j] for j = -R..R ascending, sum starting at 0.
+template <int AXIS>
+__global__ __launch_bounds__(kBX* kBY) void k_conv(float* __restrict__ dst, const float* __restrict__ src, F3dGeo g,
+                                                   f3d::ConvTaps taps, int radius)
+{
+  const int x = blockIdx.x * kBX + threadIdx.x;
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  const int n = AXIS == 0 ? g.W : (AXIS == 1 ? g.H : g.D);
+  const int i = AXIS == 0 ? x : (AXIS == 1 ? y : z);
+  float sum = 0.f;
+  for (int j = -radius; j <= radius; ++j) {
+    const int s = i + j;
+    float val = 0.f;
+    if (s >= 0 && s < n) {
+      const size_t a = AXIS == 0 ? f3d_row(g, y, z) + s : (AXIS == 1 ? f3d_row(g, s, z) + x : f3d_row(g, y, s) + x);
+      val = src[a];
+    }
+    sum = sum + taps.k[radius - j] * val;
+  }
+  dst[f3d_row(g, y, z) + x] = sum;
+}
+
+// ---- max |field| over a slab (feeds the warp halo depth of the z-slab decomposition) ---------------------------
+__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ f, F3dGeo g, unsigned* result)
+{
+  const int z = g.z_lo + blockIdx.z;
+  float m = 0.f;
+  for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
+    const size_t r = f3d_row(g, y, z);
+    for (int x = threadIdx.x; x < g.W; x += blockDim.x) m = fmaxf(m, fabsf(f[r + x]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));  // non-negative floats order like uints
+}
+
+bool same_buffer(f3d_devptr a, f3d_devptr b, const char* who)
+{
+  if (a == b) {
+    f3d::fail("%s: input buffer cannot serve as output buffer", who);
+    return true;
+  }
+  return false;
+}
+
+bool planes_inside(const F3dGeo& g, int lo, int hi, const char* who)
+{
+  const int dc = static_cast<int>(f3d::container().depth);
+  if (lo < g.z_base || hi - g.z_base > dc) {
+    f3d::fail("%s: planes [%d,%d) needed but the container holds [%d,%d)", who, lo, hi, g.z_base, g.z_base + dc);
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+             size_t width, size_t height, size_t depth, float hx, float hy, float hz, f3d_devptr output,
+             const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_warp");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_warp")) return 1;
+  if (same_buffer(frame_1, output, "f3d_warp")) return 1;
+  if (g.z_lo == g.z_hi) return 0;
+  hipLaunchKernelGGL(k_warp, grid_for(g.W, g.H, g.z_hi - g.z_lo), dim3(kBX, kBY, 1), 0, f3d::stream(),
+                     f3d_ptr<const float>(frame_0), f3d_ptr<const float>(frame_1), f3d_ptr<const float>(flow_u),
+                     f3d_ptr<const float>(flow_v), f3d_ptr<const float>(flow_w), f3d_ptr<float>(output), g, hx, hy, hz);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+static int resample_launch(int axis, f3d_devptr input, f3d_devptr output, size_t ow, size_t oh, size_t od, size_t in_n,
+                           const f3d_slab* slab_in, const f3d_slab* slab, const char* who)
+{
+  F3D_REQUIRE_READY(who);
+  if (same_buffer(input, output, who)) return 1;
+  if (in_n == 0) return f3d::fail("%s: empty input axis", who);
+  F3dGeo g, gi;
+  if (!f3d::make_geo(&g, ow, oh, od, slab, who)) return 1;
+  // the input box: same as the output except along the resampled axis
+  const size_t iw = axis == 0 ? in_n : ow, ih = axis == 1 ? in_n : oh, id = axis == 2 ? in_n : od;
+  if (!f3d::make_geo(&gi, iw, ih, id, axis == 2 ? slab_in : slab, who)) return 1;
+  if (g.z_lo == g.z_hi) return 0;
+  if (axis == 2) {
+    // output plane z reads input planes [floor(z*delta), ceil((z+1)*delta)) -- check the container holds them
+    const float delta = static_cast<float>(in_n) / static_cast<float>(od);
+    const int lo = static_cast<int>(floorf(static_cast<float>(g.z_lo) * delta));
+    int hi = static_cast<int>(ceilf(static_cast<float>(g.z_hi) * delta));
+    if (hi > static_cast<int>(in_n)) hi = static_cast<int>(in_n);
+    if (!planes_inside(gi, lo, hi, who)) return 1;
+  }
+  const dim3 grid = grid_for(g.W, g.H, g.z_hi - g.z_lo), block(kBX, kBY, 1);
+  const float* in = f3d_ptr<const float>(input);
+  float* out = f3d_ptr<float>(output);
+  const int n = static_cast<int>(in_n);
+  if (axis == 0) hipLaunchKernelGGL(k_resample<0>, grid, block, 0, f3d::stream(), in, out, gi, g, n);
+  if (axis == 1) hipLaunchKernelGGL(k_resample<1>, grid, block, 0, f3d::stream(), in, out, gi, g, n);
+  if (axis == 2) hipLaunchKernelGGL(k_resample<2>, grid, block, 0, f3d::stream(), in, out, gi, g, n);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_resample_x(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_width, const f3d_slab* slab)
+{
+  return resample_launch(0, input, output, out_width, out_height, out_depth, in_width, nullptr, slab, "f3d_resample_x");
+}
+
+int f3d_resample_y(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_height, const f3d_slab* slab)
+{
+  return resample_launch(1, input, output, out_width, out_height, out_depth, in_height, nullptr, slab, "f3d_resample_y");
+}
+
+int f3d_resample_z(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_depth, const f3d_slab* slab_in, const f3d_slab* slab)
+{
+  return resample_launch(2, input, output, out_width, out_height, out_depth, in_depth, slab_in, slab, "f3d_resample_z");
+}
+
+int f3d_add(f3d_devptr operand_0, f3d_devptr operand_1, size_t width, size_t height, size_t depth, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_add");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_add")) return 1;
+  if (g.z_lo == g.z_hi) return 0;
+  hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, g.z_hi - g.z_lo), dim3(kBX, kBY, 1), 0, f3d::stream(),
+                     f3d_ptr<float>(operand_0), f3d_ptr<const float>(operand_1), g);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+static int conv_launch(int axis, f3d_devptr dst, f3d_devptr src, size_t w, size_t h, size_t d, size_t radius,
+                       const f3d_slab* slab, const char* who)
+{
+  F3D_REQUIRE_READY(who);
+  if (same_buffer(dst, src, who)) return 1;
+  const f3d::ConvTaps& taps = f3d::conv_taps();
+  if (taps.count != static_cast<int>(2 * radius + 1))
+    return f3d::fail("%s: radius %zu does not match the %d taps uploaded with f3d_set_conv_taps", who, radius, taps.count);
+  F3dGeo g;
+  if (!f3d::make_geo(&g, w, h, d, slab, who)) return 1;
+  if (g.z_lo == g.z_hi) return 0;
+  if (axis == 2) {
+    const int r = static_cast<int>(radius);
+    if (!planes_inside(g, g.z_lo - r < 0 ? 0 : g.z_lo - r, g.z_hi + r > g.D ? g.D : g.z_hi + r, who)) return 1;
+  }
+  const dim3 grid = grid_for(g.W, g.H, g.z_hi - g.z_lo), block(kBX, kBY, 1);
+  float* o = f3d_ptr<float>(dst);
+  const float* s = f3d_ptr<const float>(src);
+  const int r = static_cast<int>(radius);
+  if (axis == 0) hipLaunchKernelGGL(k_conv<0>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
+  if (axis == 1) hipLaunchKernelGGL(k_conv<1>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
+  if (axis == 2) hipLaunchKernelGGL(k_conv<2>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_conv_rows(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                  const f3d_slab* slab)
+{
+  return conv_launch(0, dst, src, width, height, depth, kernel_radius, slab, "f3d_conv_rows");
+}
+
+int f3d_conv_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                  const f3d_slab* slab)
+{
+  return conv_launch(1, dst, src, width, height, depth, kernel_radius, slab, "f3d_conv_cols");
+}
+
+int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                    const f3d_slab* slab)
+{
+  return conv_launch(2, dst, src, width, height, depth, kernel_radius, slab, "f3d_conv_slices");
+}
+
+int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result)
+{
+  F3D_REQUIRE_READY("f3d_abs_max");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_abs_max")) return 1;
+  static unsigned* d_result = nullptr;
+  if (!d_result) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_result), sizeof(unsigned)));
+  F3D_HIP(hipMemsetAsync(d_result, 0, sizeof(unsigned), f3d::stream()));
+  if (g.z_hi > g.z_lo) {
+    const int gy = g.H < 64 ? g.H : 64;
+    hipLaunchKernelGGL(k_abs_max, dim3(1, gy, g.z_hi - g.z_lo), dim3(256, 1, 1), 0, f3d::stream(),
+                       f3d_ptr<const float>(field), g, d_result);
+    F3D_HIP(hipGetLastError());
+  }
+  unsigned bits = 0;
+  F3D_HIP(hipMemcpyAsync(&bits, d_result, sizeof(unsigned), hipMemcpyDeviceToHost, f3d::stream()));
+  F3D_HIP(hipStreamSynchronize(f3d::stream()));
+  std::memcpy(result, &bits, sizeof(float));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+#include "hip_utils.h"
+
+bool InitDeviceContextWithFirstAvailableDevice()
+{
+  int count = 0;
+  if (CheckDeviceError(f3d_device_count(&count))) return false;
+  if (count == 0) {
+    std::printf("There are no HIP capable devices.");
+    return false;
+  }
+  if (CheckDeviceError(f3d_init(-1))) return false;
+  char name[128];
+  if (CheckDeviceError(f3d_device_name(name, sizeof(name)))) return false;
+  std::printf("HIP Device: %s. Launch timeout: %s\n", name, "No");
+  return true;
+}
+
+void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_height, size_t device_pitch)
+{
+  CheckDeviceError(f3d_copy3d_h2d(device_ptr, device_pitch, device_height, 0, data3d.DataPtr(), data3d.Width(),
+                                  data3d.Height(), data3d.Depth()));
+}
+
+void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_height, size_t device_pitch)
+{
+  CheckDeviceError(f3d_copy3d_d2h(data3d.DataPtr(), data3d.Width(), data3d.Height(), data3d.Depth(), device_ptr,
+                                  device_pitch, device_height, 0));
+}

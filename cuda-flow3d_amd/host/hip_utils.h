@@ -1,0 +1,28 @@
+// Device helpers of the host side: error reporting convention, context bring-up and the dense-host <->
+// pitched-device volume copies (behaviour of src/utils/cuda_utils.{h,cpp} on top of the f3d C ABI).
+#ifndef F3D_HOST_HIP_UTILS_H_
+#define F3D_HOST_HIP_UTILS_H_
+
+#include <cstdio>
+
+#include "data_types.h"
+#include "f3d.h"
+
+// Same convention as the reference's CheckCudaError (src/utils/cuda_utils.h:26-46): prints to stderr and
+// returns TRUE ON ERROR, so callers write `if (!CheckDeviceError(call)) { ...ok... }`.
+#define CheckDeviceError(status) CheckDeviceErrorAt((status), __FILE__, __LINE__)
+inline bool CheckDeviceErrorAt(int status, const char* file, int line)
+{
+  if (status != 0) {
+    std::fprintf(stderr, "Device API error = %04d\n%s\n from file <%s>, line %i.\n", status, f3d_last_error(), file, line);
+    return true;
+  }
+  return false;
+}
+
+// cuda_utils.cpp:21-57: pick the first device, print its name, create the context.
+bool InitDeviceContextWithFirstAvailableDevice();
+void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_height, size_t device_pitch);
+void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_height, size_t device_pitch);
+
+#endif

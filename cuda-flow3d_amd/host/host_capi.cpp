@@ -1,0 +1,260 @@
+// C ABI of the host side (include/f3d_host.h): thin, exception-free wrappers over the C++ classes.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "f3d_host.h"
+#include "hip_utils.h"
+#include "operations.h"
+#include "optical_flow.h"
+#include "synth.h"
+
+struct f3d_flow_s {
+  OpticalFlowE driver;
+  bool device_ready = false;
+};
+
+struct f3d_op_s {
+  CudaOperationBase* op = nullptr;
+  ~f3d_op_s() { delete op; }
+};
+
+namespace {
+
+void FillBag(OperationParameters& bag, f3d_flow_params& p)
+{
+  bag.PushValuePtr("warp_levels_count", &p.warp_levels_count);
+  bag.PushValuePtr("warp_scale_factor", &p.warp_scale_factor);
+  bag.PushValuePtr("outer_iterations_count", &p.outer_iterations_count);
+  bag.PushValuePtr("inner_iterations_count", &p.inner_iterations_count);
+  bag.PushValuePtr("equation_alpha", &p.equation_alpha);
+  bag.PushValuePtr("equation_smoothness", &p.equation_smoothness);
+  bag.PushValuePtr("equation_data", &p.equation_data);
+  bag.PushValuePtr("median_radius", &p.median_radius);
+  bag.PushValuePtr("gaussian_sigma", &p.gaussian_sigma);
+}
+
+}  // namespace
+
+extern "C" {
+
+void f3d_flow_default_params(f3d_flow_params* p)
+{
+  p->warp_levels_count = 40;
+  p->warp_scale_factor = 0.95f;
+  p->outer_iterations_count = 40;
+  p->inner_iterations_count = 5;
+  p->equation_alpha = 7.5f;
+  p->equation_smoothness = 0.001f;
+  p->equation_data = 0.001f;
+  p->median_radius = 5;
+  p->gaussian_sigma = 2.0f;
+}
+
+int f3d_flow_create(f3d_flow* flow)
+{
+  if (!flow) return 1;
+  *flow = new (std::nothrow) f3d_flow_s;
+  return *flow ? 0 : 1;
+}
+
+int f3d_flow_initialize(f3d_flow flow, size_t width, size_t height, size_t depth)
+{
+  if (!flow) return 1;
+  if (f3d_init(-1) != 0) {
+    std::fprintf(stderr, "f3d_flow_initialize: %s\n", f3d_last_error());
+    return 1;
+  }
+  DataSize4 size = {width, height, depth, 0};
+  return flow->driver.Initialize(size) ? 0 : 1;
+}
+
+int f3d_flow_compute(f3d_flow flow, const float* frame_0, const float* frame_1, const f3d_flow_params* params,
+                     int silent, float* u, float* v, float* w)
+{
+  if (!flow || !frame_0 || !frame_1 || !params || !u || !v || !w) return 1;
+  const DataSize4& c = flow->driver.ContainerSize();
+  Data3D f0(const_cast<float*>(frame_0), c.width, c.height, c.depth);
+  Data3D f1(const_cast<float*>(frame_1), c.width, c.height, c.depth);
+  Data3D fu(u, c.width, c.height, c.depth), fv(v, c.width, c.height, c.depth), fw(w, c.width, c.height, c.depth);
+  f3d_flow_params p = *params;
+  OperationParameters bag;
+  FillBag(bag, p);
+  flow->driver.silent = silent != 0;
+  flow->driver.ComputeFlow(f0, f1, fu, fv, fw, bag);
+  return 0;
+}
+
+int f3d_flow_upload(f3d_flow flow, const float* frame_0, const float* frame_1)
+{
+  if (!flow || !frame_0 || !frame_1) return 1;
+  const DataSize4& c = flow->driver.ContainerSize();
+  Data3D f0(const_cast<float*>(frame_0), c.width, c.height, c.depth);
+  Data3D f1(const_cast<float*>(frame_1), c.width, c.height, c.depth);
+  if (!flow->driver.AllocateResidentFrames()) return 1;
+  flow->driver.UploadResidentFrames(f0, f1);
+  return 0;
+}
+
+int f3d_flow_compute_resident(f3d_flow flow, const f3d_flow_params* params, int silent, float* device_seconds)
+{
+  if (!flow || !params) return 1;
+  f3d_flow_params p = *params;
+  OperationParameters bag;
+  FillBag(bag, p);
+  flow->driver.silent = silent != 0;
+  flow->driver.ComputeFlowResident(bag);
+  if (device_seconds) *device_seconds = flow->driver.LastDeviceSeconds();
+  return 0;
+}
+
+int f3d_flow_download(f3d_flow flow, float* u, float* v, float* w)
+{
+  if (!flow || !u || !v || !w) return 1;
+  const DataSize4& c = flow->driver.ContainerSize();
+  Data3D fu(u, c.width, c.height, c.depth), fv(v, c.width, c.height, c.depth), fw(w, c.width, c.height, c.depth);
+  flow->driver.DownloadFlow(fu, fv, fw);
+  return 0;
+}
+
+int f3d_flow_container(f3d_flow flow, f3d_size4* container)
+{
+  if (!flow || !container) return 1;
+  const DataSize4& c = flow->driver.ContainerSize();
+  *container = {c.width, c.height, c.depth, c.pitch};
+  return 0;
+}
+
+int f3d_flow_destroy(f3d_flow flow)
+{
+  delete flow;
+  return 0;
+}
+
+int f3d_op_create(f3d_op* op, const char* name)
+{
+  if (!op || !name) return 1;
+  const std::string n(name);
+  CudaOperationBase* impl = nullptr;
+  if (n == "add") impl = new CudaOperationAdd;
+  else if (n == "convolution") impl = new CudaOperationConvolution3D;
+  else if (n == "median") impl = new CudaOperationMedian;
+  else if (n == "registration") impl = new CudaOperationRegistration;
+  else if (n == "resample") impl = new CudaOperationResample;
+  else if (n == "solve") impl = new CudaOperationSolve;
+  if (!impl) return 1;
+  *op = new f3d_op_s;
+  (*op)->op = impl;
+  return 0;
+}
+
+const char* f3d_op_name(f3d_op op) { return op ? op->op->GetName() : ""; }
+
+int f3d_op_initialize(f3d_op op, const f3d_size4* container_size)
+{
+  if (!op) return 1;
+  if (!container_size) return op->op->Initialize(nullptr) ? 0 : 1;
+  DataSize4 c = {container_size->width, container_size->height, container_size->depth, container_size->pitch};
+  OperationParameters bag;
+  bag.PushValuePtr("container_size", &c);
+  return op->op->Initialize(&bag) ? 0 : 1;
+}
+
+int f3d_op_execute(f3d_op op, const char* const* keys, void* const* value_ptrs, size_t count)
+{
+  if (!op) return 1;
+  OperationParameters bag;
+  for (size_t i = 0; i < count; ++i) bag.PushValuePtr(keys[i], value_ptrs[i]);
+  if (auto* solve = dynamic_cast<CudaOperationSolve*>(op->op)) solve->silent = true;
+  op->op->Execute(bag);
+  return 0;
+}
+
+int f3d_op_set_slab(f3d_op op, const f3d_slab* slab)
+{
+  if (!op) return 1;
+  op->op->SetSlab(slab);
+  return 0;
+}
+
+int f3d_op_destroy(f3d_op op)
+{
+  if (op) op->op->Destroy();
+  delete op;
+  return 0;
+}
+
+size_t f3d_max_warp_level(size_t width, size_t height, size_t depth, float scale_factor)
+{
+  return OpticalFlowBase::GetMaxWarpLevel(width, height, depth, scale_factor);
+}
+
+int f3d_level_geometry(size_t width, size_t height, size_t depth, float scale_factor, int level, f3d_size4* size,
+                       float* hx, float* hy, float* hz)
+{
+  if (!size || !hx || !hy || !hz) return 1;
+  DataSize4 original = {width, height, depth, 0};
+  PyramidLevel lv = OpticalFlowBase::GetLevel(original, scale_factor, level);
+  *size = {lv.size.width, lv.size.height, lv.size.depth, 0};
+  *hx = lv.hx;
+  *hy = lv.hy;
+  *hz = lv.hz;
+  return 0;
+}
+
+int f3d_gaussian_taps(float sigma, float* taps, size_t capacity, size_t* radius)
+{
+  if (!taps || !radius) return 1;
+  CudaOperationConvolution3D conv;
+  conv.ComputeGaussianKernel(sigma, 3, 1.0);
+  const size_t n = 2 * conv.KernelRadius() + 1;
+  if (n > capacity || n > 51) return 1;
+  std::memcpy(taps, conv.Kernel(), n * sizeof(float));
+  *radius = conv.KernelRadius();
+  return 0;
+}
+
+int f3d_raw_read_u8(const char* path, size_t width, size_t height, size_t depth, float* out)
+{
+  Data3D vol;
+  if (!vol.ReadRAWFromFileU8(path, width, height, depth)) return 1;
+  std::memcpy(out, vol.DataPtr(), width * height * depth * sizeof(float));
+  return 0;
+}
+
+int f3d_raw_read_f32(const char* path, size_t width, size_t height, size_t depth, float* out)
+{
+  Data3D vol;
+  if (!vol.ReadRAWFromFileF32(path, width, height, depth)) return 1;
+  std::memcpy(out, vol.DataPtr(), width * height * depth * sizeof(float));
+  return 0;
+}
+
+int f3d_raw_write_u8(const char* path, const float* in, size_t width, size_t height, size_t depth)
+{
+  Data3D vol(const_cast<float*>(in), width, height, depth);
+  return vol.WriteRAWToFileU8(path) ? 0 : 1;
+}
+
+int f3d_raw_write_f32(const char* path, const float* in, size_t width, size_t height, size_t depth)
+{
+  Data3D vol(const_cast<float*>(in), width, height, depth);
+  return vol.WriteRAWToFileF32(path) ? 0 : 1;
+}
+
+int f3d_vtk_write_flow(const char* path, const float* u, const float* v, const float* w, size_t width, size_t height,
+                       size_t depth)
+{
+  Data3D fu(const_cast<float*>(u), width, height, depth), fv(const_cast<float*>(v), width, height, depth),
+      fw(const_cast<float*>(w), width, height, depth);
+  return Data3D::WriteFlowToFileVTK(path, fu, fv, fw) ? 0 : 1;
+}
+
+int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, float* frame_1)
+{
+  if (!frame_0 || !frame_1 || width == 0 || height == 0 || depth == 0) return 1;
+  f3d_synth::TranslatedGaussianPair(width, height, depth, frame_0, frame_1);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Host side of the six operators.  Parameter keys, argument meaning, sanity rules and the print-and-return
+// error convention follow src/cuda_operations/entire_data/cuda_operation_*.cpp; every device action goes
+// through the f3d C ABI.  Unlike the reference the solver does not synchronise the stream after every
+// sweep (cuda_operation_solve.cpp:257): launches are queued back to back and the progress bar, when enabled,
+// is refreshed once per outer iteration.
+#include "operations.h"
+
+#include <cmath>
+#include <cstdio>
+#include <utility>
+
+#include "common_utils.h"
+#include "hip_utils.h"
+
+// ---- base ------------------------------------------------------------------------------------------------
+
+bool CudaOperationBase::IsInitialized() const
+{
+  if (!initialized_) std::printf("Error: Operation '%s' was not initialized.\n", name_);
+  return initialized_;
+}
+
+void CudaOperationBase::Execute(OperationParameters&)
+{
+  std::printf("Warning: '%s' Execute() was not defined.\n", name_);
+}
+
+void CudaOperationBase::Destroy() { initialized_ = false; }
+
+CudaOperationBase::~CudaOperationBase()
+{
+  if (initialized_) Destroy();
+}
+
+bool CudaOperationBase::InitializeContainer(const OperationParameters* params)
+{
+  initialized_ = false;
+  if (!params) {
+    std::printf("Operation: '%s'. Initialization parameters are missing.\n", GetName());
+    return initialized_;
+  }
+  DataSize4 container_size;
+  GET_PARAM_OR_RETURN_VALUE(*params, DataSize4, container_size, "container_size", initialized_);
+  dev_container_size_ = container_size;
+  f3d_size4 c = {container_size.width, container_size.height, container_size.depth, container_size.pitch};
+  if (!CheckDeviceError(f3d_set_container(&c))) initialized_ = true;
+  return initialized_;
+}
+
+// ---- add (cuda_operation_add.cpp:67-100) -----------------------------------------------------------------
+
+void CudaOperationAdd::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr operand_0, operand_1;
+  DataSize4 data_size;
+  GET_PARAM_OR_RETURN(params, DevicePtr, operand_0, "operand_0");
+  GET_PARAM_OR_RETURN(params, DevicePtr, operand_1, "operand_1");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  CheckDeviceError(f3d_add(operand_0, operand_1, data_size.width, data_size.height, data_size.depth, slab_));
+}
+
+// ---- Gaussian (cuda_operation_convolution.cpp:85-114, 134-184) -----------------------------------------------
+
+void CudaOperationConvolution3D::ComputeGaussianKernel(float sigma, size_t precision, float pixel_size)
+{
+  kernel_radius_ = static_cast<size_t>(precision * sigma / pixel_size);
+  kernel_length_ = 2 * kernel_radius_ + 1;
+  if (kernel_length_ > kMaxKernelLength) {
+    std::printf("Operation '%s': Gaussian radius %zu exceeds the supported %zu taps.\n", GetName(), kernel_radius_,
+                kMaxKernelLength);
+    kernel_length_ = 0;
+    return;
+  }
+  const int r = static_cast<int>(kernel_radius_);
+  // double-precision evaluation, pi truncated to 3.1415926, one rounding to float per tap (reference :93-96)
+  const double norm = 1.0 / (sigma * std::sqrt(2.0 * 3.1415926));
+  for (int i = -r; i <= r; ++i) {
+    const float dist2 = i * i * pixel_size * pixel_size;
+    kernel_[i + r] = static_cast<float>(norm * std::exp(-dist2 / (2.0 * sigma * sigma)));
+  }
+  float sum = 0.0f;  // normalised by the FLOAT sum
+  for (size_t i = 0; i < kernel_length_; ++i) sum = sum + kernel_[i];
+  for (size_t i = 0; i < kernel_length_; ++i) kernel_[i] = kernel_[i] / sum;
+}
+
+void CudaOperationConvolution3D::PrintConvolutionKernel() const
+{
+  if (kernel_length_ == 0) {
+    std::printf("Error: Convolution kernel is not initialized.\n");
+    return;
+  }
+  std::printf("Convolution kernel (radius = %zu)\n", kernel_radius_);
+  for (size_t i = 0; i < kernel_length_; ++i) std::printf("%.4f ", kernel_[i]);
+  std::printf("\n\n");
+}
+
+void CudaOperationConvolution3D::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr dev_input = 0, dev_output = 0, dev_temp = 0;
+  DataSize4 data_size;
+  float gaussian_sigma;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_input, "dev_input");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_output, "dev_output");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_temp, "dev_temp");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, float, gaussian_sigma, "gaussian_sigma");
+  if (dev_input == dev_output) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  ComputeGaussianKernel(gaussian_sigma, 3, 1.0);
+  if (kernel_length_ == 0) return;
+  if (CheckDeviceError(f3d_set_conv_taps(kernel_, kernel_length_))) return;
+  const size_t w = data_size.width, h = data_size.height, d = data_size.depth, r = kernel_radius_;
+  // rows: input -> output, columns: output -> temp, slices: temp -> output (reference :172-181)
+  if (CheckDeviceError(f3d_conv_rows(dev_output, dev_input, w, h, d, r, slab_))) return;
+  if (CheckDeviceError(f3d_conv_cols(dev_temp, dev_output, w, h, d, r, slab_))) return;
+  CheckDeviceError(f3d_conv_slices(dev_output, dev_temp, w, h, d, r, slab_));
+}
+
+// ---- median (cuda_operation_median.cpp:72-149) ------------------------------------------------------------
+
+void CudaOperationMedian::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr dev_input, dev_output;
+  DataSize4 data_size;
+  size_t radius;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_input, "dev_input");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_output, "dev_output");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, size_t, radius, "radius");
+  if (dev_input == dev_output) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  if (radius == 1) {  // nothing to filter: copy the whole container
+    CheckDeviceError(f3d_copy_d2d(dev_output, dev_input,
+                                  dev_container_size_.pitch * dev_container_size_.height * dev_container_size_.depth));
+    return;
+  }
+  if (radius % 2 == 0) {
+    std::printf("Warning. Median raduis is even (%zu), decresaing by 1...\n", radius);
+    radius -= 1;
+  }
+  if (radius >= 3 && radius <= 7) {
+    CheckDeviceError(f3d_median(dev_input, data_size.width, data_size.height, data_size.depth, radius, dev_output, slab_));
+  } else {
+    std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", radius);
+  }
+}
+
+// ---- warp (cuda_operation_registration.cpp:70-131) ----------------------------------------------------------
+
+void CudaOperationRegistration::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, dev_output;
+  float hx, hy, hz;
+  DataSize4 data_size;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_frame_0, "dev_frame_0");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_frame_1, "dev_frame_1");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_u, "dev_flow_u");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_v, "dev_flow_v");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_w, "dev_flow_w");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_output, "dev_output");
+  GET_PARAM_OR_RETURN(params, float, hx, "hx");
+  GET_PARAM_OR_RETURN(params, float, hy, "hy");
+  GET_PARAM_OR_RETURN(params, float, hz, "hz");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  if (dev_frame_1 == dev_output) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  CheckDeviceError(f3d_warp(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, data_size.width,
+                            data_size.height, data_size.depth, hx, hy, hz, dev_output, slab_));
+}
+
+// ---- resample (cuda_operation_resample.cpp:72-175) ----------------------------------------------------------
+
+void CudaOperationResample::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr dev_input = 0, dev_output = 0, dev_temp = 0;
+  DataSize4 data_size, resample_size;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_input, "dev_input");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_output, "dev_output");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_temp, "dev_temp");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, DataSize4, resample_size, "resample_size");
+  if (dev_input == dev_output) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  // each pass shrinks/grows one axis; its grid spans the already-resampled axes at the new size and the
+  // remaining ones at the old size
+  DataSize4 pass_out = data_size;
+  pass_out.width = resample_size.width;
+  ResampleX(dev_input, dev_output, data_size, pass_out);
+  data_size.width = pass_out.width;
+  pass_out.height = resample_size.height;
+  ResampleY(dev_output, dev_temp, data_size, pass_out);
+  data_size.height = pass_out.height;
+  pass_out.depth = resample_size.depth;
+  ResampleZ(dev_temp, dev_output, data_size, pass_out);
+}
+
+void CudaOperationResample::ResampleX(DevicePtr input, DevicePtr output, DataSize4& in, DataSize4& out) const
+{
+  CheckDeviceError(f3d_resample_x(input, output, out.width, out.height, out.depth, in.width, slab_));
+}
+
+void CudaOperationResample::ResampleY(DevicePtr input, DevicePtr output, DataSize4& in, DataSize4& out) const
+{
+  CheckDeviceError(f3d_resample_y(input, output, out.width, out.height, out.depth, in.height, slab_));
+}
+
+void CudaOperationResample::ResampleZ(DevicePtr input, DevicePtr output, DataSize4& in, DataSize4& out) const
+{
+  CheckDeviceError(f3d_resample_z(input, output, out.width, out.height, out.depth, in.depth, nullptr, slab_));
+}
+
+// ---- solve (cuda_operation_solve.cpp:75-281) ------------------------------------------------------------------
+
+void CudaOperationSolve::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+
+  DevicePtr dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, dev_phi, dev_ksi;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_frame_0, "dev_frame_0");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_frame_1, "dev_frame_1");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_u, "dev_flow_u");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_v, "dev_flow_v");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_w, "dev_flow_w");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_phi, "dev_phi");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_ksi, "dev_ksi");
+
+  // increments and their ping-pong partners are read BY POINTER so the caller sees the final roles
+  DevicePtr *du_ptr, *dv_ptr, *dw_ptr, *tdu_ptr, *tdv_ptr, *tdw_ptr;
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, du_ptr, "dev_flow_du");
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, dv_ptr, "dev_flow_dv");
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, dw_ptr, "dev_flow_dw");
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, tdu_ptr, "dev_temp_du");
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, tdv_ptr, "dev_temp_dv");
+  GET_PARAM_PTR_OR_RETURN(params, DevicePtr, tdw_ptr, "dev_temp_dw");
+
+  size_t outer_iterations_count, inner_iterations_count;
+  float equation_alpha, equation_smoothness, equation_data, hx, hy, hz;
+  DataSize4 data_size;
+  GET_PARAM_OR_RETURN(params, size_t, outer_iterations_count, "outer_iterations_count");
+  GET_PARAM_OR_RETURN(params, size_t, inner_iterations_count, "inner_iterations_count");
+  GET_PARAM_OR_RETURN(params, float, equation_alpha, "equation_alpha");
+  GET_PARAM_OR_RETURN(params, float, equation_smoothness, "equation_smoothness");
+  GET_PARAM_OR_RETURN(params, float, equation_data, "equation_data");
+  GET_PARAM_OR_RETURN(params, float, hx, "hx");
+  GET_PARAM_OR_RETURN(params, float, hy, "hy");
+  GET_PARAM_OR_RETURN(params, float, hz, "hz");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+
+  f3d_event ev_start = nullptr, ev_stop = nullptr;
+  if (!silent) {
+    CheckDeviceError(f3d_event_create(&ev_start));
+    CheckDeviceError(f3d_event_create(&ev_stop));
+    CheckDeviceError(f3d_event_record(ev_start));
+    Utils::PrintProgressBar(0.f);
+    std::printf(" % 3.0f%%", 0.f);
+  }
+
+  // increments start from zero at every level: current width, every row of the container (reference :183-188)
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  const size_t row_bytes = data_size.width * sizeof(float);
+  CheckDeviceError(f3d_memset2d(*du_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
+  CheckDeviceError(f3d_memset2d(*dv_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
+  CheckDeviceError(f3d_memset2d(*dw_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
+
+  const size_t w = data_size.width, h = data_size.height, d = data_size.depth;
+  for (size_t i = 0; i < outer_iterations_count; ++i) {
+    if (CheckDeviceError(f3d_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr,
+                                     *dw_ptr, w, h, d, hx, hy, hz, equation_smoothness, equation_data, dev_phi,
+                                     dev_ksi, slab_)))
+      return;
+    for (size_t j = 0; j < inner_iterations_count; ++j) {
+      if (CheckDeviceError(f3d_solve_sweep(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr,
+                                           *dv_ptr, *dw_ptr, dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha,
+                                           *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_)))
+        return;
+      std::swap(*du_ptr, *tdu_ptr);
+      std::swap(*dv_ptr, *tdv_ptr);
+      std::swap(*dw_ptr, *tdw_ptr);
+    }
+    if (!silent) {
+      CheckDeviceError(f3d_stream_sync());
+      const float complete = static_cast<float>(i + 1) / static_cast<float>(outer_iterations_count);
+      Utils::PrintProgressBar(complete);
+      std::printf(" % 3.0f%%", complete * 100);
+    }
+  }
+
+  if (!silent) {
+    float elapsed_ms = 0.f;
+    CheckDeviceError(f3d_event_record(ev_stop));
+    CheckDeviceError(f3d_event_sync(ev_stop));
+    CheckDeviceError(f3d_event_elapsed_ms(&elapsed_ms, ev_start, ev_stop));
+    Utils::PrintProgressBar(1.f);
+    std::printf(" %8.4fs\n", elapsed_ms / 1000.);
+    f3d_event_destroy(ev_start);
+    f3d_event_destroy(ev_stop);
+  }
+}

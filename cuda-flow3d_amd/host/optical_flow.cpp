@@ -1,0 +1,465 @@
+// Coarse-to-fine driver.  Sequence of operations, buffer counts, parameter keys and console lines follow
+// OpticalFlowE::ComputeFlow (src/optical_flow/optical_flow_e.cpp:132-601) and OpticalFlowBase
+// (src/optical_flow/optical_flow_base.cpp); the code is organised around a container pool and one
+// RunPyramid() shared by the host-volume entry point and the device-resident one.
+#include "optical_flow.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "common_utils.h"
+#include "hip_utils.h"
+
+// ---- base --------------------------------------------------------------------------------------------------
+
+size_t OpticalFlowBase::GetMaxWarpLevel(size_t width, size_t height, size_t depth, float scale_factor)
+{
+  // count levels while every axis of ceil(dim * sf^level) keeps at least 4 voxels (optical_flow_base.cpp:31-56)
+  size_t rw = 1, rh = 1, rd = 1;
+  size_t level_counter = 1;
+  while (scale_factor < 1.f) {
+    const float scale = std::pow(scale_factor, static_cast<float>(level_counter));
+    rw = static_cast<size_t>(std::ceil(width * scale));
+    rh = static_cast<size_t>(std::ceil(height * scale));
+    rd = static_cast<size_t>(std::ceil(depth * scale));
+    if (rw < 4 || rh < 4 || rd < 4) break;
+    ++level_counter;
+  }
+  if (rw == 1 || rh == 1 || rd == 1) --level_counter;
+  return level_counter;
+}
+
+PyramidLevel OpticalFlowBase::GetLevel(const DataSize4& original, float scale_factor, int level)
+{
+  // optical_flow_e.cpp:262-268: float product, std::ceil, spacing = original / current
+  PyramidLevel out;
+  const float scale = std::pow(scale_factor, static_cast<float>(level));
+  out.size.width = static_cast<size_t>(std::ceil(original.width * scale));
+  out.size.height = static_cast<size_t>(std::ceil(original.height * scale));
+  out.size.depth = static_cast<size_t>(std::ceil(original.depth * scale));
+  out.size.pitch = 0;
+  out.hx = original.width / static_cast<float>(out.size.width);
+  out.hy = original.height / static_cast<float>(out.size.height);
+  out.hz = original.depth / static_cast<float>(out.size.depth);
+  return out;
+}
+
+bool OpticalFlowBase::IsInitialized() const
+{
+  if (!initialized_) std::printf("Error: '%s' was not initialized.\n", name_);
+  return initialized_;
+}
+
+void OpticalFlowBase::ComputeFlow(Data3D&, Data3D&, Data3D&, Data3D&, Data3D&, OperationParameters&)
+{
+  std::printf("Warning: '%s' ComputeFlow() was not defined.\n", name_);
+}
+
+void OpticalFlowBase::Destroy() { initialized_ = false; }
+
+OpticalFlowBase::~OpticalFlowBase() {}
+
+// ---- single-GPU driver ---------------------------------------------------------------------------------------
+
+OpticalFlowE::OpticalFlowE() : OpticalFlowBase("Optical Flow Single GPU")
+{
+  // same initialisation order as the reference's forward_list built with push_front (optical_flow_e.cpp:34-39)
+  cuda_operations_ = {&cuop_solve_, &cuop_resample_, &cuop_register_, &cuop_median_, &cuop_convolution_, &cuop_add_};
+}
+
+OpticalFlowE::~OpticalFlowE() { Destroy(); }
+
+bool OpticalFlowE::Initialize(const DataSize4& data_size)
+{
+  dev_container_size_ = data_size;
+  dev_container_size_.pitch = 0;
+  initialized_ = InitCudaMemory() && InitCudaOperations();
+  return initialized_;
+}
+
+bool OpticalFlowE::InitCudaMemory()
+{
+  std::printf("Allocating memory on the device...\n");
+  size_t free_memory = 0, total_memory = 0;
+  CheckDeviceError(f3d_mem_info(&free_memory, &total_memory));
+  const float mb = 1024.f * 1024.f;
+  std::printf("Available\t:\t%.0fMB / %.0fMB\n", free_memory / mb, total_memory / mb);
+
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  const size_t row_bytes = dev_container_size_.width * sizeof(float);
+  const size_t pitch_guess = (row_bytes + 255) / 256 * 256;
+  const size_t needed_memory = pitch_guess * rows * kContainers;
+  std::printf("Needed (approx.):\t%.0fMB\n", needed_memory / mb);
+  if (needed_memory >= free_memory) return false;
+
+  size_t allocated_memory = 0;
+  for (size_t i = 0; i < kContainers; ++i) {
+    DevicePtr container = 0;
+    size_t pitch = 0;
+    const bool error = CheckDeviceError(f3d_alloc_pitched(&container, &pitch, row_bytes, rows));
+    if (!error) free_containers_.push_back(container);
+    // every container must come back with the same pitch
+    if (error || (i != 0 && pitch != dev_container_size_.pitch)) {
+      std::printf("Error during device memory allocation.");
+      Destroy();
+      return false;
+    }
+    dev_container_size_.pitch = pitch;
+    allocated_memory += pitch * rows;
+  }
+  std::printf("Allocated\t:\t%.0fMB\n", allocated_memory / mb);
+  return true;
+}
+
+bool OpticalFlowE::InitCudaOperations()
+{
+  if (dev_container_size_.pitch == 0) {
+    std::printf("Initialization failed. Device pitch is 0.\n");
+    return false;
+  }
+  std::printf("Initialization of cuda operations...\n");
+  OperationParameters op;
+  op.PushValuePtr("container_size", &dev_container_size_);
+  for (CudaOperationBase* cuop : cuda_operations_) {
+    std::printf("%-18s: ", cuop->GetName());
+    if (!cuop->Initialize(&op)) {
+      Destroy();
+      return false;
+    }
+    std::printf("OK\n");
+  }
+  return true;
+}
+
+DevicePtr OpticalFlowE::Borrow()
+{
+  DevicePtr p = free_containers_.back();
+  free_containers_.pop_back();
+  return p;
+}
+
+void OpticalFlowE::GiveBack(DevicePtr p) { free_containers_.push_back(p); }
+
+void OpticalFlowE::ReleaseResult()
+{
+  for (DevicePtr& p : result_flow_) {
+    if (p) GiveBack(p);
+    p = 0;
+  }
+}
+
+bool OpticalFlowE::AllocateResidentFrames()
+{
+  if (!IsInitialized()) return false;
+  if (resident_frame_[0]) return true;
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  for (int i = 0; i < 2; ++i) {
+    size_t pitch = 0;
+    if (CheckDeviceError(f3d_alloc_pitched(&resident_frame_[i], &pitch, dev_container_size_.width * sizeof(float), rows)) ||
+        pitch != dev_container_size_.pitch)
+      return false;
+  }
+  return true;
+}
+
+void OpticalFlowE::UploadResidentFrames(Data3D& frame_0, Data3D& frame_1)
+{
+  if (!AllocateResidentFrames()) return;
+  CopyData3DtoDevice(frame_0, resident_frame_[0], dev_container_size_.height, dev_container_size_.pitch);
+  CopyData3DtoDevice(frame_1, resident_frame_[1], dev_container_size_.height, dev_container_size_.pitch);
+}
+
+void OpticalFlowE::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
+                               OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  if (frame_0.Width() != dev_container_size_.width || frame_0.Height() != dev_container_size_.height ||
+      frame_0.Depth() != dev_container_size_.depth || frame_1.Width() != frame_0.Width() ||
+      frame_1.Height() != frame_0.Height() || frame_1.Depth() != frame_0.Depth()) {
+    std::printf("Error: '%s'. Frame dimensions differ from the initialised container.\n", GetName());
+    return;
+  }
+  ReleaseResult();
+
+  // the reference's timer spans H2D .. D2H (optical_flow_e.cpp:169,579)
+  f3d_event ev_start = nullptr, ev_stop = nullptr;
+  CheckDeviceError(f3d_event_create(&ev_start));
+  CheckDeviceError(f3d_event_create(&ev_stop));
+  CheckDeviceError(f3d_event_record(ev_start));
+
+  DevicePtr raw_0 = Borrow(), raw_1 = Borrow();
+  CopyData3DtoDevice(frame_0, raw_0, dev_container_size_.height, dev_container_size_.pitch);
+  CopyData3DtoDevice(frame_1, raw_1, dev_container_size_.height, dev_container_size_.pitch);
+
+  if (RunPyramid(params, raw_0, raw_1, true)) {
+    DownloadFlow(flow_u, flow_v, flow_w);
+    float elapsed_ms = 0.f;
+    CheckDeviceError(f3d_event_record(ev_stop));
+    CheckDeviceError(f3d_event_sync(ev_stop));
+    CheckDeviceError(f3d_event_elapsed_ms(&elapsed_ms, ev_start, ev_stop));
+    std::printf("Total GPU computation time: % 4.4fs\n", elapsed_ms / 1000.);
+  } else {
+    GiveBack(raw_0);
+    GiveBack(raw_1);
+  }
+  ReleaseResult();
+  f3d_event_destroy(ev_start);
+  f3d_event_destroy(ev_stop);
+}
+
+void OpticalFlowE::ComputeFlowResident(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  if (!resident_frame_[0]) {
+    std::printf("Error: '%s'. Resident frames were not allocated.\n", GetName());
+    return;
+  }
+  ReleaseResult();
+  f3d_event ev_start = nullptr, ev_stop = nullptr;
+  CheckDeviceError(f3d_event_create(&ev_start));
+  CheckDeviceError(f3d_event_create(&ev_stop));
+  CheckDeviceError(f3d_event_record(ev_start));
+  if (RunPyramid(params, resident_frame_[0], resident_frame_[1], false)) {
+    float elapsed_ms = 0.f;
+    CheckDeviceError(f3d_event_record(ev_stop));
+    CheckDeviceError(f3d_event_sync(ev_stop));
+    CheckDeviceError(f3d_event_elapsed_ms(&elapsed_ms, ev_start, ev_stop));
+    last_device_seconds_ = elapsed_ms / 1000.f;
+  }
+  f3d_event_destroy(ev_start);
+  f3d_event_destroy(ev_stop);
+}
+
+void OpticalFlowE::DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w)
+{
+  if (!result_flow_[0]) return;
+  CopyData3DFromDevice(result_flow_[0], flow_u, dev_container_size_.height, dev_container_size_.pitch);
+  CopyData3DFromDevice(result_flow_[1], flow_v, dev_container_size_.height, dev_container_size_.pitch);
+  CopyData3DFromDevice(result_flow_[2], flow_w, dev_container_size_.height, dev_container_size_.pitch);
+}
+
+bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, DevicePtr raw_1, bool raw_is_pooled)
+{
+  size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
+  float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, warp_scale_factor, "warp_scale_factor", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, outer_iterations_count, "outer_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, inner_iterations_count, "inner_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_alpha, "equation_alpha", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_smoothness, "equation_smoothness", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_data, "equation_data", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, median_radius, "median_radius", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, gaussian_sigma, "gaussian_sigma", false);
+
+  if (!silent) std::printf("\nStarting optical flow computation...\n");
+
+  DataSize4 original = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
+  const size_t max_warp_level = GetMaxWarpLevel(original.width, original.height, original.depth, warp_scale_factor);
+  int level = static_cast<int>(std::min(warp_levels_count, max_warp_level)) - 1;
+
+  OperationParameters op;
+
+  // ---- pre-blur (optical_flow_e.cpp:213-242): full-size frames -> dev_frame_0/1 ------------------------------
+  DevicePtr dev_frame_0, dev_frame_1;
+  if (gaussian_sigma > 0.0) {
+    dev_frame_0 = Borrow();
+    dev_frame_1 = Borrow();
+    DevicePtr dev_temp = Borrow();
+    DevicePtr* src[2] = {&raw_0, &raw_1};
+    DevicePtr* dst[2] = {&dev_frame_0, &dev_frame_1};
+    for (int i = 0; i < 2; ++i) {
+      op.Clear();
+      op.PushValuePtr("dev_input", src[i]);
+      op.PushValuePtr("dev_output", dst[i]);
+      op.PushValuePtr("dev_temp", &dev_temp);
+      op.PushValuePtr("data_size", &original);
+      op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+      cuop_convolution_.Execute(op);
+    }
+    GiveBack(dev_temp);
+    if (raw_is_pooled) {
+      GiveBack(raw_0);
+      GiveBack(raw_1);
+    }
+  } else if (raw_is_pooled) {
+    dev_frame_0 = raw_0;
+    dev_frame_1 = raw_1;
+  } else {
+    dev_frame_0 = Borrow();
+    dev_frame_1 = Borrow();
+    const size_t bytes = dev_container_size_.pitch * dev_container_size_.height * dev_container_size_.depth;
+    CheckDeviceError(f3d_copy_d2d(dev_frame_0, raw_0, bytes));
+    CheckDeviceError(f3d_copy_d2d(dev_frame_1, raw_1, bytes));
+  }
+
+  DevicePtr dev_frame_0_res = Borrow(), dev_frame_1_res_br = Borrow();
+  DevicePtr dev_flow_u = Borrow(), dev_flow_v = Borrow(), dev_flow_w = Borrow();
+  DevicePtr dev_flow_du = Borrow(), dev_flow_dv = Borrow(), dev_flow_dw = Borrow();
+
+  DataSize4 prev_data_size = {0, 0, 0, 0};
+  if (level < 0) {  // no level requested: the flow is identically zero
+    const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+    for (DevicePtr p : {dev_flow_u, dev_flow_v, dev_flow_w})
+      CheckDeviceError(f3d_memset2d(p, dev_container_size_.pitch, 0, dev_container_size_.width * sizeof(float), rows));
+  }
+
+  auto resample = [&](DevicePtr& in, DevicePtr& out, DataSize4& from, DataSize4& to) {
+    DevicePtr dev_temp = Borrow();
+    op.Clear();
+    op.PushValuePtr("dev_input", &in);
+    op.PushValuePtr("dev_output", &out);
+    op.PushValuePtr("dev_temp", &dev_temp);
+    op.PushValuePtr("data_size", &from);
+    op.PushValuePtr("resample_size", &to);
+    cuop_resample_.Execute(op);
+    GiveBack(dev_temp);
+  };
+
+  while (level >= 0) {
+    PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
+    DataSize4 current = lv.size;
+    float hx = lv.hx, hy = lv.hy, hz = lv.hz;
+    if (!silent)
+      std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", level, current.width, current.height, current.depth);
+
+    // frames of this level: always resampled from the ORIGINAL-size blurred frames (:274-300)
+    if (level == 0) {
+      std::swap(dev_frame_0, dev_frame_0_res);
+      std::swap(dev_frame_1, dev_frame_1_res_br);
+    } else {
+      resample(dev_frame_0, dev_frame_0_res, original, current);
+      resample(dev_frame_1, dev_frame_1_res_br, original, current);
+    }
+
+    // flow of the previous level brought to this size; values stay in original-voxel units (:303-345)
+    if (prev_data_size.width == 0) {
+      const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+      const size_t row_bytes = dev_container_size_.width * sizeof(float);
+      CheckDeviceError(f3d_memset2d(dev_flow_u, dev_container_size_.pitch, 0, row_bytes, rows));
+      CheckDeviceError(f3d_memset2d(dev_flow_v, dev_container_size_.pitch, 0, row_bytes, rows));
+      CheckDeviceError(f3d_memset2d(dev_flow_w, dev_container_size_.pitch, 0, row_bytes, rows));
+    } else {
+      resample(dev_flow_u, dev_flow_du, prev_data_size, current);
+      resample(dev_flow_v, dev_flow_dv, prev_data_size, current);
+      resample(dev_flow_w, dev_flow_dw, prev_data_size, current);
+      std::swap(dev_flow_u, dev_flow_du);
+      std::swap(dev_flow_v, dev_flow_dv);
+      std::swap(dev_flow_w, dev_flow_dw);
+    }
+
+    // backward registration of frame 1 with the current flow (:348-369)
+    {
+      DevicePtr dev_temp = Borrow();
+      op.Clear();
+      op.PushValuePtr("dev_frame_0", &dev_frame_0_res);
+      op.PushValuePtr("dev_frame_1", &dev_frame_1_res_br);
+      op.PushValuePtr("dev_flow_u", &dev_flow_u);
+      op.PushValuePtr("dev_flow_v", &dev_flow_v);
+      op.PushValuePtr("dev_flow_w", &dev_flow_w);
+      op.PushValuePtr("dev_output", &dev_temp);
+      op.PushValuePtr("data_size", &current);
+      op.PushValuePtr("hx", &hx);
+      op.PushValuePtr("hy", &hy);
+      op.PushValuePtr("hz", &hz);
+      cuop_register_.Execute(op);
+      std::swap(dev_frame_1_res_br, dev_temp);
+      GiveBack(dev_temp);
+    }
+
+    // difference problem: increments du, dv, dw (:372-417)
+    {
+      DevicePtr dev_phi = Borrow(), dev_ksi = Borrow();
+      DevicePtr dev_temp_du = Borrow(), dev_temp_dv = Borrow(), dev_temp_dw = Borrow();
+      op.Clear();
+      op.PushValuePtr("dev_frame_0", &dev_frame_0_res);
+      op.PushValuePtr("dev_frame_1", &dev_frame_1_res_br);
+      op.PushValuePtr("dev_flow_u", &dev_flow_u);
+      op.PushValuePtr("dev_flow_v", &dev_flow_v);
+      op.PushValuePtr("dev_flow_w", &dev_flow_w);
+      op.PushValuePtr("dev_flow_du", &dev_flow_du);
+      op.PushValuePtr("dev_flow_dv", &dev_flow_dv);
+      op.PushValuePtr("dev_flow_dw", &dev_flow_dw);
+      op.PushValuePtr("dev_phi", &dev_phi);
+      op.PushValuePtr("dev_ksi", &dev_ksi);
+      op.PushValuePtr("dev_temp_du", &dev_temp_du);
+      op.PushValuePtr("dev_temp_dv", &dev_temp_dv);
+      op.PushValuePtr("dev_temp_dw", &dev_temp_dw);
+      op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
+      op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
+      op.PushValuePtr("equation_alpha", &equation_alpha);
+      op.PushValuePtr("equation_smoothness", &equation_smoothness);
+      op.PushValuePtr("equation_data", &equation_data);
+      op.PushValuePtr("data_size", &current);
+      op.PushValuePtr("hx", &hx);
+      op.PushValuePtr("hy", &hy);
+      op.PushValuePtr("hz", &hz);
+      cuop_solve_.silent = silent;
+      cuop_solve_.Execute(op);
+      GiveBack(dev_phi);
+      GiveBack(dev_ksi);
+      GiveBack(dev_temp_du);
+      GiveBack(dev_temp_dv);
+      GiveBack(dev_temp_dw);
+    }
+
+    // flow += increment (:420-438), then median of each component (:444-473)
+    DevicePtr* flow[3] = {&dev_flow_u, &dev_flow_v, &dev_flow_w};
+    DevicePtr* incr[3] = {&dev_flow_du, &dev_flow_dv, &dev_flow_dw};
+    for (int i = 0; i < 3; ++i) {
+      op.Clear();
+      op.PushValuePtr("operand_0", flow[i]);
+      op.PushValuePtr("operand_1", incr[i]);
+      op.PushValuePtr("data_size", &current);
+      cuop_add_.Execute(op);
+    }
+    {
+      DevicePtr dev_temp = Borrow();
+      for (int i = 0; i < 3; ++i) {
+        op.Clear();
+        op.PushValuePtr("dev_input", flow[i]);
+        op.PushValuePtr("dev_output", &dev_temp);
+        op.PushValuePtr("data_size", &current);
+        op.PushValuePtr("radius", &median_radius);
+        cuop_median_.Execute(op);
+        std::swap(*flow[i], dev_temp);
+      }
+      GiveBack(dev_temp);
+    }
+
+    prev_data_size = current;
+    --level;
+  }
+
+  // keep (u, v, w) until they are downloaded; everything else returns to the pool
+  result_flow_[0] = dev_flow_u;
+  result_flow_[1] = dev_flow_v;
+  result_flow_[2] = dev_flow_w;
+  GiveBack(dev_frame_0);
+  GiveBack(dev_frame_1);
+  GiveBack(dev_frame_0_res);
+  GiveBack(dev_frame_1_res_br);
+  GiveBack(dev_flow_du);
+  GiveBack(dev_flow_dv);
+  GiveBack(dev_flow_dw);
+  return true;
+}
+
+void OpticalFlowE::Destroy()
+{
+  for (CudaOperationBase* cuop : cuda_operations_) cuop->Destroy();
+  ReleaseResult();
+  size_t freed = 0;
+  while (!free_containers_.empty()) {
+    CheckDeviceError(f3d_free(free_containers_.back()));
+    free_containers_.pop_back();
+    ++freed;
+  }
+  for (DevicePtr& p : resident_frame_) {
+    if (p) CheckDeviceError(f3d_free(p));
+    p = 0;
+  }
+  if (freed && freed != kContainers) std::printf("Warning. Not all device memory allocations were freed.\n");
+  initialized_ = false;
+}

@@ -1,0 +1,171 @@
+/*
+ * f3d.h -- C ABI of libf3d_hip.so, the MI355X (gfx950) device library behind the
+ * axruff/cuda-flow3d operator surface (src/cuda_operations/entire_data/ and src/optical_flow/optical_flow_e.{h,cpp}).
+ *
+ * The reference's operator hosts talk to the GPU through the CUDA *driver* API: cuModuleLoad of
+ * kernels/<name>.ptx, cuModuleGetFunction, cuModuleGetGlobal("container_size"), cuLaunchKernel(args[]),
+ * cuMemAllocPitch, cuMemcpy3D, cuMemsetD2D8, cuEvent*.  Every one of those uses on the hot path maps to
+ * one entry point below; the comment on each cites the reference call site it replaces.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, floats.  Device pointers are 64-bit integers (f3d_devptr),
+ *     the same width as the CUdeviceptr values that travel through the reference's OperationParameters bag.
+ *   - every function returns 0 on success, non-zero on failure; f3d_last_error() gives the message
+ *     (thread local).  Nothing here throws and nothing silently falls back to a CPU path.
+ *   - all device work is enqueued on one library-owned HIP stream, in order (the reference uses the NULL
+ *     stream).  Launchers do not synchronise; call f3d_stream_sync().
+ *   - volumes live in pitched "containers" addressed ((z - z_base) * container.height + y) * (pitch/4) + x
+ *     (reference IND macro, src/kernels/solve_3d.cu:26); coarse pyramid levels occupy the corner sub-box.
+ *     f3d_set_container() replaces the per-module __constant__ container_size upload.
+ *   - `slab` (nullable) restricts a launcher to global planes [z_lo, z_hi) of a container whose plane 0
+ *     holds global plane z_base; `depth` is always the GLOBAL depth of the level, so mirror / zero-padding
+ *     rules are those of the whole volume.  NULL means the whole volume (z_base 0, planes [0, depth)).
+ */
+#ifndef F3D_H_
+#define F3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t f3d_devptr;
+
+/* src/data_types/data_structs.h:20-25 (DataSize4; pitch in bytes) */
+typedef struct f3d_size4 {
+  size_t width;
+  size_t height;
+  size_t depth;
+  size_t pitch;
+} f3d_size4;
+
+typedef struct f3d_slab {
+  int z_base; /* global z held by container plane 0 */
+  int z_lo;   /* first global plane to produce       */
+  int z_hi;   /* one past the last plane to produce  */
+} f3d_slab;
+
+typedef struct f3d_event_s* f3d_event;
+
+/* ---- runtime: context, memory, copies, events ------------------------------------------------ */
+
+/* cuInit + cuDeviceGet + cuCtxCreate: src/utils/cuda_utils.cpp:21-57.  device < 0 picks LOCAL_RANK or 0. */
+int f3d_init(int device);
+/* cuCtxDestroy: src/main.cpp:236 */
+int f3d_shutdown(void);
+/* cuDeviceGetCount / cuDeviceGetName: src/utils/cuda_utils.cpp:27,44 */
+int f3d_device_count(int* count);
+int f3d_device_name(char* name, size_t capacity);
+/* cuMemGetInfo: src/optical_flow/optical_flow_e.cpp:83 */
+int f3d_mem_info(size_t* free_bytes, size_t* total_bytes);
+/* cuDeviceGetAttribute(MAX_SHARED_MEMORY_PER_BLOCK): src/cuda_operations/entire_data/cuda_operation_solve.cpp:147 */
+int f3d_lds_per_workgroup(int* bytes);
+const char* f3d_last_error(void);
+
+/* cuMemAllocPitch: src/optical_flow/optical_flow_e.cpp:104-108 (pitch is a multiple of 256 B) */
+int f3d_alloc_pitched(f3d_devptr* ptr, size_t* pitch, size_t width_bytes, size_t rows);
+/* cuMemFree: src/optical_flow/optical_flow_e.cpp:612 */
+int f3d_free(f3d_devptr ptr);
+/* cuMemsetD2D8: src/optical_flow/optical_flow_e.cpp:305-310, cuda_operation_solve.cpp:183-188 */
+int f3d_memset2d(f3d_devptr ptr, size_t pitch, int value, size_t width_bytes, size_t rows);
+/* cuMemcpy3D host->device / device->host, dense host volume <-> pitched container:
+ * src/utils/cuda_utils.cpp:59-101.  depth planes are copied starting at container plane dev_plane0. */
+int f3d_copy3d_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0,
+                   const float* src, size_t width, size_t height, size_t depth);
+int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth,
+                   f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
+/* cuMemcpyDtoD: src/cuda_operations/entire_data/cuda_operation_median.cpp:96-98 */
+int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes);
+/* cuModuleGetGlobal("container_size") + cuMemcpyHtoD in every op's Initialize, e.g. cuda_operation_solve.cpp:59-61 */
+int f3d_set_container(const f3d_size4* container);
+
+/* cuEventCreate/Record/Synchronize/ElapsedTime/Destroy: optical_flow_e.cpp:163-169,579-587 */
+int f3d_event_create(f3d_event* ev);
+int f3d_event_record(f3d_event ev);
+int f3d_event_sync(f3d_event ev);
+int f3d_event_elapsed_ms(float* ms, f3d_event start, f3d_event stop);
+int f3d_event_destroy(f3d_event ev);
+/* cuStreamSynchronize(NULL): cuda_operation_solve.cpp:257 */
+int f3d_stream_sync(void);
+
+/* ---- kernel launchers (one per reference __global__; same scalar lists as the reference arg arrays) -- */
+
+/* compute_phi_ksi_3d, 18 args: cuda_operation_solve.cpp:195-213; kernel src/kernels/solve_3d.cu:33-262 */
+int f3d_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw,
+                size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                float equation_smoothness, float equation_data, f3d_devptr phi, f3d_devptr ksi,
+                const f3d_slab* slab);
+
+/* solve_3d, 20 args: cuda_operation_solve.cpp:224-244; kernel src/kernels/solve_3d.cu:264-508.
+ * One Jacobi sweep (in-voxel Gauss-Seidel du->dv->dw) into temp_d*; the caller ping-pongs the buffers. */
+int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                    f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                    size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                    f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
+
+/* registration_3d, 12 args: cuda_operation_registration.cpp:110-122; kernel src/kernels/registration_3d.cu:28-82 */
+int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+             size_t width, size_t height, size_t depth, float hx, float hy, float hz, f3d_devptr output,
+             const f3d_slab* slab);
+
+/* resample_{x,y,z}_3d, 6 args: cuda_operation_resample.cpp:115-120,138-143,161-166; src/kernels/resample_3d.cu.
+ * slab_in describes the input container (z pass only reads through it), slab the output planes. */
+int f3d_resample_x(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_width, const f3d_slab* slab);
+int f3d_resample_y(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_height, const f3d_slab* slab);
+int f3d_resample_z(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
+                   size_t in_depth, const f3d_slab* slab_in, const f3d_slab* slab);
+
+/* add_3d, 5 args: cuda_operation_add.cpp:86-91; src/kernels/add_3d.cu:26-41 */
+int f3d_add(f3d_devptr operand_0, f3d_devptr operand_1, size_t width, size_t height, size_t depth,
+            const f3d_slab* slab);
+
+/* median_3d, 6 args: cuda_operation_median.cpp:131-137; src/kernels/median_3d.cu:49-299.
+ * radius is the window DIAMETER, one of 3, 5, 7 (the host op applies the 1 / even rules). */
+int f3d_median(f3d_devptr input, size_t width, size_t height, size_t depth, size_t radius, f3d_devptr output,
+               const f3d_slab* slab);
+
+/* c_Kernel upload: cuda_operation_convolution.cpp:160-161 (at most 51 taps, MAX_KERNEL_LENGTH) */
+int f3d_set_conv_taps(const float* taps, size_t count);
+/* convolution{Rows,Columns,Slices}Kernel, 7 args: cuda_operation_convolution.cpp:221-228,274-281,327-334;
+ * src/kernels/convolution_3d.cu:75-172,186-271,284-372.  Zero padding; taps from f3d_set_conv_taps. */
+int f3d_conv_rows(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                  const f3d_slab* slab);
+int f3d_conv_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                  const f3d_slab* slab);
+int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                    const f3d_slab* slab);
+
+/* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
+
+enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_COUNT = 2 };
+/* enable = 1 brackets every launch of the two solver kernels with events on the library stream */
+int f3d_prof_enable(int enable);
+int f3d_prof_reset(void);
+/* drains the pending events; min_voxels filters launches by level size (0 = all) */
+int f3d_prof_read(int kernel, size_t min_voxels, double* total_ms, uint64_t* launches, double* total_voxels);
+
+/* ---- multi-GPU: z-slab halo exchange on RCCL (no reference counterpart) ---------------- */
+
+/* 128-byte ncclUniqueId, created on rank 0 and handed to the other ranks by the launcher */
+int f3d_comm_unique_id(void* id128);
+int f3d_comm_init(const void* id128, int rank, int n_ranks);
+int f3d_comm_destroy(void);
+int f3d_comm_rank(int* rank, int* n_ranks);
+/* Send whole planes of `field` to / receive from peers: entry i moves n_planes[i] container planes
+ * starting at container plane send_plane0[i] / recv_plane0[i] (negative count = skip) with peer[i]. */
+int f3d_comm_exchange_planes(const f3d_devptr* fields, int n_fields, size_t plane_rows, size_t row_bytes,
+                             const int* peer, const int* send_plane0, const int* send_count,
+                             const int* recv_plane0, const int* recv_count, int n_peers);
+int f3d_comm_allreduce_max_f32(float* value);
+/* max |field| over the slab's planes, on the device (feeds the warp halo depth) */
+int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3D_H_ */

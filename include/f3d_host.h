@@ -1,0 +1,81 @@
+/*
+ * f3d_host.h -- C ABI of libf3d_host.so: the C++ host side (driver + operator classes that mirror the
+ * reference's src/optical_flow and src/cuda_operations/entire_data) exposed to other languages.
+ * The Python package binds exactly these entry points with ctypes; nothing here carries torch or numpy types.
+ *
+ *   f3d_flow_*  : OpticalFlowE  (src/optical_flow/optical_flow_e.h:38-66; ComputeFlow optical_flow_e.cpp:132-601)
+ *   f3d_op_*    : the six CudaOperation* classes through their string-keyed parameter bag
+ *                 (src/cuda_operations/cuda_operation_base.h:40-46, keys in SURVEY.md 8b)
+ *   host helpers: level schedule (optical_flow_base.cpp:31-56), Gaussian taps
+ *                 (cuda_operation_convolution.cpp:85-108), RAW volume I/O (data3d.cpp:95-237),
+ *                 the synthetic translated-Gaussian benchmark pair.
+ * All functions return 0 on success unless stated otherwise.
+ */
+#ifndef F3D_HOST_H_
+#define F3D_HOST_H_
+
+#include "f3d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the 9-key driver bag of src/main.cpp:156-165 as a plain struct */
+typedef struct f3d_flow_params {
+  size_t warp_levels_count;
+  float  warp_scale_factor;
+  size_t outer_iterations_count;
+  size_t inner_iterations_count;
+  float  equation_alpha;
+  float  equation_smoothness;
+  float  equation_data;
+  size_t median_radius;
+  float  gaussian_sigma;
+} f3d_flow_params;
+
+typedef struct f3d_flow_s* f3d_flow;
+typedef struct f3d_op_s* f3d_op;
+
+/* defaults of src/main.cpp:77-85 */
+void f3d_flow_default_params(f3d_flow_params* p);
+
+int f3d_flow_create(f3d_flow* flow);
+/* OpticalFlowE::Initialize: allocates the 15 containers and initialises the six operators */
+int f3d_flow_initialize(f3d_flow flow, size_t width, size_t height, size_t depth);
+/* OpticalFlowE::ComputeFlow on dense host volumes (x fastest); u, v, w receive width*height*depth floats */
+int f3d_flow_compute(f3d_flow flow, const float* frame_0, const float* frame_1, const f3d_flow_params* params,
+                     int silent, float* u, float* v, float* w);
+/* device-resident variant: upload once, solve any number of times, download on demand */
+int f3d_flow_upload(f3d_flow flow, const float* frame_0, const float* frame_1);
+int f3d_flow_compute_resident(f3d_flow flow, const f3d_flow_params* params, int silent, float* device_seconds);
+int f3d_flow_download(f3d_flow flow, float* u, float* v, float* w);
+int f3d_flow_container(f3d_flow flow, f3d_size4* container);
+int f3d_flow_destroy(f3d_flow flow);
+
+/* name: "add" | "convolution" | "median" | "registration" | "resample" | "solve" */
+int f3d_op_create(f3d_op* op, const char* name);
+const char* f3d_op_name(f3d_op op);
+int f3d_op_initialize(f3d_op op, const f3d_size4* container_size);
+/* Execute(OperationParameters&): keys[i] -> value_ptrs[i] (non-owning, like the reference's bag) */
+int f3d_op_execute(f3d_op op, const char* const* keys, void* const* value_ptrs, size_t count);
+int f3d_op_set_slab(f3d_op op, const f3d_slab* slab);
+int f3d_op_destroy(f3d_op op);
+
+/* host-only helpers (no device needed) */
+size_t f3d_max_warp_level(size_t width, size_t height, size_t depth, float scale_factor);
+int f3d_level_geometry(size_t width, size_t height, size_t depth, float scale_factor, int level,
+                       f3d_size4* size, float* hx, float* hy, float* hz);
+int f3d_gaussian_taps(float sigma, float* taps, size_t capacity, size_t* radius);
+int f3d_raw_read_u8(const char* path, size_t width, size_t height, size_t depth, float* out);
+int f3d_raw_read_f32(const char* path, size_t width, size_t height, size_t depth, float* out);
+int f3d_raw_write_u8(const char* path, const float* in, size_t width, size_t height, size_t depth);
+int f3d_raw_write_f32(const char* path, const float* in, size_t width, size_t height, size_t depth);
+int f3d_vtk_write_flow(const char* path, const float* u, const float* v, const float* w, size_t width, size_t height,
+                       size_t depth);
+/* translated-Gaussian pair: 64 blobs, splitmix64 seed 20241003, frame_1(p) = frame_0(p - t), t = (2, -1, 0.5) */
+int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, float* frame_1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3D_HOST_H_ */

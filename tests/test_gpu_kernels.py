@@ -1,0 +1,258 @@
+"""Per-kernel parity on the MI355X: every launcher of include/f3d.h against the CPU oracle on the same seeded
+inputs.  Float work, but the kernels keep the reference's expression trees with contraction off, so the bar is
+EXACT equality (tolerance 0; only the sign of a zero may differ in the median).  Boxes have odd sizes and sit in
+the corner of a larger NaN-poisoned container, so partial tiles, mirror halos, depth < tile and stale reads
+outside the sub-box are all exercised."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bit_same, box_in_container, same
+
+pytestmark = pytest.mark.gpu
+
+# (W,H,D) box, (Wc,Hc,Dc) container
+CASES = [
+    ((37, 21, 9), (64, 32, 16)),
+    ((64, 8, 5), (64, 8, 5)),
+    ((70, 70, 70), (128, 72, 70)),
+    ((5, 4, 4), (16, 8, 8)),
+    ((131, 7, 13), (192, 8, 16)),
+    ((62, 4, 4), (62, 4, 4)),
+    ((63, 5, 6), (63, 5, 6)),
+    ((125, 9, 7), (125, 9, 7)),
+]
+SPACINGS = [(1.0, 1.0, 1.0), (7.1, 1.6, 1.25)]
+
+
+class Dev:
+    """Uploads host containers, runs a launcher, downloads the box."""
+
+    def __init__(self, f3d, cdims):
+        self.f3d = f3d
+        self.cdims = cdims
+        self.cont = f3d.Containers(*cdims)
+        self.cont.alloc(fill=0xFF)
+        self.cont.set_current()
+
+    def put(self, host_container):
+        p = self.cont.new()
+        self.cont.upload(p, host_container)
+        return p
+
+    def out(self):
+        return self.cont.new()
+
+    def get(self, p):
+        self.f3d.sync()
+        return self.cont.download(p, self.cdims)
+
+    def close(self):
+        self.f3d.sync()
+        self.cont.free()
+
+
+def solver_inputs(rng, dims, cdims):
+    mk = lambda lo, hi: box_in_container(rng, dims, cdims, lo, hi)
+    f0, f1 = mk(0, 255), mk(0, 255)
+    u, v, w = mk(-3, 3), mk(-3, 3), mk(-3, 3)
+    du, dv, dw = mk(-0.5, 0.5), mk(-0.5, 0.5), mk(-0.5, 0.5)
+    return [f0, f1, u, v, w, du, dv, dw]
+
+
+@pytest.mark.parametrize("dims,cdims", CASES)
+@pytest.mark.parametrize("h", SPACINGS)
+def test_phi_ksi_and_sweeps(f3d, oracle, dims, cdims, h):
+    rng = np.random.default_rng(hash((dims, h)) % 2**32)
+    W, H, D = dims
+    arrs = solver_inputs(rng, dims, cdims)
+    eps_s, eps_d, alpha = 0.001, 0.001, 7.5
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.out(), dev.out()
+        f3d.check(f3d.hip().f3d_phi_ksi(*ptr, W, H, D, *h, eps_s, eps_d, phi, ksi, None))
+        got_phi, got_ksi = dev.get(phi)[:D, :H, :W], dev.get(ksi)[:D, :H, :W]
+        assert bit_same(got_phi, phi_o[:D, :H, :W])
+        assert bit_same(got_ksi, ksi_o[:D, :H, :W])
+
+        # 5 ping-pong sweeps from these phi/ksi (tolerance 0)
+        du, dv, dw = arrs[5], arrs[6], arrs[7]
+        tmp = [dev.out() for _ in range(3)]
+        cur = ptr[5:8]
+        for it in range(5):
+            o = oracle.solve_sweep(*arrs[:5], du, dv, dw, phi_o, ksi_o, dims, h, alpha)
+            f3d.check(f3d.hip().f3d_solve_sweep(*ptr[:5], *cur, phi, ksi, W, H, D, *h, alpha, *tmp, None))
+            cur, tmp = tmp, cur
+            du, dv, dw = o
+            if it in (0, 4):
+                for g, e in zip(cur, (du, dv, dw)):
+                    assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W]), f"sweep {it}"
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:5])
+def test_solver_slab_window(f3d, oracle, dims, cdims):
+    """A z-slab launch (container plane 0 = global plane z_base) equals the same planes of the whole-volume result."""
+    rng = np.random.default_rng(7)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    sw_o = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    z_lo, z_hi = 1, D - 1
+    z_base = 0 if z_lo - 1 < 0 else z_lo - 1
+    planes = z_hi + 1 - z_base  # halo planes z_lo-1 .. z_hi
+    sub = lambda a: np.ascontiguousarray(a[z_base:z_base + planes])
+    dev = Dev(f3d, (cdims[0], cdims[1], planes))
+    try:
+        ptr = [dev.put(sub(a)) for a in arrs]
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        phi, ksi = dev.out(), dev.out()
+        f3d.check(f3d.hip().f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, C.byref(slab)))
+        got = dev.get(phi)
+        assert bit_same(got[z_lo - z_base:z_hi - z_base, :H, :W], phi_o[z_lo:z_hi, :H, :W])
+        pphi, pksi = dev.put(sub(phi_o)), dev.put(sub(ksi_o))
+        outs = [dev.out() for _ in range(3)]
+        f3d.check(f3d.hip().f3d_solve_sweep(*ptr, pphi, pksi, W, H, D, *h, 7.5, *outs, C.byref(slab)))
+        for g, e in zip(outs, sw_o):
+            assert bit_same(dev.get(g)[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:5])
+def test_warp(f3d, oracle, dims, cdims):
+    rng = np.random.default_rng(11)
+    W, H, D = dims
+    h = (2.0, 1.0, 0.7)
+    f0 = box_in_container(rng, dims, cdims, 0, 255)
+    f1 = box_in_container(rng, dims, cdims, 0, 255)
+    # flows large enough that ~40 % of targets leave the domain, plus exact-integer landings and NaN
+    u = box_in_container(rng, dims, cdims, -0.6 * W, 0.6 * W)
+    v = box_in_container(rng, dims, cdims, -0.6 * H, 0.6 * H)
+    w = box_in_container(rng, dims, cdims, -0.6 * D, 0.6 * D)
+    u[:D, :H, :W][::2, ::3, ::2] = 2.0
+    v[:D, :H, :W][::2, ::3, ::2] = -1.0
+    w[:D, :H, :W][::2, ::3, ::2] = 0.0
+    u[0, 0, 0] = np.nan
+    v[D - 1, H - 1, W - 1] = np.nan
+    exp = oracle.warp(f0, f1, u, v, w, dims, h)
+    dev = Dev(f3d, cdims)
+    try:
+        p = [dev.put(a) for a in (f0, f1, u, v, w)]
+        out = dev.out()
+        f3d.check(f3d.hip().f3d_warp(*p, W, H, D, *h, out, None))
+        assert bit_same(dev.get(out)[:D, :H, :W], exp[:D, :H, :W])
+    finally:
+        dev.close()
+
+
+RESAMPLE = [
+    ((37, 21, 9), (36, 20, 9)),      # down ~0.95
+    ((36, 20, 9), (37, 21, 9)),      # up
+    ((50, 33, 23), (7, 5, 4)),       # strong down, > 7 cells per output
+    ((64, 40, 5), (61, 38, 4)),      # thin slab
+    ((19, 19, 19), (19, 19, 19)),    # identity
+    ((18, 18, 18), (128, 20, 40)),   # strong anisotropic up
+]
+
+
+@pytest.mark.parametrize("src,dst", RESAMPLE)
+def test_resample(f3d, oracle, src, dst):
+    rng = np.random.default_rng(13)
+    cdims = tuple(max(a, b) + 3 for a, b in zip(src, dst))
+    inp = box_in_container(rng, src, cdims, -5, 5)
+    exp = oracle.resample(inp, src, dst)
+    dev = Dev(f3d, cdims)
+    try:
+        op = f3d.Operation("resample")
+        assert op.initialize(dev.cont)
+        pin, pout, ptmp = dev.put(inp), dev.out(), dev.out()
+        op.execute(dev_input=pin, dev_output=pout, dev_temp=ptmp, data_size=src, resample_size=dst)
+        got = dev.get(pout)
+        W, H, D = dst
+        assert bit_same(got[:D, :H, :W], exp[:D, :H, :W])
+        op.destroy()
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("r", [3, 5, 7])
+@pytest.mark.parametrize("dims,cdims", [((37, 21, 9), (64, 32, 16)), ((9, 6, 4), (9, 6, 4)), ((70, 33, 5), (70, 33, 5)),
+                                        ((4, 4, 4), (8, 8, 8))])
+def test_median(f3d, oracle, dims, cdims, r):
+    rng = np.random.default_rng(17 + r)
+    W, H, D = dims
+    inp = box_in_container(rng, dims, cdims, -2, 2)
+    # plateaus of equal values and exact zeros
+    inp[:D, :H, :W][rng.random((D, H, W)) < 0.3] = 0.5
+    inp[:D, :H, :W][rng.random((D, H, W)) < 0.1] = 0.0
+    exp = oracle.median(inp, dims, r)
+    dev = Dev(f3d, cdims)
+    try:
+        pin, pout = dev.put(inp), dev.out()
+        f3d.check(f3d.hip().f3d_median(pin, W, H, D, r, pout, None))
+        assert same(dev.get(pout)[:D, :H, :W], exp[:D, :H, :W])
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("sigma", [1.0, 2.0, 3.5, 5.0])
+@pytest.mark.parametrize("dims", [(37, 20, 9), (64, 8, 5), (130, 12, 33)])
+def test_gaussian(f3d, oracle, dims, sigma):
+    """Clean zero-padded spec; the container height equals the data height as at the reference's only call site."""
+    rng = np.random.default_rng(19)
+    W, H, D = dims
+    cdims = (W + 5, H, D)
+    inp = box_in_container(rng, dims, cdims, 0, 255)
+    exp = oracle.gaussian(inp, dims, sigma)
+    r_o, taps_o = oracle.gaussian_taps(sigma)
+    r_p, taps_p = f3d.gaussian_taps(sigma)
+    assert r_o == r_p and bit_same(taps_o, taps_p)
+    dev = Dev(f3d, cdims)
+    try:
+        op = f3d.Operation("convolution")
+        assert op.initialize(dev.cont)
+        pin, pout, ptmp = dev.put(inp), dev.out(), dev.out()
+        op.execute(dev_input=pin, dev_output=pout, dev_temp=ptmp, data_size=dims, gaussian_sigma=sigma)
+        assert bit_same(dev.get(pout)[:D, :H, :W], exp[:D, :H, :W])
+        op.destroy()
+    finally:
+        dev.close()
+
+
+def test_add(f3d, oracle):
+    rng = np.random.default_rng(23)
+    dims, cdims = (37, 21, 9), (64, 32, 16)
+    W, H, D = dims
+    a = box_in_container(rng, dims, cdims)
+    b = box_in_container(rng, dims, cdims)
+    exp = a.copy()
+    oracle.add(exp, b, dims)
+    dev = Dev(f3d, cdims)
+    try:
+        pa, pb = dev.put(a), dev.put(b)
+        f3d.check(f3d.hip().f3d_add(pa, pb, W, H, D, None))
+        got = dev.get(pa)
+        assert bit_same(got[:D, :H, :W], exp[:D, :H, :W])
+        # nothing outside the box was touched
+        assert np.isnan(got[D:]).all() and np.isnan(got[:, H:]).all() and np.isnan(got[:, :, W:]).all()
+    finally:
+        dev.close()
+
+
+def test_errors_are_loud(f3d):
+    dev = Dev(f3d, (16, 8, 8))
+    try:
+        p = dev.out()
+        assert f3d.hip().f3d_median(p, 8, 8, 8, 5, p, None) != 0           # in == out
+        assert f3d.hip().f3d_median(p, 8, 8, 8, 4, dev.out(), None) != 0   # unsupported window
+        assert f3d.hip().f3d_add(p, p, 32, 8, 8, None) != 0                # box larger than the container
+        assert b"container" in f3d.hip().f3d_last_error()
+    finally:
+        dev.close()
