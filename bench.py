@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native 3-D optical-flow solver.
+
+Metric (BASELINE.json): Mvoxels/s of a FULL coarse-to-fine pyramid solve (default parameters of the reference,
+src/main.cpp:77-85) of a 512^3 float32 pair, frames already resident in HBM when the timed region starts.
+A "step" is one ComputeFlow over the whole pyramid (40 levels x (40 x (phi/ksi + 5 sweeps)) + warp, resample,
+add, median).  One JSON line on stdout carries the metric plus
+  roofline     : the dominant kernel (the solver sweep, 52 algorithmic B/voxel) timed live with HIP events on the
+                 library stream over the timed region, against the 8 TB/s HBM peak,
+  cpu_baseline : the same numerics (the oracle, a scalar-per-voxel C port with OpenMP over planes) run on the
+                 box's own host cores on a bounded sample (a smaller volume of the same synthetic family).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
+For N > 1 launch through torch.distributed.run (one rank per GPU); the volume is z-slab partitioned.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SWEEP_BYTES_PER_VOXEL = 52.0    # 10 reads + 3 writes of float32
+PHI_KSI_BYTES_PER_VOXEL = 40.0  # 8 reads + 2 writes
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(size):
+    """Oracle (CPU port of the same numerics) on a size^3 pair of the same synthetic family, all host cores."""
+    import numpy as np  # noqa: F401
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    from oracle import oracle as orc  # cpu_baseline leg only
+    f0, f1 = pkg.synth_pair(size, size, size)
+    t0 = time.perf_counter()
+    orc.compute_flow(f0, f1)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(size ** 3 / dt / 1e6, 5), "unit": "Mvoxels/s", "cores": orc.num_threads(), "kind": "port",
+        "sample": f"{size}^3 synthetic translated-Gaussian pair, full default pyramid, oracle/f3d_oracle.c with "
+                  f"OpenMP over planes ({dt:.1f} s)",
+    }
+
+
+def run_single(args):
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    S = args.size
+    log(f"[bench] generating the {S}^3 synthetic pair on the host ...")
+    f0, f1 = pkg.synth_pair(S, S, S)
+    flow = pkg.OpticalFlow()
+    flow.initialize(S, S, S)
+    flow.upload(f0, f1)
+    del f0, f1
+    hip = pkg.hip()
+
+    for i in range(args.warmup):
+        t = flow.compute_resident(silent=True)
+        log(f"[bench] warmup {i}: {t:.3f} s")
+
+    hip.f3d_prof_reset()
+    hip.f3d_prof_enable(1)
+    pkg.sync()
+    t0 = time.perf_counter()
+    dev_s = 0.0
+    for i in range(args.steps):
+        dev_s += flow.compute_resident(silent=True)
+    pkg.sync()
+    wall = time.perf_counter() - t0
+    hip.f3d_prof_enable(0)
+
+    def prof(kernel, min_vox):
+        ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
+        pkg.check(hip.f3d_prof_read(kernel, min_vox, C.byref(ms), C.byref(n), C.byref(vox)))
+        return ms.value, n.value, vox.value
+
+    sw_ms, sw_n, sw_vox = prof(1, 0)
+    fin_ms, fin_n, fin_vox = prof(1, S ** 3)
+    pk_ms, pk_n, pk_vox = prof(0, 0)
+    hip.f3d_prof_reset()
+    flow.destroy()
+
+    achieved = SWEEP_BYTES_PER_VOXEL * sw_vox / (sw_ms * 1e-3) / 1e9 if sw_ms else 0.0
+    finest = SWEEP_BYTES_PER_VOXEL * fin_vox / (fin_ms * 1e-3) / 1e9 if fin_ms else 0.0
+    phi_gbs = PHI_KSI_BYTES_PER_VOXEL * pk_vox / (pk_ms * 1e-3) / 1e9 if pk_ms else 0.0
+    ms_per_step = wall / args.steps * 1e3
+    out = {
+        "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
+        "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair, full coarse-to-fine pyramid "
+                               "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
+                               "frames resident in HBM", "parallelism": "1 GPU"},
+        "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
+        "roofline": {
+            "bound": "hbm", "kernel": "k_solver<true> (solver sweep, f3d_solve_sweep)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "launches": sw_n, "avg_launch_us": round(sw_ms / sw_n * 1e3, 3) if sw_n else None,
+            "avg_voxels_per_launch": round(sw_vox / sw_n, 1) if sw_n else None,
+            "finest_level": {"achieved": round(finest, 1), "frac": round(finest / HBM_PEAK_GBS, 4), "launches": fin_n,
+                             "avg_launch_us": round(fin_ms / fin_n * 1e3, 3) if fin_n else None},
+            "phi_ksi": {"achieved": round(phi_gbs, 1), "frac": round(phi_gbs / HBM_PEAK_GBS, 4), "launches": pk_n},
+        },
+    }
+    if not args.no_cpu:
+        log("[bench] timing the CPU baseline (oracle) ...")
+        out["cpu_baseline"] = cpu_baseline(args.cpu_size)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--cpu-size", type=int, default=96)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        run_single(args)
+    else:
+        from bench_multi import run_multi  # z-slab decomposition over RCCL
+        run_multi(args)
+
+
+if __name__ == "__main__":
+    main()

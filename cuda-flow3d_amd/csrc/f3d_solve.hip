@@ -12,6 +12,8 @@
 //   * the y-neighbour rows are the rows the adjacent waves of the same workgroup stream at the same
 //     moment, so they are served by the CU's L1/the XCD's L2; mirror (Neumann) halos are index arithmetic.
 //   * loads for the next z step are issued before the arithmetic of the current one (software pipelining).
+#include <cstdlib>
+
 #include "f3d_internal.h"
 
 namespace {
@@ -259,6 +261,381 @@ bool slab_reach_ok(const F3dGeo& g, int reach, const char* who)
   return true;
 }
 
+
+// ---- variant 2: rows of the current plane shared through LDS, 64-aligned x tiles, XCD-aware tile order ----------
+//
+// A workgroup is kRows = 8 waves = rows y0-1 .. y0+6 of one aligned 64-column tile: the 6 inner rows compute,
+// the two outer waves only stream the halo rows.  Every wave keeps its own row's z-window (z-1, z, z+1, z+2) in
+// registers, publishes plane z through LDS once per step, and reads its y-neighbours from there, so each row of
+// each plane is requested from L2/HBM once per workgroup.  The two x-halo columns of the row come from one extra
+// load (lanes < 32 fetch column x0-1, the others x0+64) that is merged into the DPP wave shift as the value the
+// edge lane keeps.  Tiles are dealt to the 8 XCDs in contiguous runs, so the halo rows/columns a tile shares
+// with its neighbours are served by the same L2.
+constexpr int kRows = 8;
+constexpr int kOutRows = kRows - 2;
+
+__device__ __forceinline__ float lane_left_or(float v, float edge)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right_or(float v, float edge)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+template <bool SWEEP>
+__global__ __launch_bounds__(kLanes* kRows, 4) void k_solver_lds(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty,
+                                                              int n_tiles, int xcd_remap)
+{
+  constexpr int NA = SWEEP ? 9 : 8;
+  __shared__ float sh[NA][kRows][kLanes];
+
+  // tile order: XCD k (blocks with id % 8 == k) walks tiles [k * per_xcd, (k + 1) * per_xcd) in sequence
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+
+  const int y = ty * kOutRows - 1 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x0 = tx * kLanes;
+  const int x = x0 + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const int xh = f3d_clampi(f3d_mir(lane < 32 ? x0 - 1 : x0 + kLanes, g.W), 0, g.W - 1);
+  const bool owner = r >= 1 && r <= kOutRows && y < g.H && x < g.W;
+
+  float m[NA], c[NA], p[NA], q[NA], hc[NA], hn[NA];
+  float kc = 0.f, kn = 0.f;
+  {
+    const size_t rm = f3d_row(g, yy, f3d_mir(z0 - 1, g.D));
+    const size_t rc = f3d_row(g, yy, z0);
+    const size_t rp = f3d_row(g, yy, f3d_mir(z0 + 1, g.D));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      m[i] = a.in[i][rm + xi];
+      c[i] = a.in[i][rc + xi];
+      p[i] = a.in[i][rp + xi];
+      hc[i] = a.in[i][rc + xh];
+    }
+    if (SWEEP) kc = a.in[9][rc + xi];
+  }
+
+  for (int z = z0; z < z1; ++z) {
+    const bool more = z + 1 < z1;
+    if (more) {
+      const size_t rq = f3d_row(g, yy, f3d_mir(z + 2, g.D));
+      const size_t rn = f3d_row(g, yy, z + 1);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        q[i] = a.in[i][rq + xi];
+        hn[i] = a.in[i][rn + xh];
+      }
+      if (SWEEP) kn = a.in[9][rn + xi];
+    }
+
+    __syncthreads();  // everybody is done reading the previous plane
+#pragma unroll
+    for (int i = 0; i < NA; ++i) sh[i][r][lane] = c[i];
+    __syncthreads();
+
+    if (r >= 1 && r <= kOutRows) {
+      Hood<NA> n;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        n.c[i] = c[i];
+        n.xm[i] = lane_left_or(c[i], hc[i]);
+        n.xp[i] = lane_right_or(c[i], hc[i]);
+        n.ym[i] = sh[i][r - 1][lane];
+        n.yp[i] = sh[i][r + 1][lane];
+        n.zm[i] = m[i];
+        n.zp[i] = p[i];
+      }
+      const size_t o = f3d_row(g, yy, z) + xi;
+      if constexpr (SWEEP) {
+        float r_du, r_dv, r_dw;
+        sweep_voxel(n, kc, a.hx, a.hy, a.hz, a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du,
+                    r_dv, r_dw);
+        if (owner) {
+          a.out[0][o] = r_du;
+          a.out[1][o] = r_dv;
+          a.out[2][o] = r_dw;
+        }
+      } else {
+        float phi, ksi;
+        phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
+        if (owner) {
+          a.out[0][o] = phi;
+          a.out[1][o] = ksi;
+        }
+      }
+    }
+
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        m[i] = c[i];
+        c[i] = p[i];
+        p[i] = q[i];
+        hc[i] = hn[i];
+      }
+      kc = kn;
+    }
+  }
+}
+
+// ---- variant 3 (sweep only): overlapping 62-wide x tiles (DPP halo lanes), all 8 waves compute, y-neighbours of
+// the current plane through a double-buffered LDS image (one barrier per z step), the workgroup's two y-halo rows
+// streamed by its edge waves.  The neighbour sums use S = U + dU formed once per voxel: the reference's
+// (U[nb] + dU[nb]) - U[c] reads the same two operands, so S[nb] - U[c] is bit-identical and saves 15 adds, 6 lane
+// shifts and 3 of the 9 LDS images per voxel.
+constexpr int kTY3 = 8;
+enum { LF0 = 0, LF1 = 1, LPHI = 2, LSU = 3, LSV = 4, LSW = 5, kNL = 6 };
+
+struct Face6 {  // the six stencilled quantities of one neighbour
+  float v[kNL];
+};
+
+__device__ __forceinline__ void sweep_voxel_s(const Face6& xm, const Face6& xp, const Face6& ym, const Face6& yp,
+                                              const Face6& zm, const Face6& zp, const float (&c)[kNL], float Uc, float Vc,
+                                              float Wc, float dVc, float dWc, float ksi, float hx, float hy, float hz,
+                                              float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym, bool has_zp,
+                                              bool has_zm, float& r_du, float& r_dv, float& r_dw)
+{
+  const float fx = (xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1]) / (4.f * hx);
+  const float fy = (yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1]) / (4.f * hy);
+  const float fz = (zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]) / (4.f * hz);
+  const float ft = c[LF1] - c[LF0];
+
+  const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
+  const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
+  const float J14 = fx * ft, J24 = fy * ft, J34 = fz * ft;
+
+  const float hx_2 = alpha / (hx * hx);
+  const float hy_2 = alpha / (hy * hy);
+  const float hz_2 = alpha / (hz * hz);
+  const float wxp = static_cast<float>(has_xp) * hx_2;
+  const float wxm = static_cast<float>(has_xm) * hx_2;
+  const float wyp = static_cast<float>(has_yp) * hy_2;
+  const float wym = static_cast<float>(has_ym) * hy_2;
+  const float wzp = static_cast<float>(has_zp) * hz_2;
+  const float wzm = static_cast<float>(has_zm) * hz_2;
+
+  const float phi_xp = (xp.v[LPHI] + c[LPHI]) / 2.f;
+  const float phi_xm = (xm.v[LPHI] + c[LPHI]) / 2.f;
+  const float phi_yp = (yp.v[LPHI] + c[LPHI]) / 2.f;
+  const float phi_ym = (ym.v[LPHI] + c[LPHI]) / 2.f;
+  const float phi_zp = (zp.v[LPHI] + c[LPHI]) / 2.f;
+  const float phi_zm = (zm.v[LPHI] + c[LPHI]) / 2.f;
+
+  const float sumH = (wxp * phi_xp + wxm * phi_xm + wyp * phi_yp + wym * phi_ym + wzp * phi_zp + wzm * phi_zm);
+  const float sumU = phi_xp * wxp * (xp.v[LSU] - Uc) + phi_xm * wxm * (xm.v[LSU] - Uc) + phi_yp * wyp * (yp.v[LSU] - Uc) +
+                     phi_ym * wym * (ym.v[LSU] - Uc) + phi_zp * wzp * (zp.v[LSU] - Uc) + phi_zm * wzm * (zm.v[LSU] - Uc);
+  const float sumV = phi_xp * wxp * (xp.v[LSV] - Vc) + phi_xm * wxm * (xm.v[LSV] - Vc) + phi_yp * wyp * (yp.v[LSV] - Vc) +
+                     phi_ym * wym * (ym.v[LSV] - Vc) + phi_zp * wzp * (zp.v[LSV] - Vc) + phi_zm * wzm * (zm.v[LSV] - Vc);
+  const float sumW = phi_xp * wxp * (xp.v[LSW] - Wc) + phi_xm * wxm * (xm.v[LSW] - Wc) + phi_yp * wyp * (yp.v[LSW] - Wc) +
+                     phi_ym * wym * (ym.v[LSW] - Wc) + phi_zp * wzp * (zp.v[LSW] - Wc) + phi_zm * wzm * (zm.v[LSW] - Wc);
+
+  r_du = (ksi * (-J14 - J12 * dVc - J13 * dWc) + sumU) / (ksi * J11 + sumH);
+  r_dv = (ksi * (-J24 - J12 * r_du - J23 * dWc) + sumV) / (ksi * J22 + sumH);
+  r_dw = (ksi * (-J34 - J13 * r_du - J23 * r_dv) + sumW) / (ksi * J33 + sumH);
+}
+
+// raw 9-array row sample -> the six stencilled quantities
+__device__ __forceinline__ void to_face(const float (&raw)[9], Face6& f)
+{
+  f.v[LF0] = raw[F0];
+  f.v[LF1] = raw[F1];
+  f.v[LPHI] = raw[PHI];
+  f.v[LSU] = raw[U] + raw[DU];
+  f.v[LSV] = raw[V] + raw[DV];
+  f.v[LSW] = raw[Wf] + raw[DW];
+}
+
+__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                            int xcd_remap)
+{
+  __shared__ float sh[2][kNL][kTY3 + 2][kLanes];
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * kTY3;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kOutX - 1 + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const bool owner = lane >= 1 && lane <= kOutX && x < g.W && y < g.H;
+  // edge waves stream the workgroup's y-halo rows: row y0-1 (wave 0) and row y0+TY (last wave)
+  const bool edge = (r == 0) || (r == kTY3 - 1);
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
+
+  Face6 m, cf, pf;          // planes z-1, z, z+1: stencilled quantities
+  float cU, cV, cW, cdV, cdW, pU, pV, pW, pdV, pdW;  // centre-only extras of planes z and z+1
+  float q[9], hq[9];        // raw rows in flight: own row plane z+2, halo row plane z+1
+  Face6 hcf;                // halo row of the current plane
+  float kc, kn = 0.f;
+  {
+    float raw[9];
+    const size_t rm = f3d_row(g, yy, f3d_mir(z0 - 1, g.D)) + xi;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rm];
+    to_face(raw, m);
+    const size_t rc = f3d_row(g, yy, z0) + xi;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rc];
+    to_face(raw, cf);
+    cU = raw[U]; cV = raw[V]; cW = raw[Wf]; cdV = raw[DV]; cdW = raw[DW];
+    kc = a.in[9][rc];
+    const size_t rp = f3d_row(g, yy, f3d_mir(z0 + 1, g.D)) + xi;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rp];
+    to_face(raw, pf);
+    pU = raw[U]; pV = raw[V]; pW = raw[Wf]; pdV = raw[DV]; pdW = raw[DW];
+    if (edge) {
+      const size_t rh = f3d_row(g, yh_row, z0) + xi;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rh];
+      to_face(raw, hcf);
+    }
+  }
+
+  for (int z = z0; z < z1; ++z) {
+    const bool more = z + 1 < z1;
+    if (more) {
+      const size_t rq = f3d_row(g, yy, f3d_mir(z + 2, g.D)) + xi;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q[i] = a.in[i][rq];
+      kn = a.in[9][f3d_row(g, yy, z + 1) + xi];
+      if (edge) {
+        const size_t rh = f3d_row(g, yh_row, z + 1) + xi;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hq[i] = a.in[i][rh];
+      }
+    }
+
+    const int b = z & 1;
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) sh[b][i][r + 1][lane] = cf.v[i];
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) sh[b][i][lds_halo][lane] = hcf.v[i];
+    }
+    __syncthreads();
+
+    Face6 ym, yp, xm, xp;
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      ym.v[i] = sh[b][i][r][lane];
+      yp.v[i] = sh[b][i][r + 2][lane];
+      xm.v[i] = lane_left(cf.v[i]);
+      xp.v[i] = lane_right(cf.v[i]);
+    }
+    float r_du, r_dv, r_dw;
+    sweep_voxel_s(xm, xp, ym, yp, m, pf, cf.v, cU, cV, cW, cdV, cdW, kc, a.hx, a.hy, a.hz, a.p0, x < g.W - 1, x > 0,
+                  y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    if (owner) {
+      const size_t o = f3d_row(g, yy, z) + xi;
+      a.out[0][o] = r_du;
+      a.out[1][o] = r_dv;
+      a.out[2][o] = r_dw;
+    }
+
+    if (more) {
+      m = cf;
+      cf = pf;
+      cU = pU; cV = pV; cW = pW; cdV = pdV; cdW = pdW;
+      to_face(q, pf);
+      pU = q[U]; pV = q[V]; pW = q[Wf]; pdV = q[DV]; pdW = q[DW];
+      kc = kn;
+      if (edge) to_face(hq, hcf);
+    }
+  }
+}
+
+
+struct Tuning {
+  int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds)
+  int xcd_remap;
+  int zchunk;      // 0 = automatic
+  long want_wg;
+};
+
+const Tuning& tuning()
+{
+  static const Tuning t = [] {
+    Tuning v = {3, 1, 0, 2048};
+    if (const char* e = std::getenv("F3D_SOLVER_VARIANT")) v.variant = std::atoi(e);
+    if (const char* e = std::getenv("F3D_XCD_REMAP")) v.xcd_remap = std::atoi(e);
+    if (const char* e = std::getenv("F3D_ZCHUNK")) v.zchunk = std::atoi(e);
+    if (const char* e = std::getenv("F3D_WANT_WG")) v.want_wg = std::atol(e);
+    return v;
+  }();
+  return t;
+}
+
+template <bool SWEEP>
+void launch_solver(const SolveArgs& a, const F3dGeo& g)
+{
+  const Tuning& t = tuning();
+  const int planes = g.z_hi - g.z_lo;
+  if (t.variant == 1) {
+    dim3 grid;
+    int zchunk = pick_zchunk(g, &grid);
+    if (t.zchunk > 0) {
+      zchunk = t.zchunk;
+      grid.z = (planes + zchunk - 1) / zchunk;
+    }
+    hipLaunchKernelGGL(k_solver<SWEEP>, grid, dim3(kLanes, kTY, 1), 0, f3d::stream(), a, g, zchunk);
+    return;
+  }
+  const bool v3 = SWEEP && t.variant == 3;
+  const int ntx = v3 ? (g.W + kOutX - 1) / kOutX : (g.W + kLanes - 1) / kLanes;
+  const int nty = v3 ? (g.H + kTY3 - 1) / kTY3 : (g.H + kOutRows - 1) / kOutRows;
+  long nzc = (t.want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
+  const long max_chunks = planes / 4 > 0 ? planes / 4 : 1;
+  if (nzc > max_chunks) nzc = max_chunks;
+  if (nzc < 1) nzc = 1;
+  int zchunk = static_cast<int>((planes + nzc - 1) / nzc);
+  if (t.zchunk > 0) zchunk = t.zchunk;
+  const int nz = (planes + zchunk - 1) / zchunk;
+  const int n_tiles = ntx * nty * nz;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int blocks = t.xcd_remap ? per_xcd * 8 : n_tiles;
+  if constexpr (SWEEP) {
+    if (v3) {
+      hipLaunchKernelGGL(k_sweep3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
+                         n_tiles, t.xcd_remap);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(k_solver_lds<SWEEP>, dim3(blocks, 1, 1), dim3(kLanes, kRows, 1), 0, f3d::stream(), a, g, zchunk, ntx,
+                     nty, n_tiles, t.xcd_remap);
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,10 +661,8 @@ int f3d_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_d
   a.hx = hx; a.hy = hy; a.hz = hz;
   a.p0 = equation_smoothness;
   a.p1 = equation_data;
-  dim3 grid;
-  const int zchunk = pick_zchunk(g, &grid);
   f3d::prof_begin(F3D_K_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  hipLaunchKernelGGL(k_solver<false>, grid, dim3(kLanes, kTY, 1), 0, f3d::stream(), a, g, zchunk);
+  launch_solver<false>(a, g);
   f3d::prof_end(F3D_K_PHI_KSI);
   F3D_HIP(hipGetLastError());
   return 0;
@@ -313,10 +688,8 @@ int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f
   a.hx = hx; a.hy = hy; a.hz = hz;
   a.p0 = equation_alpha;
   a.p1 = 0.f;
-  dim3 grid;
-  const int zchunk = pick_zchunk(g, &grid);
   f3d::prof_begin(F3D_K_SWEEP, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  hipLaunchKernelGGL(k_solver<true>, grid, dim3(kLanes, kTY, 1), 0, f3d::stream(), a, g, zchunk);
+  launch_solver<true>(a, g);
   f3d::prof_end(F3D_K_SWEEP);
   F3D_HIP(hipGetLastError());
   return 0;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
+(f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
+   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|phi|both]
+"""
+import argparse
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dims", type=int, nargs=3)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--kernel", default="both")
+    a = ap.parse_args()
+    W, H, D = a.dims if a.dims else (a.size,) * 3
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    hip = pkg.hip()
+    cont = pkg.Containers(W, H, D)
+    rng = np.random.default_rng(1)
+    plane = lambda lo, hi: rng.uniform(lo, hi, size=(1, H, W)).astype(np.float32)
+    ptr = []
+    for lo, hi in [(0, 255), (0, 255), (-3, 3), (-3, 3), (-3, 3), (-.5, .5), (-.5, .5), (-.5, .5)]:
+        p = cont.alloc()
+        base = plane(lo, hi)
+        vol = np.repeat(base, D, axis=0)
+        vol += rng.uniform(-0.01, 0.01, size=(D, 1, 1)).astype(np.float32)
+        cont.upload(p, vol)
+        ptr.append(p)
+    cont.set_current()
+    phi, ksi = cont.alloc(fill=0), cont.alloc(fill=0)
+    out = [cont.alloc(fill=0) for _ in range(3)]
+    h = (1.0, 1.0, 1.0)
+    pkg.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
+    pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+    pkg.sync()
+    hip.f3d_prof_reset()
+    hip.f3d_prof_enable(1)
+    for _ in range(a.reps):
+        if a.kernel in ("phi", "both"):
+            pkg.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
+        if a.kernel in ("sweep", "both"):
+            pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+    pkg.sync()
+    for kid, name, bpv in ((0, "phi_ksi", 40.0), (1, "sweep", 52.0)):
+        ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
+        hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox))
+        if n.value:
+            us = ms.value / n.value * 1e3
+            gbs = bpv * vox.value / (ms.value * 1e-3) / 1e9
+            print(f"{name:8s} {W}x{H}x{D}: {us:9.1f} us/launch  {gbs:8.1f} GB/s algorithmic  ({gbs / 80:.1f} % of 8 TB/s)")
+    cont.free()
+
+
+if __name__ == "__main__":
+    main()

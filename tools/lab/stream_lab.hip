@@ -1,0 +1,107 @@
+// Lab: what does the MI355X memory system deliver for the sweep's access shape (10 input + 3 output streams, 512^3)?
+//  A: flat grid-stride float4 copy-sum (ceiling)            B: flat dword
+//  C: z-march, wave = 64-float row, WG = TY rows, 10 loads + 3 stores / voxel / step (no neighbours), prefetch 1 plane
+//  D: C + the y-neighbour row loads of 9 arrays (28 loads), like k_solver v1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+struct Args { const float* in[10]; float* out[3]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_flat(Args a, size_t n)
+{
+  const size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T s = reinterpret_cast<const T*>(a.in[0])[i];
+#pragma unroll
+    for (int k = 1; k < 10; ++k) s += reinterpret_cast<const T*>(a.in[k])[i];
+    reinterpret_cast<T*>(a.out[0])[i] = s;
+    reinterpret_cast<T*>(a.out[1])[i] = s * 2.f;
+    reinterpret_cast<T*>(a.out[2])[i] = s * 3.f;
+  }
+}
+
+template <int TY, bool YN>
+__global__ __launch_bounds__(64 * TY) void k_march(Args a, int W, int H, int D, int pitch, int zchunk)
+{
+  const int lane = threadIdx.x;
+  const int y = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * TY + int(threadIdx.y));
+  const int x = blockIdx.x * 64 + lane;
+  const int z0 = blockIdx.z * zchunk, z1 = min(z0 + zchunk, D);
+  if (y >= H || x >= W) return;
+  const int yl = y == 0 ? 1 : y - 1, yh = y == H - 1 ? H - 2 : y + 1;
+  float c[10], q[10], l[9], h[9], nl[9], nh[9];
+  auto row = [&](int yy, int zz) { return (size_t(zz) * H + yy) * pitch + x; };
+#pragma unroll
+  for (int i = 0; i < 10; ++i) c[i] = a.in[i][row(y, z0)];
+  if (YN) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { l[i] = a.in[i][row(yl, z0)]; h[i] = a.in[i][row(yh, z0)]; }
+  }
+  for (int z = z0; z < z1; ++z) {
+    const bool more = z + 1 < z1;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) q[i] = a.in[i][row(y, z + 1)];
+      if (YN) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { nl[i] = a.in[i][row(yl, z + 1)]; nh[i] = a.in[i][row(yh, z + 1)]; }
+      }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s += c[i];
+    if (YN) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s += l[i] - h[i];
+    }
+    const size_t o = row(y, z);
+    a.out[0][o] = s; a.out[1][o] = s * 2.f; a.out[2][o] = s * 3.f;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) c[i] = q[i];
+      if (YN) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { l[i] = nl[i]; h[i] = nh[i]; }
+      }
+    }
+  }
+}
+
+int main()
+{
+  const int W = 512, H = 512, D = 512, pitch = 512;
+  const size_t n = size_t(W) * H * D;
+  Args a;
+  std::vector<float> host(n);
+  for (size_t i = 0; i < n; ++i) host[i] = float(i % 977) * 1e-3f;
+  for (int i = 0; i < 10; ++i) { float* p; CK(hipMalloc(&p, n * 4 + 256)); CK(hipMemcpy(p, host.data(), n * 4, hipMemcpyHostToDevice)); a.in[i] = p; }
+  for (int i = 0; i < 3; ++i) { float* p; CK(hipMalloc(&p, n * 4 + 256)); a.out[i] = p; }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto time = [&](const char* name, auto launch) {
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) launch();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    printf("%-44s %8.3f ms  %7.1f GB/s (52 B/voxel)\n", name, ms, 52.0 * n / (ms * 1e-3) / 1e9);
+    return 0;
+  };
+  time("A flat float4, 2048 blocks", [&] { k_flat<float4><<<2048, 256>>>(a, n / 4); });
+  time("A flat float4, 8192 blocks", [&] { k_flat<float4><<<8192, 256>>>(a, n / 4); });
+  time("B flat dword, 4096 blocks", [&] { k_flat<float><<<4096, 256>>>(a, n); });
+  for (int zc : {512, 128, 32}) {
+    char nm[64];
+    snprintf(nm, 64, "C march TY=4 zchunk=%d", zc);
+    time(nm, [&] { k_march<4, false><<<dim3(W / 64, H / 4, D / zc), dim3(64, 4)>>>(a, W, H, D, pitch, zc); });
+    snprintf(nm, 64, "C march TY=8 zchunk=%d", zc);
+    time(nm, [&] { k_march<8, false><<<dim3(W / 64, H / 8, D / zc), dim3(64, 8)>>>(a, W, H, D, pitch, zc); });
+    snprintf(nm, 64, "D march+yn TY=4 zchunk=%d", zc);
+    time(nm, [&] { k_march<4, true><<<dim3(W / 64, H / 4, D / zc), dim3(64, 4)>>>(a, W, H, D, pitch, zc); });
+    snprintf(nm, 64, "D march+yn TY=8 zchunk=%d", zc);
+    time(nm, [&] { k_march<8, true><<<dim3(W / 64, H / 8, D / zc), dim3(64, 8)>>>(a, W, H, D, pitch, zc); });
+  }
+  return 0;
+}
