@@ -452,6 +452,17 @@ __device__ __forceinline__ void sweep_voxel_s(const Face6& xm, const Face6& xp, 
   r_dw = (ksi * (-J34 - J13 * r_du - J23 * r_dv) + sumW) / (ksi * J33 + sumH);
 }
 
+// Buffer-resource access (guide T8): a 128-bit descriptor per input array, a wave-uniform row offset in an SGPR
+// (soffset) and the lane's byte offset in one VGPR -- a load costs no VALU address arithmetic at all.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, unsigned row_bytes)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, row_bytes, 0));
+}
+
 // raw 9-array row sample -> the six stencilled quantities
 __device__ __forceinline__ void to_face(const float (&raw)[9], Face6& f)
 {
@@ -461,6 +472,26 @@ __device__ __forceinline__ void to_face(const float (&raw)[9], Face6& f)
   f.v[LSU] = raw[U] + raw[DU];
   f.v[LSV] = raw[V] + raw[DV];
   f.v[LSW] = raw[Wf] + raw[DW];
+}
+
+// One plane of the z-window of a lane: the nine streamed inputs, rewritten in place into what the stencil needs
+// (du becomes Su = u + du; Sv, Sw are kept beside dv, dw because the in-voxel Gauss-Seidel step still needs those).
+struct PlaneRegs {
+  float f0, f1, phi, u, v, w, su, dv, dw, sv, sw, ksi;
+};
+
+__device__ __forceinline__ void plane_finish(PlaneRegs& p)
+{
+  p.su = p.u + p.su;  // su held the raw du
+  p.sv = p.v + p.dv;
+  p.sw = p.w + p.dw;
+}
+
+__device__ __forceinline__ Face6 plane_face(const PlaneRegs& p)
+{
+  Face6 f;
+  f.v[LF0] = p.f0; f.v[LF1] = p.f1; f.v[LPHI] = p.phi; f.v[LSU] = p.su; f.v[LSV] = p.sv; f.v[LSW] = p.sw;
+  return f;
 }
 
 __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
@@ -487,62 +518,57 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
   const int x = tx * kOutX - 1 + lane;
   const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
   const bool owner = lane >= 1 && lane <= kOutX && x < g.W && y < g.H;
   // edge waves stream the workgroup's y-halo rows: row y0-1 (wave 0) and row y0+TY (last wave)
   const bool edge = (r == 0) || (r == kTY3 - 1);
   const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
   const int lds_halo = r == 0 ? 0 : kTY3 + 1;
 
-  Face6 m, cf, pf;          // planes z-1, z, z+1: stencilled quantities
-  float cU, cV, cW, cdV, cdW, pU, pV, pW, pdV, pdW;  // centre-only extras of planes z and z+1
-  float q[9], hq[9];        // raw rows in flight: own row plane z+2, halo row plane z+1
-  Face6 hcf;                // halo row of the current plane
-  float kc, kn = 0.f;
-  {
-    float raw[9];
-    const size_t rm = f3d_row(g, yy, f3d_mir(z0 - 1, g.D)) + xi;
+  // descriptors are based at the first plane this chunk touches, so every offset fits 32 bits
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
+  __amdgpu_buffer_rsrc_t rs[10];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rm];
-    to_face(raw, m);
-    const size_t rc = f3d_row(g, yy, z0) + xi;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rc];
-    to_face(raw, cf);
-    cU = raw[U]; cV = raw[V]; cW = raw[Wf]; cdV = raw[DV]; cdW = raw[DW];
-    kc = a.in[9][rc];
-    const size_t rp = f3d_row(g, yy, f3d_mir(z0 + 1, g.D)) + xi;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rp];
-    to_face(raw, pf);
-    pU = raw[U]; pV = raw[V]; pW = raw[Wf]; pdV = raw[DV]; pdW = raw[DW];
-    if (edge) {
-      const size_t rh = f3d_row(g, yh_row, z0) + xi;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) raw[i] = a.in[i][rh];
-      to_face(raw, hcf);
-    }
-  }
+  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
+  auto rowoff = [&](int yrow, int zz) {  // wave-uniform by construction; say so, or hipcc builds waterfall loops (T20)
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](PlaneRegs& p, int yrow, int zz) {  // issue only; plane_finish() after the data is needed
+    const unsigned ro = rowoff(yrow, zz);
+    p.f0 = buf_ld(rs[F0], xb, ro);
+    p.f1 = buf_ld(rs[F1], xb, ro);
+    p.u = buf_ld(rs[U], xb, ro);
+    p.v = buf_ld(rs[V], xb, ro);
+    p.w = buf_ld(rs[Wf], xb, ro);
+    p.su = buf_ld(rs[DU], xb, ro);
+    p.dv = buf_ld(rs[DV], xb, ro);
+    p.dw = buf_ld(rs[DW], xb, ro);
+    p.phi = buf_ld(rs[PHI], xb, ro);
+  };
 
-  for (int z = z0; z < z1; ++z) {
+  // One z step.  M, C, P hold planes z-1, z, z+1 (finished); Q receives plane z+2; Hc is the finished halo row of
+  // plane z (edge waves only), Hn receives the halo row of plane z+1.
+  auto step = [&](const PlaneRegs& M, const PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, const PlaneRegs& Hc, PlaneRegs& Hn,
+                  int z) {
     const bool more = z + 1 < z1;
     if (more) {
-      const size_t rq = f3d_row(g, yy, f3d_mir(z + 2, g.D)) + xi;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) q[i] = a.in[i][rq];
-      kn = a.in[9][f3d_row(g, yy, z + 1) + xi];
-      if (edge) {
-        const size_t rh = f3d_row(g, yh_row, z + 1) + xi;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) hq[i] = a.in[i][rh];
-      }
+      load_plane(Q, yy, f3d_mir(z + 2, g.D));
+      P.ksi = buf_ld(rs[9], xb, rowoff(yy, z + 1));
+      if (edge) load_plane(Hn, yh_row, z + 1);
     }
-
     const int b = z & 1;
+    const Face6 cf = plane_face(C);
 #pragma unroll
     for (int i = 0; i < kNL; ++i) sh[b][i][r + 1][lane] = cf.v[i];
     if (edge) {
+      const Face6 hf = plane_face(Hc);
 #pragma unroll
-      for (int i = 0; i < kNL; ++i) sh[b][i][lds_halo][lane] = hcf.v[i];
+      for (int i = 0; i < kNL; ++i) sh[b][i][lds_halo][lane] = hf.v[i];
     }
     __syncthreads();
 
@@ -555,27 +581,39 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
       xp.v[i] = lane_right(cf.v[i]);
     }
     float r_du, r_dv, r_dw;
-    sweep_voxel_s(xm, xp, ym, yp, m, pf, cf.v, cU, cV, cW, cdV, cdW, kc, a.hx, a.hy, a.hz, a.p0, x < g.W - 1, x > 0,
-                  y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
     if (owner) {
       const size_t o = f3d_row(g, yy, z) + xi;
       a.out[0][o] = r_du;
       a.out[1][o] = r_dv;
       a.out[2][o] = r_dw;
     }
-
     if (more) {
-      m = cf;
-      cf = pf;
-      cU = pU; cV = pV; cW = pW; cdV = pdV; cdW = pdW;
-      to_face(q, pf);
-      pU = q[U]; pV = q[V]; pW = q[Wf]; pdV = q[DV]; pdW = q[DW];
-      kc = kn;
-      if (edge) to_face(hq, hcf);
+      plane_finish(Q);
+      if (edge) plane_finish(Hn);
     }
+  };
+
+  PlaneRegs A, B, C, D, H0, H1;
+  load_plane(A, yy, f3d_mir(z0 - 1, g.D));
+  load_plane(B, yy, z0);
+  B.ksi = buf_ld(rs[9], xb, rowoff(yy, z0));
+  load_plane(C, yy, f3d_mir(z0 + 1, g.D));
+  if (edge) load_plane(H0, yh_row, z0);
+  plane_finish(A);
+  plane_finish(B);
+  plane_finish(C);
+  if (edge) plane_finish(H0);
+
+  // the four plane register sets take the roles (z-1, z, z+1, z+2) in rotation: no register moves per step
+  for (int z = z0; z < z1; z += 4) {
+    step(A, B, C, D, H0, H1, z);
+    if (z + 1 < z1) step(B, C, D, A, H1, H0, z + 1);
+    if (z + 2 < z1) step(C, D, A, B, H0, H1, z + 2);
+    if (z + 3 < z1) step(D, A, B, C, H1, H0, z + 3);
   }
 }
-
 
 struct Tuning {
   int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds)
