@@ -494,6 +494,7 @@ __device__ __forceinline__ Face6 plane_face(const PlaneRegs& p)
   return f;
 }
 
+template <bool ALIGNED, bool CLEANWAIT>
 __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                             int xcd_remap)
 {
@@ -516,10 +517,14 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   const int y0 = ty * kTY3;
   const int y = y0 + r;
   const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x = tx * kOutX - 1 + lane;
+  const int x = ALIGNED ? tx * kLanes + lane : tx * kOutX - 1 + lane;
   const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
   const unsigned xb = static_cast<unsigned>(xi) * 4u;
-  const bool owner = lane >= 1 && lane <= kOutX && x < g.W && y < g.H;
+  const bool owner = (ALIGNED || (lane >= 1 && lane <= kOutX)) && x < g.W && y < g.H;
+  // aligned tiles: the two x-halo columns of the row come from one narrow load per array (lanes < 32 fetch
+  // column x0-1, the others x0+64) that the DPP shift keeps in the edge lane
+  const int xh = f3d_clampi(f3d_mir(lane < 32 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
   // edge waves stream the workgroup's y-halo rows: row y0-1 (wave 0) and row y0+TY (last wave)
   const bool edge = (r == 0) || (r == kTY3 - 1);
   const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
@@ -556,6 +561,19 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   auto step = [&](const PlaneRegs& M, const PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, const PlaneRegs& Hc, PlaneRegs& Hn,
                   int z) {
     const bool more = z + 1 < z1;
+    PlaneRegs X;  // x-halo columns of plane z (aligned tiles only)
+    if (ALIGNED) {
+      const unsigned ro = rowoff(yy, z);
+      X.f0 = buf_ld(rs[F0], xhb, ro);
+      X.f1 = buf_ld(rs[F1], xhb, ro);
+      X.u = buf_ld(rs[U], xhb, ro);
+      X.v = buf_ld(rs[V], xhb, ro);
+      X.w = buf_ld(rs[Wf], xhb, ro);
+      X.su = buf_ld(rs[DU], xhb, ro);
+      X.dv = buf_ld(rs[DV], xhb, ro);
+      X.dw = buf_ld(rs[DW], xhb, ro);
+      X.phi = buf_ld(rs[PHI], xhb, ro);
+    }
     if (more) {
       load_plane(Q, yy, f3d_mir(z + 2, g.D));
       P.ksi = buf_ld(rs[9], xb, rowoff(yy, z + 1));
@@ -577,22 +595,51 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
     for (int i = 0; i < kNL; ++i) {
       ym.v[i] = sh[b][i][r][lane];
       yp.v[i] = sh[b][i][r + 2][lane];
-      xm.v[i] = lane_left(cf.v[i]);
-      xp.v[i] = lane_right(cf.v[i]);
+    }
+    if (ALIGNED) {
+      if (CLEANWAIT) {  // wait for the x-halo loads only: they were issued before this step's plane loads
+        if (!more) __builtin_amdgcn_s_waitcnt(0x0F70);
+        else if (edge) __builtin_amdgcn_s_waitcnt(0x4F73);  // vmcnt(19)
+        else __builtin_amdgcn_s_waitcnt(0x0F7A);            // vmcnt(10)
+      }
+      plane_finish(X);
+      const Face6 xf = plane_face(X);
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) {
+        xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+        xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) {
+        xm.v[i] = lane_left(cf.v[i]);
+        xp.v[i] = lane_right(cf.v[i]);
+      }
     }
     float r_du, r_dv, r_dw;
     sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
                   a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    // Consume this step's loads HERE: the wait lands after the arithmetic (the loads had the whole step to
+    // arrive) and before the stores are issued, so it never waits for a store, and nothing issued in the next
+    // step sits between these loads and their first use (vmcnt counts in order).
+    if (CLEANWAIT) {
+      // pin the arithmetic before the wait (otherwise it is sunk into the `if (owner)` store block behind it)
+      asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this step (and the previous step's stores)
+    }
+    if (more) {
+      plane_finish(Q);
+      if (edge) plane_finish(Hn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (owner) {
       const size_t o = f3d_row(g, yy, z) + xi;
       a.out[0][o] = r_du;
       a.out[1][o] = r_dv;
       a.out[2][o] = r_dw;
     }
-    if (more) {
-      plane_finish(Q);
-      if (edge) plane_finish(Hn);
-    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   PlaneRegs A, B, C, D, H0, H1;
@@ -601,11 +648,13 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   B.ksi = buf_ld(rs[9], xb, rowoff(yy, z0));
   load_plane(C, yy, f3d_mir(z0 + 1, g.D));
   if (edge) load_plane(H0, yh_row, z0);
+  if (CLEANWAIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing in flight
   plane_finish(A);
   plane_finish(B);
   plane_finish(C);
   if (edge) plane_finish(H0);
 
+  __builtin_amdgcn_sched_barrier(0);
   // the four plane register sets take the roles (z-1, z, z+1, z+2) in rotation: no register moves per step
   for (int z = z0; z < z1; z += 4) {
     step(A, B, C, D, H0, H1, z);
@@ -615,8 +664,131 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   }
 }
 
+// ---- variant 3, phi/ksi: same data movement as k_sweep3 (aligned 64-wide tiles, rows of the current plane through a
+// double-buffered LDS image, edge waves stream the y-halo rows, four rotating plane register sets); all eight inputs
+// are stencilled here (the central differences of A.3 do not factor), and there is nothing to pre-combine.
+struct Plane8 {
+  float v[8];
+};
+
+__global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                             int xcd_remap)
+{
+  __shared__ float sh[2][8][kTY3 + 2][kLanes];
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * kTY3;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kLanes + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool owner = x < g.W && y < g.H;
+  const int xh = f3d_clampi(f3d_mir(lane < 32 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
+  const bool edge = (r == 0) || (r == kTY3 - 1);
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
+
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
+  __amdgpu_buffer_rsrc_t rs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](Plane8& p, unsigned lane_bytes, int yrow, int zz) {
+    const unsigned ro = rowoff(yrow, zz);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.v[i] = buf_ld(rs[i], lane_bytes, ro);
+  };
+
+  auto step = [&](const Plane8& M, const Plane8& C, const Plane8& P, Plane8& Q, const Plane8& Hc, Plane8& Hn, int z) {
+    const bool more = z + 1 < z1;
+    Plane8 X;
+    load_plane(X, xhb, yy, z);
+    if (more) {
+      load_plane(Q, xb, yy, f3d_mir(z + 2, g.D));
+      if (edge) load_plane(Hn, xb, yh_row, z + 1);
+    }
+    const int b = z & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh[b][i][r + 1][lane] = C.v[i];
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sh[b][i][lds_halo][lane] = Hc.v[i];
+    }
+    __syncthreads();
+
+    Hood<8> n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      n.c[i] = C.v[i];
+      n.ym[i] = sh[b][i][r][lane];
+      n.yp[i] = sh[b][i][r + 2][lane];
+      n.zm[i] = M.v[i];
+      n.zp[i] = P.v[i];
+    }
+    // wait for the x-halo loads only: they were issued before this step's plane loads
+    if (!more) __builtin_amdgcn_s_waitcnt(0x0F70);
+    else if (edge) __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16)
+    else __builtin_amdgcn_s_waitcnt(0x0F78);            // vmcnt(8)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      n.xm[i] = lane_left_or(C.v[i], X.v[i]);
+      n.xp[i] = lane_right_or(C.v[i], X.v[i]);
+    }
+    float phi, ksi;
+    phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
+    asm volatile("" ::"v"(phi), "v"(ksi));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's plane loads (and the previous step's stores)
+    __builtin_amdgcn_sched_barrier(0);
+    if (owner) {
+      const size_t o = f3d_row(g, yy, z) + xi;
+      a.out[0][o] = phi;
+      a.out[1][o] = ksi;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  Plane8 A, B, C, D, H0, H1;
+  load_plane(A, xb, yy, f3d_mir(z0 - 1, g.D));
+  load_plane(B, xb, yy, z0);
+  load_plane(C, xb, yy, f3d_mir(z0 + 1, g.D));
+  if (edge) load_plane(H0, xb, yh_row, z0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int z = z0; z < z1; z += 4) {
+    step(A, B, C, D, H0, H1, z);
+    if (z + 1 < z1) step(B, C, D, A, H1, H0, z + 1);
+    if (z + 2 < z1) step(C, D, A, B, H0, H1, z + 2);
+    if (z + 3 < z1) step(D, A, B, C, H1, H0, z + 3);
+  }
+}
+
 struct Tuning {
-  int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds)
+  int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds), 3 = k_sweep3 (sweep) + 2 (phi/ksi)
+  int aligned;     // variant 3: 64-aligned x tiles with narrow x-halo loads instead of overlapping 62-wide tiles
+  int cleanwait;   // variant 3: explicit end-of-step vmcnt(0)
   int xcd_remap;
   int zchunk;      // 0 = automatic
   long want_wg;
@@ -625,9 +797,11 @@ struct Tuning {
 const Tuning& tuning()
 {
   static const Tuning t = [] {
-    Tuning v = {3, 1, 0, 2048};
+    Tuning v = {3, 1, 1, 1, 0, 4096};
     if (const char* e = std::getenv("F3D_SOLVER_VARIANT")) v.variant = std::atoi(e);
     if (const char* e = std::getenv("F3D_XCD_REMAP")) v.xcd_remap = std::atoi(e);
+    if (const char* e = std::getenv("F3D_ALIGNED")) v.aligned = std::atoi(e);
+    if (const char* e = std::getenv("F3D_CLEANWAIT")) v.cleanwait = std::atoi(e);
     if (const char* e = std::getenv("F3D_ZCHUNK")) v.zchunk = std::atoi(e);
     if (const char* e = std::getenv("F3D_WANT_WG")) v.want_wg = std::atol(e);
     return v;
@@ -650,8 +824,8 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
     hipLaunchKernelGGL(k_solver<SWEEP>, grid, dim3(kLanes, kTY, 1), 0, f3d::stream(), a, g, zchunk);
     return;
   }
-  const bool v3 = SWEEP && t.variant == 3;
-  const int ntx = v3 ? (g.W + kOutX - 1) / kOutX : (g.W + kLanes - 1) / kLanes;
+  const bool v3 = t.variant == 3;
+  const int ntx = (v3 && SWEEP && !t.aligned) ? (g.W + kOutX - 1) / kOutX : (g.W + kLanes - 1) / kLanes;
   const int nty = v3 ? (g.H + kTY3 - 1) / kTY3 : (g.H + kOutRows - 1) / kOutRows;
   long nzc = (t.want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
   const long max_chunks = planes / 4 > 0 ? planes / 4 : 1;
@@ -665,7 +839,19 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   const int blocks = t.xcd_remap ? per_xcd * 8 : n_tiles;
   if constexpr (SWEEP) {
     if (v3) {
-      hipLaunchKernelGGL(k_sweep3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
+      const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
+      auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
+      if (t.aligned) {
+        if (t.cleanwait) go(k_sweep3<true, true>); else go(k_sweep3<true, false>);
+      } else {
+        if (t.cleanwait) go(k_sweep3<false, true>); else go(k_sweep3<false, false>);
+      }
+      return;
+    }
+  }
+  if constexpr (!SWEEP) {
+    if (v3) {
+      hipLaunchKernelGGL(k_phiksi3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
                          n_tiles, t.xcd_remap);
       return;
     }
