@@ -1,0 +1,169 @@
+"""Whole-path parity on the MI355X: the driver (OpticalFlowE::ComputeFlow through the C ABI) and the operator classes
+against the oracle and the committed golden fixtures.  Tolerance: the north star allows RMS 1e-4; because every kernel
+is bit-faithful the tests demand max |diff| == 0 (sign of zero aside) and report the RMS in the assertion message."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import same
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def digest(*vols):
+    h = hashlib.sha256()
+    for v in vols:
+        h.update(np.ascontiguousarray(v + np.float32(0.0)).tobytes())
+    return h.hexdigest()
+
+
+def run_flow(f3d, f0, f1, **kw):
+    d, h, w = f0.shape
+    flow = f3d.OpticalFlow()
+    flow.initialize(w, h, d)
+    try:
+        return flow.compute(f0, f1, silent=True, **kw)
+    finally:
+        flow.destroy()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    e = np.load(os.path.join(GOLD, "expected_oracle.npz"))
+    i128 = np.load(os.path.join(GOLD, "inputs_128.npz"))
+    irub = np.load(os.path.join(GOLD, "inputs_rub.npz"))
+    f0 = i128["frame_0"].astype(np.float32)
+    f1 = i128["frame_1"].astype(np.float32)
+    r0 = np.repeat(irub["slice_0"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    r1 = np.repeat(irub["slice_1"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    return dict(e=e, f0=f0, f1=f1, r0=r0, r1=r1)
+
+
+def check3(got, exp, what):
+    for g, e, n in zip(got, exp, "uvw"):
+        assert np.isfinite(g).all(), f"{what}: {n} not finite"
+        assert same(g, e), f"{what}: component {n} differs, rms {rms(g, e):.3e}, max {np.abs(g - e).max():.3e}"
+
+
+def test_small_synthetic_pair_matches_oracle_live(f3d, oracle):
+    f0, f1 = f3d.synth_pair(40, 36, 32)
+    got = run_flow(f3d, f0, f1)
+    (exp, levels) = oracle.compute_flow(f0, f1)
+    assert levels == f3d.max_warp_level(40, 36, 32, 0.95) or levels == 40
+    check3(got, exp, "40x36x32 synthetic, defaults")
+    # property: the known translation (+2, -1, +0.5) is recovered in the textured interior
+    inner = (slice(8, -8),) * 3
+    means = [float(g[inner].mean()) for g in got]
+    assert abs(means[0] - 2.0) < 0.15 and abs(means[1] + 1.0) < 0.15 and abs(means[2] - 0.5) < 0.15, means
+
+
+def test_c1_plumbing_config(f3d, gold):
+    """BASELINE config 1: 128^3 pair, 1 level, 1 x 5 iterations."""
+    u, v, w = run_flow(f3d, gold["f0"], gold["f1"], warp_levels_count=1, outer_iterations_count=1, inner_iterations_count=5)
+    c = slice(48, 80)
+    check3([a[c, c, c] for a in (u, v, w)], gold["e"]["c1_crop"], "C1 centre crop")
+    assert digest(u, v, w) == str(gold["e"]["c1_sha256"])
+
+
+def test_crop_pipelines_match_golden(f3d, gold):
+    crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+    got = run_flow(f3d, gold["f0"][crop].copy(), gold["f1"][crop].copy())
+    check3(got, gold["e"]["crop128_flow"], "48x40x24 crop of the 128^3 pair")
+    rc = (slice(0, 5), slice(100, 164), slice(200, 296))
+    got = run_flow(f3d, gold["r0"][rc].copy(), gold["r1"][rc].copy())
+    check3(got, gold["e"]["croprub_flow"], "96x64x5 crop of the rub pair")
+
+
+def test_c2_full_128_defaults(f3d, gold):
+    """BASELINE config 2: 128^3 pair, full pyramid (40 levels, 40 x 5)."""
+    u, v, w = run_flow(f3d, gold["f0"], gold["f1"])
+    check3([a[64] for a in (u, v, w)], gold["e"]["c2_slice_z"], "C2 z-slice")
+    check3([a[:, 64] for a in (u, v, w)], gold["e"]["c2_slice_y"], "C2 y-slice")
+    assert digest(u, v, w) == str(gold["e"]["c2_sha256"])
+
+
+def test_c3_thin_slab_defaults(f3d, gold):
+    """BASELINE config 3: 584 x 388 x 5, 10 levels, depth 5 -> 4, anisotropic spacing."""
+    u, v, w = run_flow(f3d, gold["r0"], gold["r1"])
+    check3([a[2][130:258, 228:356] for a in (u, v, w)], gold["e"]["c3_slice_z"], "C3 z-slice window")
+    check3([a[:, 194] for a in (u, v, w)], gold["e"]["c3_slice_y"], "C3 y-slice")
+    assert digest(u, v, w) == str(gold["e"]["c3_sha256"])
+    # five identical slices in: w stays tiny
+    assert float(np.abs(w).max()) < 1.0
+
+
+def test_identical_frames_give_zero_flow(f3d):
+    f0, _ = f3d.synth_pair(48, 40, 24)
+    u, v, w = run_flow(f3d, f0, f0.copy(), warp_levels_count=8, outer_iterations_count=5)
+    assert float(np.abs(u).max()) == 0.0 and float(np.abs(v).max()) == 0.0 and float(np.abs(w).max()) == 0.0
+
+
+def test_resident_path_equals_host_path(f3d):
+    f0, f1 = f3d.synth_pair(40, 36, 24)
+    kw = dict(warp_levels_count=10, outer_iterations_count=6)
+    a = run_flow(f3d, f0, f1, **kw)
+    flow = f3d.OpticalFlow()
+    flow.initialize(40, 36, 24)
+    flow.upload(f0, f1)
+    flow.compute_resident(**kw)
+    flow.compute_resident(**kw)  # repeatable: the raw frames are not consumed
+    b = flow.download()
+    flow.destroy()
+    check3(b, a, "resident vs host entry point")
+
+
+def test_solve_operator_through_the_bag(f3d, oracle):
+    """CudaOperationSolve with the reference's parameter keys; the swapped du/temp pointers come back through the bag."""
+    rng = np.random.default_rng(5)
+    dims, cdims = (37, 21, 9), (64, 24, 12)
+    W, H, D = dims
+    cont = f3d.Containers(*cdims)
+
+    def put(lo, hi):
+        c = np.full((cdims[2], cdims[1], cdims[0]), np.nan, np.float32)
+        c[:D, :H, :W] = rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32)
+        return c, cont.new(c)
+
+    hosts, ptrs = zip(*[put(*r) for r in [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2)]])
+    names = ["dev_flow_du", "dev_flow_dv", "dev_flow_dw", "dev_phi", "dev_ksi", "dev_temp_du", "dev_temp_dv", "dev_temp_dw"]
+    extra = {n: cont.new() for n in names}
+    op = f3d.Operation("solve")
+    assert op.name == "CUDA Solve" and op.initialize(cont)
+    h = (1.5, 1.2, 2.0)
+    outer, inner = 3, 5
+    vals = op.execute(dev_frame_0=ptrs[0], dev_frame_1=ptrs[1], dev_flow_u=ptrs[2], dev_flow_v=ptrs[3], dev_flow_w=ptrs[4],
+                      outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5,
+                      equation_smoothness=0.001, equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **extra)
+    f3d.sync()
+    # oracle
+    du = np.full_like(hosts[0], np.nan); du[:, :, :W] = 0
+    dv, dw = du.copy(), du.copy()
+    for _ in range(outer):
+        phi, ksi = oracle.phi_ksi(*hosts, du, dv, dw, dims, h, 0.001, 0.001)
+        for _ in range(inner):
+            du, dv, dw = oracle.solve_sweep(*hosts, du, dv, dw, phi, ksi, dims, h, 7.5)
+    # 15 swaps: the final increments live where dev_temp_d* started
+    assert vals["dev_flow_du"] == extra["dev_temp_du"] and vals["dev_temp_du"] == extra["dev_flow_du"]
+    for key, e in (("dev_flow_du", du), ("dev_flow_dv", dv), ("dev_flow_dw", dw)):
+        g = cont.download(vals[key], cdims)
+        assert same(g[:D, :H, :W], e[:D, :H, :W]), key
+    op.destroy()
+    cont.free()
+
+
+def test_missing_key_is_reported_not_fatal(f3d, capfd):
+    cont = f3d.Containers(16, 8, 8)
+    p = cont.new()
+    op = f3d.Operation("add")
+    assert op.initialize(cont)
+    op.execute(operand_0=p, data_size=(8, 8, 8))  # operand_1 missing: prints and returns, like the reference macro
+    op.destroy()
+    cont.free()
+    assert "Missing parameter 'operand_1'" in capfd.readouterr().out
