@@ -6,6 +6,9 @@
 
 #include <cmath>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace f3d_synth {
 
@@ -75,6 +78,9 @@ float Render(const std::vector<Blob>& blobs, size_t w, size_t h, size_t d, const
 
 void TranslatedGaussianPair(size_t w, size_t h, size_t d, float* frame_0, float* frame_1)
 {
+#ifdef _OPENMP
+  if (omp_get_max_threads() > 16) omp_set_num_threads(16);  // stay within the per-GPU CPU share of a shared box
+#endif
   SplitMix64 rng{kSeed};
   const double dims[3] = {static_cast<double>(w), static_cast<double>(h), static_cast<double>(d)};
   const double m = (dims[0] + dims[1] + dims[2]) / 3.0;

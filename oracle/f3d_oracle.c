@@ -21,7 +21,19 @@
 
 /* mirror index of the reference halo loads: src/kernels/solve_3d.cu:73-75,89-90,104-105;
  * src/kernels/median_3d.cu:70-72,79-80,87-88 */
+/* small levels run serially: forking a team costs more than the loop */
+#define ORC_BIG(g, W, H) ((long)(W) * (H) * ((g)->z_hi - (g)->z_lo) > 20000)
+
 static inline int mir(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - i - 2 : i); }
+
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 int orc_num_threads(void)
 {
@@ -91,7 +103,7 @@ void orc_conv_axis(float* dst, const float* src, int W, int H, int D, int radius
                    const float* taps, int axis, const orc_geom* g)
 {
   const int n[3] = { W, H, D };
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g, W, H))
   for (int z = g->z_lo; z < g->z_hi; z++)
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -116,7 +128,7 @@ void orc_resample_axis(const float* in, float* out, int ow, int oh, int od, int 
   const float delta = (float)in_n / (float)out_n;
   const float normalization = (float)out_n / (float)in_n;
   (void)od;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g_out, ow, oh))
   for (int z = g_out->z_lo; z < g_out->z_hi; z++)
     for (int y = 0; y < oh; y++)
       for (int x = 0; x < ow; x++) {
@@ -146,7 +158,7 @@ void orc_resample_axis(const float* in, float* out, int ow, int oh, int od, int 
 void orc_warp(const float* f0, const float* f1, const float* u, const float* v, const float* w,
               int W, int H, int D, float hx, float hy, float hz, float* out, const orc_geom* g)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g, W, H))
   for (int z = g->z_lo; z < g->z_hi; z++)
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -187,7 +199,7 @@ void orc_phi_ksi(const float* f0, const float* f1, const float* u, const float* 
                  float hx, float hy, float hz, float eps_s, float eps_d,
                  float* phi, float* ksi, const orc_geom* g)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g, W, H))
   for (int z = g->z_lo; z < g->z_hi; z++)
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -235,7 +247,7 @@ void orc_solve_sweep(const float* f0, const float* f1, const float* u, const flo
                      int W, int H, int D, float hx, float hy, float hz, float alpha,
                      float* tdu, float* tdv, float* tdw, const orc_geom* g)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g, W, H))
   for (int z = g->z_lo; z < g->z_hi; z++)
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -297,7 +309,7 @@ void orc_solve_sweep(const float* f0, const float* f1, const float* u, const flo
 void orc_add(float* a, const float* b, int W, int H, int D, const orc_geom* g)
 {
   (void)D;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (ORC_BIG(g, W, H))
   for (int z = g->z_lo; z < g->z_hi; z++)
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -322,7 +334,7 @@ void orc_median(const float* in, float* out, int W, int H, int D, int r, const o
 {
   const int h = r / 2;
   const int len = r * r * r;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if ((long)W * H * (g->z_hi - g->z_lo) > 2000)
   for (int z = g->z_lo; z < g->z_hi; z++) {
     float buffer[343];
     for (int y = 0; y < H; y++)

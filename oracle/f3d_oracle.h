@@ -92,6 +92,7 @@ int orc_compute_flow(const float* frame0, const float* frame1, size_t W, size_t 
                      const orc_params* p, int pitch_f, float* u, float* v, float* w);
 
 int orc_num_threads(void);
+void orc_set_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -41,9 +41,20 @@ def build(force=False):
     return so
 
 
+def cpu_share():
+    """Threads to use: the process's CPU affinity, capped at 16 (the GPU box's share per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # no spinning if the box is oversubscribed
+        os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))
         L = C.CDLL(build())
         fp = C.POINTER(C.c_float)
         gp = C.POINTER(Geom)
@@ -71,6 +82,9 @@ def lib():
         L.orc_compute_flow.restype = C.c_int
         L.orc_compute_flow.argtypes = [fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(Params), C.c_int, fp, fp, fp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads(cpu_share())
         _LIB = L
     return _LIB
 
