@@ -93,6 +93,13 @@ def hip():
         "f3d_prof_enable": [C.c_int], "f3d_prof_reset": [],
         "f3d_prof_read": [C.c_int, _sz, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
         "f3d_abs_max": [_dp, _sz, _sz, _sz, _slabp, _fp],
+        "f3d_comm_unique_id": [C.c_void_p], "f3d_comm_init": [C.c_void_p, C.c_int, C.c_int], "f3d_comm_destroy": [],
+        "f3d_comm_rank": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "f3d_pack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
+        "f3d_unpack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
+        "f3d_copy_planes": [_dp, C.c_int, _dp, C.c_int, C.c_int, _sz, _sz],
+        "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
+        "f3d_comm_allreduce_max_f32": [_fp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -126,6 +133,16 @@ def host():
         "f3d_raw_write_u8": [C.c_char_p, _fp, _sz, _sz, _sz], "f3d_raw_write_f32": [C.c_char_p, _fp, _sz, _sz, _sz],
         "f3d_vtk_write_flow": [C.c_char_p, _fp, _fp, _fp, _sz, _sz, _sz],
         "f3d_synth_pair": [_sz, _sz, _sz, _fp, _fp],
+        "f3d_slabflow_create": [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int],
+        "f3d_slabflow_initialize": [C.c_void_p, _sz, _sz, _sz],
+        "f3d_slabflow_compute": [C.c_void_p, _fp, _fp, pp, _fp, _fp, _fp],
+        "f3d_slabflow_upload": [C.c_void_p, _fp, _fp],
+        "f3d_slabflow_compute_resident": [C.c_void_p, pp, _fp],
+        "f3d_slabflow_download": [C.c_void_p, _fp, _fp, _fp],
+        "f3d_slabflow_destroy": [C.c_void_p],
+        "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
+        "f3d_plan_resample_source": [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2,
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -389,4 +406,92 @@ class OpticalFlow:
     def destroy(self):
         if self._h:
             host().f3d_flow_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+# ---- multi-GPU z-slab driver (OpticalFlowSlab) -----------------------------------------------------------------------
+
+def plan_owned(depth, rank, n_ranks):
+    lo, hi = C.c_int(), C.c_int()
+    check(host().f3d_plan_owned(depth, rank, n_ranks, C.byref(lo), C.byref(hi)), "f3d_plan_owned")
+    return lo.value, hi.value
+
+
+def plan_exchange(depth, rank, n_ranks, need_lo, need_hi):
+    """[(peer, (send_lo, send_hi), (recv_lo, recv_hi)), ...] in global planes."""
+    cap = max(1, n_ranks)
+    arr = [(C.c_int * cap)() for _ in range(5)]
+    n = host().f3d_plan_exchange(depth, rank, n_ranks, need_lo, need_hi, *arr, cap)
+    if n < 0:
+        raise F3dError("f3d_plan_exchange failed")
+    return [(arr[0][i], (arr[1][i], arr[2][i]), (arr[3][i], arr[4][i])) for i in range(n)]
+
+
+def plan_resample_source(in_depth, out_depth, out_lo, out_hi):
+    lo, hi = C.c_int(), C.c_int()
+    check(host().f3d_plan_resample_source(in_depth, out_depth, out_lo, out_hi, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(hip().f3d_comm_unique_id(buf), "f3d_comm_unique_id")
+    return buf.raw
+
+
+def comm_init(unique_id, rank, n_ranks, device=-1):
+    check(hip().f3d_init(device), "f3d_init")
+    buf = C.create_string_buffer(bytes(unique_id), 128)
+    check(hip().f3d_comm_init(buf, rank, n_ranks), "f3d_comm_init")
+
+
+def comm_destroy():
+    hip().f3d_comm_destroy()
+
+
+class SlabOpticalFlow:
+    """OpticalFlowSlab: the same solve on n_ranks z-slabs.  local_ranks = [rank] with RCCL (call comm_init first), or
+    list(range(n_ranks)) for the one-GPU rehearsal."""
+
+    def __init__(self, n_ranks, local_ranks, halo_capacity=16):
+        self._h = C.c_void_p()
+        lr = (C.c_int * len(local_ranks))(*local_ranks)
+        check(host().f3d_slabflow_create(C.byref(self._h), n_ranks, lr, len(local_ranks), halo_capacity), "f3d_slabflow_create")
+        self.dims = None
+
+    def initialize(self, width, height, depth):
+        if host().f3d_slabflow_initialize(self._h, width, height, depth) != 0:
+            raise F3dError("OpticalFlowSlab::Initialize failed: " + (hip().f3d_last_error() or b"").decode())
+        self.dims = (width, height, depth)
+
+    def compute(self, frame_0, frame_1, **kw):
+        f0, p0 = _f32(frame_0)
+        f1, p1 = _f32(frame_1)
+        w, h, d = self.dims
+        u, v, ww = (np.zeros((d, h, w), np.float32) for _ in range(3))
+        prm = make_params(**kw)
+        check(host().f3d_slabflow_compute(self._h, p0, p1, C.byref(prm), u.ctypes.data_as(_fp), v.ctypes.data_as(_fp),
+                                          ww.ctypes.data_as(_fp)), "f3d_slabflow_compute")
+        return u, v, ww
+
+    def upload(self, frame_0, frame_1):
+        f0, p0 = _f32(frame_0)
+        f1, p1 = _f32(frame_1)
+        check(host().f3d_slabflow_upload(self._h, p0, p1), "f3d_slabflow_upload")
+
+    def compute_resident(self, **kw):
+        prm = make_params(**kw)
+        secs = C.c_float()
+        check(host().f3d_slabflow_compute_resident(self._h, C.byref(prm), C.byref(secs)), "f3d_slabflow_compute_resident")
+        return secs.value
+
+    def download(self):
+        w, h, d = self.dims
+        u, v, ww = (np.zeros((d, h, w), np.float32) for _ in range(3))
+        check(host().f3d_slabflow_download(self._h, u.ctypes.data_as(_fp), v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)))
+        return u, v, ww
+
+    def destroy(self):
+        if self._h:
+            host().f3d_slabflow_destroy(self._h)
             self._h = C.c_void_p()

@@ -7,11 +7,17 @@
 #include "hip_utils.h"
 #include "operations.h"
 #include "optical_flow.h"
+#include "optical_flow_slab.h"
 #include "synth.h"
 
 struct f3d_flow_s {
   OpticalFlowE driver;
   bool device_ready = false;
+};
+
+struct f3d_slabflow_s {
+  OpticalFlowSlab* driver = nullptr;
+  ~f3d_slabflow_s() { delete driver; }
 };
 
 struct f3d_op_s {
@@ -254,6 +260,115 @@ int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, fl
 {
   if (!frame_0 || !frame_1 || width == 0 || height == 0 || depth == 0) return 1;
   f3d_synth::TranslatedGaussianPair(width, height, depth, frame_0, frame_1);
+  return 0;
+}
+
+int f3d_slabflow_create(f3d_slabflow* flow, int n_ranks, const int* local_ranks, int n_local, int halo_capacity)
+{
+  if (!flow || !local_ranks || n_local < 1 || n_ranks < 1) return 1;
+  *flow = new (std::nothrow) f3d_slabflow_s;
+  if (!*flow) return 1;
+  (*flow)->driver = new OpticalFlowSlab(n_ranks, std::vector<int>(local_ranks, local_ranks + n_local),
+                                        halo_capacity > 0 ? halo_capacity : 16);
+  return 0;
+}
+
+int f3d_slabflow_initialize(f3d_slabflow flow, size_t width, size_t height, size_t depth)
+{
+  if (!flow) return 1;
+  if (f3d_init(-1) != 0) {
+    std::fprintf(stderr, "f3d_slabflow_initialize: %s\n", f3d_last_error());
+    return 1;
+  }
+  DataSize4 size = {width, height, depth, 0};
+  return flow->driver->Initialize(size) ? 0 : 1;
+}
+
+namespace {
+struct FullVolumes {
+  Data3D f0, f1;
+  FullVolumes(const float* a, const float* b, size_t w, size_t h, size_t d)
+      : f0(const_cast<float*>(a), w, h, d), f1(const_cast<float*>(b), w, h, d) {}
+};
+}  // namespace
+
+int f3d_slabflow_upload(f3d_slabflow flow, const float* frame_0, const float* frame_1)
+{
+  if (!flow || !frame_0 || !frame_1) return 1;
+  const DataSize4 s = flow->driver->FullSize();
+  FullVolumes v(frame_0, frame_1, s.width, s.height, s.depth);
+  flow->driver->UploadFrames(v.f0, v.f1);
+  return flow->driver->failed() ? 1 : 0;
+}
+
+int f3d_slabflow_compute_resident(f3d_slabflow flow, const f3d_flow_params* params, float* device_seconds)
+{
+  if (!flow || !params) return 1;
+  f3d_flow_params p = *params;
+  OperationParameters bag;
+  FillBag(bag, p);
+  const bool ok = flow->driver->ComputeResident(bag);
+  if (device_seconds) *device_seconds = flow->driver->LastDeviceSeconds();
+  return ok ? 0 : 1;
+}
+
+int f3d_slabflow_download(f3d_slabflow flow, float* u, float* v, float* w)
+{
+  if (!flow || !u || !v || !w) return 1;
+  const DataSize4 s = flow->driver->FullSize();
+  Data3D fu(u, s.width, s.height, s.depth), fv(v, s.width, s.height, s.depth), fw(w, s.width, s.height, s.depth);
+  flow->driver->DownloadFlow(fu, fv, fw);
+  return flow->driver->failed() ? 1 : 0;
+}
+
+int f3d_slabflow_compute(f3d_slabflow flow, const float* frame_0, const float* frame_1, const f3d_flow_params* params,
+                         float* u, float* v, float* w)
+{
+  if (f3d_slabflow_upload(flow, frame_0, frame_1) != 0) return 1;
+  if (f3d_slabflow_compute_resident(flow, params, nullptr) != 0) return 1;
+  return f3d_slabflow_download(flow, u, v, w);
+}
+
+int f3d_slabflow_destroy(f3d_slabflow flow)
+{
+  delete flow;
+  return 0;
+}
+
+int f3d_plan_owned(int depth, int rank, int n_ranks, int* lo, int* hi)
+{
+  if (!lo || !hi || n_ranks < 1 || rank < 0 || rank >= n_ranks || depth < 0) return 1;
+  const PlaneRange r = OwnedPlanes(depth, rank, n_ranks);
+  *lo = r.lo;
+  *hi = r.hi;
+  return 0;
+}
+
+int f3d_plan_exchange(int depth, int rank, int n_ranks, int need_lo, int need_hi, int* peer, int* send_lo, int* send_hi,
+                      int* recv_lo, int* recv_hi, int capacity)
+{
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return -1;
+  const std::vector<HaloTransfer> plan = PlanHaloExchange(depth, rank, n_ranks, need_lo, need_hi);
+  if (static_cast<int>(plan.size()) > capacity) return -1;
+  for (size_t i = 0; i < plan.size(); ++i) {
+    peer[i] = plan[i].peer;
+    send_lo[i] = plan[i].send.lo;
+    send_hi[i] = plan[i].send.hi;
+    recv_lo[i] = plan[i].recv.lo;
+    recv_hi[i] = plan[i].recv.hi;
+  }
+  return static_cast<int>(plan.size());
+}
+
+int f3d_plan_resample_source(int in_depth, int out_depth, int out_lo, int out_hi, int* lo, int* hi)
+{
+  if (!lo || !hi || in_depth < 1 || out_depth < 1) return 1;
+  PlaneRange out;
+  out.lo = out_lo;
+  out.hi = out_hi;
+  const PlaneRange r = ResampleSourcePlanes(in_depth, out_depth, out);
+  *lo = r.lo;
+  *hi = r.hi;
   return 0;
 }
 

@@ -1,0 +1,415 @@
+#include "optical_flow_slab.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <utility>
+
+#include "common_utils.h"
+#include "hip_utils.h"
+
+OpticalFlowSlab::OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int halo_capacity)
+    : OpticalFlowBase("Optical Flow z-slab Multi GPU"), n_ranks_(n_ranks), local_ranks_(std::move(local_ranks)), halo_(halo_capacity)
+{
+}
+
+OpticalFlowSlab::~OpticalFlowSlab() { Destroy(); }
+
+bool OpticalFlowSlab::Check(int status)
+{
+  if (CheckDeviceError(status)) failed_ = true;
+  return status == 0;
+}
+
+bool OpticalFlowSlab::Initialize(const DataSize4& data_size)
+{
+  if (n_ranks_ < 1 || local_ranks_.empty()) return false;
+  for (int r : local_ranks_)
+    if (r < 0 || r >= n_ranks_) return false;
+  if (local_ranks_.size() != 1 && static_cast<int>(local_ranks_.size()) != n_ranks_) {
+    std::printf("'%s': a process computes either one rank (RCCL) or all of them (one-GPU rehearsal).\n", GetName());
+    return false;
+  }
+  full_size_ = data_size;
+  full_size_.pitch = 0;
+  const size_t max_planes = (data_size.depth + n_ranks_ - 1) / n_ranks_ + 1;
+  local_container_ = {data_size.width, data_size.height, max_planes + 2 * static_cast<size_t>(halo_), 0};
+
+  const size_t rows = local_container_.height * local_container_.depth;
+  for (int r : local_ranks_) {
+    Local l;
+    l.rank = r;
+    for (int i = 0; i < kRoles; ++i) {
+      size_t pitch = 0;
+      if (!Check(f3d_alloc_pitched(&l.buf[i], &pitch, data_size.width * sizeof(float), rows))) return false;
+      if (local_container_.pitch && pitch != local_container_.pitch) return false;
+      local_container_.pitch = pitch;
+    }
+    locals_.push_back(l);
+  }
+  // staging for the RCCL path: both halos of the deepest exchange (5 fields, halo_ planes each side)
+  stage_floats_ = static_cast<size_t>(2 * halo_) * 5 * data_size.width * data_size.height;
+  if (local_ranks_.size() == 1 && n_ranks_ > 1) {
+    size_t p = 0;
+    if (!Check(f3d_alloc_pitched(&stage_send_, &p, stage_floats_ * sizeof(float), 1))) return false;
+    if (!Check(f3d_alloc_pitched(&stage_recv_, &p, stage_floats_ * sizeof(float), 1))) return false;
+  }
+  f3d_size4 c = {local_container_.width, local_container_.height, local_container_.depth, local_container_.pitch};
+  if (!Check(f3d_set_container(&c))) return false;
+  initialized_ = true;
+  return true;
+}
+
+void OpticalFlowSlab::Destroy()
+{
+  for (Local& l : locals_)
+    for (DevicePtr& p : l.buf) {
+      if (p) f3d_free(p);
+      p = 0;
+    }
+  locals_.clear();
+  if (stage_send_) f3d_free(stage_send_);
+  if (stage_recv_) f3d_free(stage_recv_);
+  stage_send_ = stage_recv_ = 0;
+  initialized_ = false;
+}
+
+f3d_slab OpticalFlowSlab::Window(int depth, int rank, int grow_lo, int grow_hi) const
+{
+  const PlaneRange own = OwnedPlanes(depth, rank, n_ranks_);
+  f3d_slab s;
+  s.z_base = own.lo - halo_;
+  if (own.empty()) {
+    s.z_lo = s.z_hi = std::max(0, own.lo);
+    if (s.z_lo < s.z_base) s.z_base = s.z_lo;
+    return s;
+  }
+  s.z_lo = std::max(0, own.lo - grow_lo);
+  s.z_hi = std::min(depth, own.hi + grow_hi);
+  return s;
+}
+
+bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std::vector<Role>& roles, int need_lo, int need_hi)
+{
+  if (n_ranks_ == 1 || (need_lo <= 0 && need_hi <= 0)) return true;
+  if (need_lo > halo_ || need_hi > halo_) {
+    std::printf("'%s': a halo of %d/%d planes exceeds the capacity of %d; raise halo_capacity.\n", GetName(), need_lo, need_hi, halo_);
+    failed_ = true;
+    return false;
+  }
+  const size_t plane = width * height;
+  if (locals_.size() > 1) {  // every rank lives here: copy planes between their containers
+    for (Local& me : locals_) {
+      const int my_base = ZBase(depth, me.rank);
+      for (const HaloTransfer& t : PlanHaloExchange(depth, me.rank, n_ranks_, need_lo, need_hi)) {
+        if (t.recv.empty()) continue;
+        const Local& peer = locals_[t.peer];
+        const int peer_base = ZBase(depth, peer.rank);
+        for (Role role : roles)
+          if (!Check(f3d_copy_planes(me.buf[role], t.recv.lo - my_base, peer.buf[role], t.recv.lo - peer_base, t.recv.size(),
+                                     width, height)))
+            return false;
+      }
+    }
+    return true;
+  }
+  // one rank per process: pack -> grouped send/recv -> unpack
+  Local& me = locals_[0];
+  const int my_base = ZBase(depth, me.rank);
+  const std::vector<HaloTransfer> plan = PlanHaloExchange(depth, me.rank, n_ranks_, need_lo, need_hi);
+  std::vector<size_t> s_off, s_cnt, r_off, r_cnt;
+  std::vector<int> peers;
+  size_t s_pos = 0, r_pos = 0;
+  for (const HaloTransfer& t : plan) {
+    peers.push_back(t.peer);
+    s_off.push_back(s_pos);
+    r_off.push_back(r_pos);
+    const size_t sc = static_cast<size_t>(t.send.size()) * plane * roles.size();
+    const size_t rc = static_cast<size_t>(t.recv.size()) * plane * roles.size();
+    s_cnt.push_back(sc);
+    r_cnt.push_back(rc);
+    size_t at = s_pos;
+    for (Role role : roles) {
+      if (!Check(f3d_pack_planes(me.buf[role], t.send.lo - my_base, t.send.size(), width, height, stage_send_, at))) return false;
+      at += static_cast<size_t>(t.send.size()) * plane;
+    }
+    s_pos += sc;
+    r_pos += rc;
+  }
+  if (s_pos > stage_floats_ || r_pos > stage_floats_) {
+    std::printf("'%s': staging buffer too small for this exchange.\n", GetName());
+    failed_ = true;
+    return false;
+  }
+  if (peers.empty()) return true;
+  if (!Check(f3d_comm_sendrecv(stage_send_, s_off.data(), s_cnt.data(), stage_recv_, r_off.data(), r_cnt.data(), peers.data(),
+                               static_cast<int>(peers.size()))))
+    return false;
+  for (size_t i = 0; i < plan.size(); ++i) {
+    size_t at = r_off[i];
+    for (Role role : roles) {
+      if (!Check(f3d_unpack_planes(me.buf[role], plan[i].recv.lo - my_base, plan[i].recv.size(), width, height, stage_recv_, at)))
+        return false;
+      at += static_cast<size_t>(plan[i].recv.size()) * plane;
+    }
+  }
+  return true;
+}
+
+void OpticalFlowSlab::UploadFrames(Data3D& frame_0, Data3D& frame_1)
+{
+  if (!IsInitialized()) return;
+  const int D = static_cast<int>(full_size_.depth);
+  const size_t plane = full_size_.width * full_size_.height;
+  for (Local& l : locals_) {
+    // raw planes [own.lo - halo, own.hi + halo) of the volume: enough for the blur's z taps
+    const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+    if (own.empty()) continue;
+    const int lo = std::max(0, own.lo - halo_), hi = std::min(D, own.hi + halo_);
+    const int base = ZBase(D, l.rank);
+    Check(f3d_copy3d_h2d(l.buf[RAW0], local_container_.pitch, local_container_.height, lo - base,
+                         frame_0.DataPtr() + static_cast<size_t>(lo) * plane, full_size_.width, full_size_.height, hi - lo));
+    Check(f3d_copy3d_h2d(l.buf[RAW1], local_container_.pitch, local_container_.height, lo - base,
+                         frame_1.DataPtr() + static_cast<size_t>(lo) * plane, full_size_.width, full_size_.height, hi - lo));
+  }
+}
+
+void OpticalFlowSlab::DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w)
+{
+  const int D = static_cast<int>(full_size_.depth);
+  const size_t plane = full_size_.width * full_size_.height;
+  Data3D* out[3] = {&flow_u, &flow_v, &flow_w};
+  const Role roles[3] = {FU, FV, FW};
+  for (Local& l : locals_) {
+    const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+    if (own.empty()) continue;
+    for (int i = 0; i < 3; ++i)
+      Check(f3d_copy3d_d2h(out[i]->DataPtr() + static_cast<size_t>(own.lo) * plane, full_size_.width, full_size_.height,
+                           own.size(), l.buf[roles[i]], local_container_.pitch, local_container_.height, halo_));
+  }
+}
+
+void OpticalFlowSlab::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
+                                  OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  UploadFrames(frame_0, frame_1);
+  if (ComputeResident(params)) DownloadFlow(flow_u, flow_v, flow_w);
+}
+
+bool OpticalFlowSlab::ComputeResident(OperationParameters& params)
+{
+  if (!IsInitialized()) return false;
+  failed_ = false;
+  f3d_event ev_start = nullptr, ev_stop = nullptr;
+  Check(f3d_event_create(&ev_start));
+  Check(f3d_event_create(&ev_stop));
+  Check(f3d_event_record(ev_start));
+  const bool ok = Pyramid(params) && !failed_;
+  float ms = 0.f;
+  Check(f3d_event_record(ev_stop));
+  Check(f3d_event_sync(ev_stop));
+  Check(f3d_event_elapsed_ms(&ms, ev_start, ev_stop));
+  last_device_seconds_ = ms / 1000.f;
+  f3d_event_destroy(ev_start);
+  f3d_event_destroy(ev_stop);
+  return ok;
+}
+
+bool OpticalFlowSlab::Pyramid(OperationParameters& params)
+{
+  size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
+  float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, warp_scale_factor, "warp_scale_factor", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, outer_iterations_count, "outer_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, inner_iterations_count, "inner_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_alpha, "equation_alpha", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_smoothness, "equation_smoothness", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_data, "equation_data", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, median_radius, "median_radius", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, gaussian_sigma, "gaussian_sigma", false);
+
+  const size_t W0 = full_size_.width, H0 = full_size_.height;
+  const int D0 = static_cast<int>(full_size_.depth);
+  const int K = static_cast<int>(inner_iterations_count);
+  const size_t crows = local_container_.height * local_container_.depth;
+  const size_t cpitch = local_container_.pitch;
+
+  f3d_size4 c = {local_container_.width, local_container_.height, local_container_.depth, local_container_.pitch};
+  if (!Check(f3d_set_container(&c))) return false;
+
+  // ---- pre-blur on the original planes: rows and columns on the slab widened by the tap radius, slices on the slab
+  if (gaussian_sigma > 0.0) {
+    taps_.ComputeGaussianKernel(gaussian_sigma, 3, 1.0);
+    const size_t R = taps_.KernelRadius();
+    if (static_cast<int>(R) > halo_) {
+      std::printf("'%s': Gaussian radius %zu exceeds the halo capacity %d.\n", GetName(), R, halo_);
+      return false;
+    }
+    if (!Check(f3d_set_conv_taps(taps_.Kernel(), 2 * R + 1))) return false;
+    for (Local& l : locals_) {
+      const f3d_slab wide = Window(D0, l.rank, static_cast<int>(R), static_cast<int>(R));
+      const f3d_slab own = Window(D0, l.rank, 0, 0);
+      const Role src[2] = {RAW0, RAW1}, dst[2] = {F0, F1};
+      for (int i = 0; i < 2; ++i) {
+        if (!Check(f3d_conv_rows(l.buf[dst[i]], l.buf[src[i]], W0, H0, D0, R, &wide))) return false;
+        if (!Check(f3d_conv_cols(l.buf[TMP], l.buf[dst[i]], W0, H0, D0, R, &wide))) return false;
+        if (!Check(f3d_conv_slices(l.buf[dst[i]], l.buf[TMP], W0, H0, D0, R, &own))) return false;
+      }
+    }
+  } else {
+    const size_t bytes = cpitch * crows;
+    for (Local& l : locals_) {
+      if (!Check(f3d_copy_d2d(l.buf[F0], l.buf[RAW0], bytes))) return false;
+      if (!Check(f3d_copy_d2d(l.buf[F1], l.buf[RAW1], bytes))) return false;
+    }
+  }
+
+  DataSize4 original = {W0, H0, static_cast<size_t>(D0), 0};
+  const size_t max_warp_level = GetMaxWarpLevel(W0, H0, D0, warp_scale_factor);
+  int level = static_cast<int>(std::min(warp_levels_count, max_warp_level)) - 1;
+  DataSize4 prev = {0, 0, 0, 0};
+
+  if (level < 0)
+    for (Local& l : locals_)
+      for (Role r : {FU, FV, FW})
+        if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, cpitch, crows))) return false;
+
+  // Two-pass (x, y) resample on the source slab, halo exchange of the intermediate, z pass onto the destination slab.
+  // `items` pairs (source role, intermediate role, destination role); all share the source/destination geometry.
+  struct Item { Role src, mid, dst; };
+  auto resample = [&](const std::vector<Item>& items, const DataSize4& from, const DataSize4& to) -> bool {
+    const int Din = static_cast<int>(from.depth), Dout = static_cast<int>(to.depth);
+    int need_lo = 0, need_hi = 0;
+    for (int r = 0; r < n_ranks_; ++r) {  // every rank must ask for the same depths: take the maximum
+      const PlaneRange out = OwnedPlanes(Dout, r, n_ranks_), in = OwnedPlanes(Din, r, n_ranks_);
+      if (out.empty()) continue;
+      const PlaneRange src = ResampleSourcePlanes(Din, Dout, out);
+      need_lo = std::max(need_lo, in.lo - src.lo);
+      need_hi = std::max(need_hi, src.hi - in.hi);
+    }
+    for (Local& l : locals_) {
+      const f3d_slab in_own = Window(Din, l.rank, 0, 0);
+      for (const Item& it : items) {
+        if (!Check(f3d_resample_x(l.buf[it.src], l.buf[it.dst], to.width, from.height, Din, from.width, &in_own))) return false;
+        if (!Check(f3d_resample_y(l.buf[it.dst], l.buf[it.mid], to.width, to.height, Din, from.height, &in_own))) return false;
+      }
+    }
+    std::vector<Role> mids;
+    for (const Item& it : items) mids.push_back(it.mid);
+    if (!Exchange(Din, to.width, to.height, mids, need_lo, need_hi)) return false;
+    for (Local& l : locals_) {
+      const f3d_slab in_win = Window(Din, l.rank, need_lo, need_hi);
+      const f3d_slab out_own = Window(Dout, l.rank, 0, 0);
+      for (const Item& it : items)
+        if (!Check(f3d_resample_z(l.buf[it.mid], l.buf[it.dst], to.width, to.height, Dout, Din, &in_win, &out_own))) return false;
+    }
+    return true;
+  };
+
+  while (level >= 0) {
+    const PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
+    const DataSize4 cur = lv.size;
+    const size_t W = cur.width, H = cur.height;
+    const int D = static_cast<int>(cur.depth);
+    const float hx = lv.hx, hy = lv.hy, hz = lv.hz;
+    if (!silent) std::printf("Solve level %2d (%4zu x%4zu x%4d) on %d slabs\n", level, W, H, D, n_ranks_);
+
+    // frames of this level
+    if (level == 0) {
+      for (Local& l : locals_) {
+        std::swap(l.buf[F0], l.buf[F0R]);
+        std::swap(l.buf[F1], l.buf[F1R]);
+      }
+    } else {
+      if (!resample({{F0, PHI, F0R}, {F1, KSI, F1R}}, original, cur)) return false;
+    }
+    // flow of the previous level (values stay in original-voxel units)
+    if (prev.width == 0) {
+      for (Local& l : locals_)
+        for (Role r : {FU, FV, FW})
+          if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, cpitch, crows))) return false;
+    } else {
+      if (!resample({{FU, TDU, DU}, {FV, TDV, DV}, {FW, TDW, DW}}, prev, cur)) return false;
+      for (Local& l : locals_) {
+        std::swap(l.buf[FU], l.buf[DU]);
+        std::swap(l.buf[FV], l.buf[DV]);
+        std::swap(l.buf[FW], l.buf[DW]);
+      }
+    }
+
+    // level-static halos: K+1 planes of u, v, w, f0 for the widened sweeps; f1 additionally by the warp's z reach
+    float max_w = 0.f;
+    for (Local& l : locals_) {
+      const f3d_slab own = Window(D, l.rank, 0, 0);
+      float m = 0.f;
+      if (!Check(f3d_abs_max(l.buf[FW], W, H, D, &own, &m))) return false;
+      max_w = std::max(max_w, m);
+    }
+    if (locals_.size() == 1 && n_ranks_ > 1 && !Check(f3d_comm_allreduce_max_f32(&max_w))) return false;
+    const int reach = static_cast<int>(std::ceil(max_w / hz)) + 1;
+    const int wide = K + 1;
+    if (!Exchange(D, W, H, {FU, FV, FW, F0R}, wide, wide)) return false;
+    if (!Exchange(D, W, H, {F1R}, wide + reach, wide + reach)) return false;
+
+    // warp on the widened slab
+    for (Local& l : locals_) {
+      const f3d_slab win = Window(D, l.rank, wide, wide);
+      if (!Check(f3d_warp(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], W, H, D, hx, hy, hz, l.buf[TMP], &win))) return false;
+      std::swap(l.buf[F1R], l.buf[TMP]);
+    }
+
+    // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per outer iteration
+    for (Local& l : locals_)
+      for (Role r : {DU, DV, DW})
+        if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, W * sizeof(float), crows))) return false;
+    for (size_t i = 0; i < outer_iterations_count; ++i) {
+      for (Local& l : locals_) {
+        const f3d_slab pw = Window(D, l.rank, K, K);
+        if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy,
+                               hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &pw)))
+          return false;
+        for (int j = 0; j < K; ++j) {
+          const f3d_slab sw = Window(D, l.rank, K - 1 - j, K - 1 - j);
+          if (!Check(f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
+                                     l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV], l.buf[TDW],
+                                     &sw)))
+            return false;
+          std::swap(l.buf[DU], l.buf[TDU]);
+          std::swap(l.buf[DV], l.buf[TDV]);
+          std::swap(l.buf[DW], l.buf[TDW]);
+        }
+      }
+      if (i + 1 < outer_iterations_count && !Exchange(D, W, H, {DU, DV, DW}, wide, wide)) return false;
+    }
+
+    // flow += increment on the slab, then the median with its own halo
+    for (Local& l : locals_) {
+      const f3d_slab own = Window(D, l.rank, 0, 0);
+      if (!Check(f3d_add(l.buf[FU], l.buf[DU], W, H, D, &own))) return false;
+      if (!Check(f3d_add(l.buf[FV], l.buf[DV], W, H, D, &own))) return false;
+      if (!Check(f3d_add(l.buf[FW], l.buf[DW], W, H, D, &own))) return false;
+    }
+    size_t radius = median_radius;
+    if (radius != 1 && radius % 2 == 0) radius -= 1;
+    if (radius != 1) {
+      if (radius < 3 || radius > 7) {
+        std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", radius);
+        return false;
+      }
+      const int half = static_cast<int>(radius) / 2;
+      if (!Exchange(D, W, H, {FU, FV, FW}, half, half)) return false;
+      for (Local& l : locals_) {
+        const f3d_slab own = Window(D, l.rank, 0, 0);
+        for (Role r : {FU, FV, FW}) {
+          if (!Check(f3d_median(l.buf[r], W, H, D, radius, l.buf[TMP], &own))) return false;
+          std::swap(l.buf[r], l.buf[TMP]);
+        }
+      }
+    }
+    prev = cur;
+    --level;
+  }
+  return !failed_;
+}

@@ -1,0 +1,74 @@
+// Multi-GPU driver: the volume is cut into z-slabs, one per rank, and every rank runs the same coarse-to-fine loop on
+// its slab with halo planes exchanged between neighbours.  New design (the reference is single-GPU);
+// it reuses the reference-shaped pieces (level schedule, Gaussian taps, parameter keys) and the same kernels, so the
+// result is bit-identical to OpticalFlowE on one GPU.
+//
+//   * Partition: rank r owns planes [floor(r D_l / P), floor((r+1) D_l / P)) of every level l.
+//   * Halos are communication-avoiding: increments du, dv, dw are exchanged once per OUTER iteration, K + 1 planes
+//     deep (K = inner sweeps); sweep j then runs on the slab widened by K-1-j planes, phi/ksi on the slab widened
+//     by K.  The sweep is a Jacobi update, so the redundant planes reproduce the neighbour's values exactly.
+//   * Per level: level-size halos of the two-pass-resampled frames and flows (z pass sources), K+1 planes of
+//     u, v, w, f0; K+1+reach planes of f1 for the warp (reach = ceil(max|w| / hz) + 1, one all-reduce(max));
+//     2 planes of u, v, w for the 5^3 median.
+//   * Transport: RCCL send/recv between processes (one rank per GPU), or plane copies between the virtual ranks of
+//     one process (a one-GPU rehearsal that exercises exactly the same plan).
+#ifndef F3D_HOST_OPTICAL_FLOW_SLAB_H_
+#define F3D_HOST_OPTICAL_FLOW_SLAB_H_
+
+#include <vector>
+
+#include "optical_flow.h"
+#include "slab_plan.h"
+
+class OpticalFlowSlab : public OpticalFlowBase {
+ public:
+  // n_ranks slabs in total; local_ranks are the ones this process computes: {rank} with RCCL, {0..n-1} for the
+  // one-GPU rehearsal.  halo_capacity = planes kept free below and above the slab in every local container.
+  OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int halo_capacity = 16);
+  ~OpticalFlowSlab() override;
+
+  bool Initialize(const DataSize4& data_size) override;
+  // frame_0 / frame_1 are the FULL host volumes; each local rank uploads its planes.  flow_* are full-size too and
+  // receive the planes of the local ranks only.
+  void ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
+                   OperationParameters& params) override;
+  void Destroy() override;
+
+  // device-resident variant for benchmarks
+  void UploadFrames(Data3D& frame_0, Data3D& frame_1);
+  bool ComputeResident(OperationParameters& params);
+  void DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w);
+  float LastDeviceSeconds() const { return last_device_seconds_; }
+  bool failed() const { return failed_; }
+  DataSize4 FullSize() const { return full_size_; }
+
+  bool silent = true;
+
+ private:
+  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, kRoles };
+  struct Local {
+    int rank;
+    DevicePtr buf[kRoles];
+  };
+
+  bool Pyramid(OperationParameters& params);
+  int ZBase(int depth, int rank) const { return OwnedPlanes(depth, rank, n_ranks_).lo - halo_; }
+  f3d_slab Window(int depth, int rank, int grow_lo, int grow_hi) const;
+  // make `need` planes below/above every slab valid for the given roles (level of `depth`, sub-box width x height)
+  bool Exchange(int depth, size_t width, size_t height, const std::vector<Role>& roles, int need_lo, int need_hi);
+  bool Check(int status);
+
+  int n_ranks_;
+  std::vector<int> local_ranks_;
+  int halo_;
+  DataSize4 full_size_ = {0, 0, 0, 0};
+  DataSize4 local_container_ = {0, 0, 0, 0};
+  std::vector<Local> locals_;
+  DevicePtr stage_send_ = 0, stage_recv_ = 0;
+  size_t stage_floats_ = 0;
+  bool failed_ = false;
+  float last_device_seconds_ = 0.f;
+  CudaOperationConvolution3D taps_;  // only for ComputeGaussianKernel (host arithmetic)
+};
+
+#endif

@@ -149,18 +149,28 @@ int f3d_prof_reset(void);
 /* drains the pending events; min_voxels filters launches by level size (0 = all) */
 int f3d_prof_read(int kernel, size_t min_voxels, double* total_ms, uint64_t* launches, double* total_voxels);
 
-/* ---- multi-GPU: z-slab halo exchange on RCCL (no reference counterpart) ---------------- */
+/* ---- multi-GPU: z-slab halo exchange on RCCL over xGMI (no reference counterpart) --------- */
 
-/* 128-byte ncclUniqueId, created on rank 0 and handed to the other ranks by the launcher */
+/* 128-byte ncclUniqueId, created on rank 0 and handed to the other ranks by the launcher (bench.py sends it
+ * through torch.distributed).  librccl is loaded on the first of these calls, never for single-GPU use. */
 int f3d_comm_unique_id(void* id128);
 int f3d_comm_init(const void* id128, int rank, int n_ranks);
 int f3d_comm_destroy(void);
 int f3d_comm_rank(int* rank, int* n_ranks);
-/* Send whole planes of `field` to / receive from peers: entry i moves n_planes[i] container planes
- * starting at container plane send_plane0[i] / recv_plane0[i] (negative count = skip) with peer[i]. */
-int f3d_comm_exchange_planes(const f3d_devptr* fields, int n_fields, size_t plane_rows, size_t row_bytes,
-                             const int* peer, const int* send_plane0, const int* send_count,
-                             const int* recv_plane0, const int* recv_count, int n_peers);
+/* Gather `count` container planes (sub-box width x height of each) of `field`, starting at container plane
+ * plane0, into the dense staging buffer at staging[offset_floats ...]; unpack is the inverse. */
+int f3d_pack_planes(f3d_devptr field, int plane0, int count, size_t width, size_t height, f3d_devptr staging,
+                    size_t offset_floats);
+int f3d_unpack_planes(f3d_devptr field, int plane0, int count, size_t width, size_t height, f3d_devptr staging,
+                      size_t offset_floats);
+/* same-device plane copy between two containers (one-GPU rehearsal of the slab decomposition) */
+int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width,
+                    size_t height);
+/* One grouped exchange on the library stream: for every i, send send_count[i] floats from send_buf + send_offset[i]
+ * to peers[i] and receive recv_count[i] floats into recv_buf + recv_offset[i] from peers[i] (zero counts skipped). */
+int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
+                      const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers);
+/* max over all ranks of *value (host in/out) */
 int f3d_comm_allreduce_max_f32(float* value);
 /* max |field| over the slab's planes, on the device (feeds the warp halo depth) */
 int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result);

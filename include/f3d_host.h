@@ -75,6 +75,29 @@ int f3d_vtk_write_flow(const char* path, const float* u, const float* v, const f
 /* translated-Gaussian pair: 64 blobs, splitmix64 seed 20241003, frame_1(p) = frame_0(p - t), t = (2, -1, 0.5) */
 int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, float* frame_1);
 
+/* ---- multi-GPU z-slab driver (OpticalFlowSlab; no reference counterpart) ------------------------ */
+
+typedef struct f3d_slabflow_s* f3d_slabflow;
+
+/* n_ranks slabs in total; this process computes local_ranks[0..n_local): one rank (RCCL between processes, after
+ * f3d_comm_init) or all n_ranks (one-GPU rehearsal with plane copies instead of RCCL). */
+int f3d_slabflow_create(f3d_slabflow* flow, int n_ranks, const int* local_ranks, int n_local, int halo_capacity);
+int f3d_slabflow_initialize(f3d_slabflow flow, size_t width, size_t height, size_t depth);
+/* frames and flows are FULL volumes; only the planes of the local ranks are read / written */
+int f3d_slabflow_compute(f3d_slabflow flow, const float* frame_0, const float* frame_1, const f3d_flow_params* params,
+                         float* u, float* v, float* w);
+int f3d_slabflow_upload(f3d_slabflow flow, const float* frame_0, const float* frame_1);
+int f3d_slabflow_compute_resident(f3d_slabflow flow, const f3d_flow_params* params, float* device_seconds);
+int f3d_slabflow_download(f3d_slabflow flow, float* u, float* v, float* w);
+int f3d_slabflow_destroy(f3d_slabflow flow);
+
+/* the decomposition plan (pure host arithmetic, usable without a device) */
+int f3d_plan_owned(int depth, int rank, int n_ranks, int* lo, int* hi);
+/* fills up to `capacity` transfers; returns their number, or -1 if capacity is too small */
+int f3d_plan_exchange(int depth, int rank, int n_ranks, int need_lo, int need_hi, int* peer, int* send_lo, int* send_hi,
+                      int* recv_lo, int* recv_hi, int capacity);
+int f3d_plan_resample_source(int in_depth, int out_depth, int out_lo, int out_hi, int* lo, int* hi);
+
 #ifdef __cplusplus
 }
 #endif
