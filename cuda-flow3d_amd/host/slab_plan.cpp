@@ -24,9 +24,8 @@ PlaneRange Intersect(PlaneRange a, PlaneRange b)
 // the planes below / above its slab a rank asks for
 void Wanted(int depth, PlaneRange own, int need_lo, int need_hi, PlaneRange* below, PlaneRange* above)
 {
-  *below = PlaneRange();
-  *above = PlaneRange();
-  if (own.empty()) return;
+  // a rank that owns nothing here still asks around its (empty) position: the z pass of a resample can need
+  // source planes for a destination slab that is not empty
   below->lo = std::max(0, own.lo - need_lo);
   below->hi = own.lo;
   above->lo = own.hi;

@@ -24,7 +24,7 @@ struct HaloTransfer {
 
 // Transfers that make planes [own.lo - need_lo, own.lo) and [own.hi, own.hi + need_hi) (clipped to the volume) valid
 // on every rank, assuming every rank asks for the same depths.  A halo deeper than a neighbour's slab reaches
-// further ranks; ranks that own nothing at this level neither send nor ask.
+// further ranks; a rank that owns nothing at this level sends nothing but still receives around its position.
 std::vector<HaloTransfer> PlanHaloExchange(int depth, int rank, int n_ranks, int need_lo, int need_hi);
 
 // Input planes the z pass of the area resample reads to produce output planes `out` (A.1: floor(z * delta) ..
