@@ -133,6 +133,7 @@ def host():
         "f3d_raw_write_u8": [C.c_char_p, _fp, _sz, _sz, _sz], "f3d_raw_write_f32": [C.c_char_p, _fp, _sz, _sz, _sz],
         "f3d_vtk_write_flow": [C.c_char_p, _fp, _fp, _fp, _sz, _sz, _sz],
         "f3d_synth_pair": [_sz, _sz, _sz, _fp, _fp],
+        "f3d_synth_planes": [_sz, _sz, _sz, _sz, _sz, _fp, _fp, _fp],
         "f3d_slabflow_create": [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int],
         "f3d_slabflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_slabflow_compute": [C.c_void_p, _fp, _fp, pp, _fp, _fp, _fp],
@@ -230,6 +231,14 @@ def synth_pair(width, height, depth):
     f1 = np.empty_like(f0)
     check(host().f3d_synth_pair(width, height, depth, f0.ctypes.data_as(_fp), f1.ctypes.data_as(_fp)))
     return f0, f1
+
+
+def synth_planes(width, height, depth, z_lo, z_hi, frame_0, frame_1):
+    """Render planes [z_lo, z_hi) of the synthetic pair, unscaled, into full-size arrays; returns max(frame_0 planes)."""
+    m = C.c_float()
+    check(host().f3d_synth_planes(width, height, depth, z_lo, z_hi, frame_0.ctypes.data_as(_fp), frame_1.ctypes.data_as(_fp),
+                                  C.byref(m)), "f3d_synth_planes")
+    return m.value
 
 
 # ---- device memory ---------------------------------------------------------------------------------------------

@@ -263,6 +263,14 @@ int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, fl
   return 0;
 }
 
+int f3d_synth_planes(size_t width, size_t height, size_t depth, size_t z_lo, size_t z_hi, float* frame_0, float* frame_1,
+                      float* frame_0_max)
+{
+  if (!frame_0 || !frame_1 || !frame_0_max || z_lo > z_hi || z_hi > depth) return 1;
+  *frame_0_max = f3d_synth::TranslatedGaussianPlanes(width, height, depth, z_lo, z_hi, frame_0, frame_1);
+  return 0;
+}
+
 int f3d_slabflow_create(f3d_slabflow* flow, int n_ranks, const int* local_ranks, int n_local, int halo_capacity)
 {
   if (!flow || !local_ranks || n_local < 1 || n_ranks < 1) return 1;

@@ -49,7 +49,8 @@ std::vector<double> AxisTable(const std::vector<Blob>& blobs, int axis, size_t n
 }
 
 // unscaled field; returns its maximum
-float Render(const std::vector<Blob>& blobs, size_t w, size_t h, size_t d, const double shift[3], float* out)
+float Render(const std::vector<Blob>& blobs, size_t w, size_t h, size_t d, const double shift[3], float* out, size_t z_lo,
+             size_t z_hi)
 {
   const std::vector<double> tx = AxisTable(blobs, 0, w, shift[0]);
   const std::vector<double> ty = AxisTable(blobs, 1, h, shift[1]);
@@ -57,7 +58,7 @@ float Render(const std::vector<Blob>& blobs, size_t w, size_t h, size_t d, const
   const size_t nb = blobs.size();
   float vmax = 0.f;
 #pragma omp parallel for schedule(static) reduction(max : vmax)
-  for (long long row = 0; row < static_cast<long long>(h * d); ++row) {
+  for (long long row = static_cast<long long>(z_lo * h); row < static_cast<long long>(z_hi * h); ++row) {
     const size_t y = static_cast<size_t>(row) % h, z = static_cast<size_t>(row) / h;
     std::vector<double> acc(w, 0.0);
     for (size_t k = 0; k < nb; ++k) {
@@ -76,11 +77,9 @@ float Render(const std::vector<Blob>& blobs, size_t w, size_t h, size_t d, const
 
 }  // namespace
 
-void TranslatedGaussianPair(size_t w, size_t h, size_t d, float* frame_0, float* frame_1)
+namespace {
+std::vector<Blob> MakeBlobs(size_t w, size_t h, size_t d)
 {
-#ifdef _OPENMP
-  if (omp_get_max_threads() > 16) omp_set_num_threads(16);  // stay within the per-GPU CPU share of a shared box
-#endif
   SplitMix64 rng{kSeed};
   const double dims[3] = {static_cast<double>(w), static_cast<double>(h), static_cast<double>(d)};
   const double m = (dims[0] + dims[1] + dims[2]) / 3.0;
@@ -90,9 +89,30 @@ void TranslatedGaussianPair(size_t w, size_t h, size_t d, float* frame_0, float*
     b.sigma = rng.Uniform(m / 32.0, m / 12.0);
     b.amp = rng.Uniform(0.3, 1.0);
   }
+  return blobs;
+}
+
+void LimitThreads()
+{
+#ifdef _OPENMP
+  if (omp_get_max_threads() > 16) omp_set_num_threads(16);  // stay within the per-GPU CPU share of a shared box
+#endif
+}
+}  // namespace
+
+float TranslatedGaussianPlanes(size_t w, size_t h, size_t d, size_t z_lo, size_t z_hi, float* frame_0, float* frame_1)
+{
+  LimitThreads();
+  const std::vector<Blob> blobs = MakeBlobs(w, h, d);
   const double none[3] = {0.0, 0.0, 0.0};
-  const float vmax = Render(blobs, w, h, d, none, frame_0);
-  Render(blobs, w, h, d, kShift, frame_1);
+  const float vmax = Render(blobs, w, h, d, none, frame_0, z_lo, z_hi);
+  Render(blobs, w, h, d, kShift, frame_1, z_lo, z_hi);
+  return vmax;
+}
+
+void TranslatedGaussianPair(size_t w, size_t h, size_t d, float* frame_0, float* frame_1)
+{
+  const float vmax = TranslatedGaussianPlanes(w, h, d, 0, d, frame_0, frame_1);
   const float s = vmax > 0.f ? 255.f / vmax : 1.f;
   const size_t count = w * h * d;
 #pragma omp parallel for schedule(static)

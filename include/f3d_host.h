@@ -74,6 +74,9 @@ int f3d_vtk_write_flow(const char* path, const float* u, const float* v, const f
                        size_t depth);
 /* translated-Gaussian pair: 64 blobs, splitmix64 seed 20241003, frame_1(p) = frame_0(p - t), t = (2, -1, 0.5) */
 int f3d_synth_pair(size_t width, size_t height, size_t depth, float* frame_0, float* frame_1);
+/* slab form: planes [z_lo, z_hi) only, unscaled, plus the maximum of frame_0 over them (scale = 255 / global max) */
+int f3d_synth_planes(size_t width, size_t height, size_t depth, size_t z_lo, size_t z_hi, float* frame_0, float* frame_1,
+                     float* frame_0_max);
 
 /* ---- multi-GPU z-slab driver (OpticalFlowSlab; no reference counterpart) ------------------------ */
 
