@@ -46,3 +46,9 @@ def same(a, b):
 
 def bit_same(a, b):
     return a.shape == b.shape and bool(np.all(np.ascontiguousarray(a).view(np.uint32) == np.ascontiguousarray(b).view(np.uint32)))
+
+
+def flush_c_stdio():
+    """The native side prints with printf; push libc's buffers out so capfd sees the text."""
+    import ctypes
+    ctypes.CDLL(None).fflush(None)

@@ -1,0 +1,70 @@
+"""The C-ABI boundary without a GPU: both shared libraries load, export every symbol the headers declare, fail loudly
+when no device is present, and the product never reaches into the oracle."""
+import ctypes as C
+import glob
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(f3d_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header,lib", [("f3d.h", "hip"), ("f3d_host.h", "host")])
+def test_every_declared_symbol_is_exported(f3d, header, lib):
+    handle = getattr(f3d, lib)()
+    names = declared(header)
+    assert len(names) > 20
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, f"{header} declares symbols the library does not export: {missing}"
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(f3d):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    hip = f3d.hip()
+    assert hip.f3d_init(-1) != 0
+    assert hip.f3d_last_error()
+    assert hip.f3d_stream_sync() != 0  # every entry point refuses to run before f3d_init
+    assert b"f3d_init" in hip.f3d_last_error()
+    flow = f3d.OpticalFlow()
+    with pytest.raises(f3d.F3dError):
+        flow.initialize(16, 16, 16)
+
+
+def test_missing_library_raises(f3d, monkeypatch, tmp_path):
+    monkeypatch.setattr(f3d, "_LIBDIR", str(tmp_path))
+    monkeypatch.setattr(f3d, "_hip", None)
+    with pytest.raises(f3d.F3dError, match="no fallback"):
+        f3d.hip()
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "cuda-flow3d_amd")
+    sources = [p for ext in ("py", "cpp", "h", "hip") for p in glob.glob(os.path.join(pkg, "**", "*." + ext), recursive=True)]
+    sources += [os.path.join(ROOT, "include", h) for h in ("f3d.h", "f3d_host.h")]
+    assert len(sources) > 15
+    for path in sources:
+        text = open(path).read().lower()
+        assert "oracle" not in text, f"{path} mentions the oracle"
+    # and the built libraries do not link it
+    for so in glob.glob(os.path.join(pkg, "lib", "*.so")):
+        assert b"liboracle" not in open(so, "rb").read()
+
+
+def test_struct_layouts_match_the_header(f3d):
+    assert C.sizeof(f3d.Size4) == 4 * C.sizeof(C.c_size_t)       # DataSize4: 4 x size_t, 32 bytes
+    assert C.sizeof(f3d.Slab) == 12
+    p = f3d.FlowParams()
+    f3d.host().f3d_flow_default_params(C.byref(p))
+    got = {k: getattr(p, k) for k, _ in f3d.FlowParams._fields_}
+    for k, v in f3d.DEFAULT_PARAMS.items():
+        assert got[k] == pytest.approx(v), k

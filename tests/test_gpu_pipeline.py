@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import same
+from conftest import flush_c_stdio, same
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -166,4 +166,5 @@ def test_missing_key_is_reported_not_fatal(f3d, capfd):
     op.execute(operand_0=p, data_size=(8, 8, 8))  # operand_1 missing: prints and returns, like the reference macro
     op.destroy()
     cont.free()
+    flush_c_stdio()
     assert "Missing parameter 'operand_1'" in capfd.readouterr().out

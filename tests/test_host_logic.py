@@ -1,0 +1,181 @@
+"""Host-side logic of the product against the oracle and, where it was built, against the reference's own CUDA-free
+sources compiled in place (oracle/_ref): level schedule, Gaussian taps, RAW/VTK I/O, the synthetic generator and the
+z-slab plan.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bit_same, flush_c_stdio
+
+DIMS = [(128, 128, 128), (584, 388, 5), (512, 512, 512), (1024, 1024, 1024), (450, 180, 450), (40, 36, 32), (7, 9, 11),
+        (4, 4, 4), (3, 10, 10), (100, 4, 100), (17, 1000, 33)]
+FACTORS = [0.95, 0.9, 0.5, 0.99, 0.8]
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    r = oracle.ref()
+    if r is None:
+        pytest.skip("oracle/_ref was not built (no reference tree on this machine)")
+    return r
+
+
+@pytest.mark.parametrize("sf", FACTORS)
+def test_level_schedule_product_vs_oracle(f3d, oracle, sf):
+    for dims in DIMS:
+        n = f3d.max_warp_level(*dims, sf)
+        assert n == oracle.max_warp_level(*dims, sf), (dims, sf)
+        for level in {0, 1, n // 2, max(n - 1, 0)}:
+            assert f3d.level_geometry(*dims, sf, level) == oracle.level_geometry(*dims, sf, level)
+
+
+@pytest.mark.parametrize("sf", FACTORS)
+def test_level_schedule_vs_reference_source(f3d, oracle, ref, sf):
+    """optical_flow_base.cpp compiled verbatim: GetMaxWarpLevel is the pinned part of the oracle."""
+    for dims in DIMS:
+        expected = ref.ref_max_warp_level(*dims, sf)
+        assert oracle.max_warp_level(*dims, sf) == expected, (dims, sf)
+        assert f3d.max_warp_level(*dims, sf) == expected, (dims, sf)
+
+
+def test_survey_level_counts(f3d):
+    # 74 / 10 / 101 / 114 possible levels for the four benchmark volumes at 0.95
+    assert [f3d.max_warp_level(*d, 0.95) for d in DIMS[:4]] == [74, 10, 101, 114]
+    assert f3d.level_geometry(128, 128, 128, 0.95, 39)[0] == (18, 18, 18)
+    assert f3d.level_geometry(584, 388, 5, 0.95, 9)[0] == (369, 245, 4)
+
+
+def test_parameter_bag_semantics_of_the_reference(ref):
+    assert ref.ref_params_first_push_wins() == 1
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 2.0, 3.5, 5.0, 8.0])
+def test_gaussian_taps(f3d, oracle, sigma):
+    r_p, t_p = f3d.gaussian_taps(sigma)
+    r_o, t_o = oracle.gaussian_taps(sigma)
+    assert r_p == r_o == int(3 * sigma)
+    assert bit_same(t_p, t_o)
+    assert abs(float(t_p.sum()) - 1.0) < 1e-6 and np.allclose(t_p, t_p[::-1])
+
+
+def test_raw_io_roundtrip_and_reference_reader(f3d, oracle, tmp_path):
+    rng = np.random.default_rng(3)
+    vol = rng.uniform(-20, 300, size=(5, 7, 9)).astype(np.float32)
+    p32 = str(tmp_path / "v-9-7-5.raw")
+    f3d.write_raw(p32, vol)
+    assert np.array_equal(f3d.read_raw(p32, (9, 7, 5), u8=False), vol)
+    assert os.path.getsize(p32) == vol.size * 4
+    p8 = str(tmp_path / "v8.raw")
+    f3d.write_raw(p8, vol, u8=True)
+    back = f3d.read_raw(p8, (9, 7, 5), u8=True)
+    assert np.array_equal(back, np.clip(vol, 0, 255).astype(np.uint8).astype(np.float32))  # clamp, truncate
+    with pytest.raises(f3d.F3dError):
+        f3d.read_raw(p8, (9, 7, 4), u8=True)  # one plane too many in the file: "wrong dimensions"
+    with pytest.raises(f3d.F3dError):
+        f3d.read_raw(p8, (9, 7, 6), u8=True)  # file too short
+    r = oracle.ref()
+    if r is not None and r.ref_have_data3d():
+        import ctypes as C
+        fp = C.POINTER(C.c_float)
+        out = np.empty_like(vol)
+        assert r.ref_read_raw_u8(p8.encode(), 9, 7, 5, out.ctypes.data_as(fp)) == 1
+        assert np.array_equal(out, back)
+        assert r.ref_read_raw_f32(p32.encode(), 9, 7, 5, out.ctypes.data_as(fp)) == 1
+        assert np.array_equal(out, vol)
+        # writers: byte-identical files
+        q8, q32, qv, pv = (str(tmp_path / n) for n in ("r8.raw", "r32.raw", "r.vtk", "p.vtk"))
+        assert r.ref_write_raw(q8.encode(), vol.ctypes.data_as(fp), 9, 7, 5, 1)
+        assert r.ref_write_raw(q32.encode(), vol.ctypes.data_as(fp), 9, 7, 5, 0)
+        assert open(q8, "rb").read() == open(p8, "rb").read()
+        assert open(q32, "rb").read() == open(p32, "rb").read()
+        u, v, w = vol, vol * 2, vol - 1
+        f3d.write_vtk(pv, u, v, w)
+        assert r.ref_write_vtk(qv.encode(), u.ctypes.data_as(fp), v.ctypes.data_as(fp), w.ctypes.data_as(fp), 9, 7, 5)
+        assert open(qv, "rb").read() == open(pv, "rb").read()
+
+
+def test_reference_data_files_read_like_the_fixtures(f3d):
+    path = "/root/reference/data/frame_0_128-128-128.raw"
+    if not os.path.exists(path):
+        pytest.skip("reference data not on this machine")
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "inputs_128.npz"))
+    assert np.array_equal(f3d.read_raw(path, (128, 128, 128), u8=True), gold["frame_0"].astype(np.float32))
+
+
+def test_synthetic_pair_is_deterministic_and_slabwise(f3d):
+    a0, a1 = f3d.synth_pair(40, 36, 24)
+    b0, b1 = f3d.synth_pair(40, 36, 24)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    assert float(a0.max()) == 255.0 and float(a0.min()) >= 0.0
+    f0 = np.zeros((24, 36, 40), np.float32)
+    f1 = np.zeros_like(f0)
+    m = max(f3d.synth_planes(40, 36, 24, lo, hi, f0, f1) for lo, hi in ((0, 7), (7, 19), (19, 24)))
+    s = np.float32(255.0) / np.float32(m)
+    assert np.array_equal(f0 * s, a0) and np.array_equal(f1 * s, a1)
+    # frame_1 is frame_0 moved by (+2, -1, +0.5): the centre of mass moves by about that much
+    def com(v):
+        z, y, x = np.indices(v.shape)
+        t = v.sum(dtype=np.float64)
+        return np.array([(x * v).sum(dtype=np.float64) / t, (y * v).sum(dtype=np.float64) / t, (z * v).sum(dtype=np.float64) / t])
+    assert np.allclose(com(a1) - com(a0), [2.0, -1.0, 0.5], atol=0.1)
+
+
+@pytest.mark.parametrize("depth,n", [(512, 8), (70, 8), (18, 8), (5, 8), (4, 3), (129, 2), (40, 1)])
+def test_slab_partition_covers_the_volume(f3d, depth, n):
+    edges = [f3d.plan_owned(depth, r, n) for r in range(n)]
+    assert edges[0][0] == 0 and edges[-1][1] == depth
+    for (a, b), (c, d) in zip(edges, edges[1:]):
+        assert b == c and a <= b
+    sizes = [b - a for a, b in edges]
+    assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("depth,n,need", [(512, 8, 6), (70, 8, 6), (18, 8, 6), (5, 8, 2), (40, 3, 16), (129, 2, 9)])
+def test_halo_plan_is_consistent_and_complete(f3d, depth, n, need):
+    plans = [f3d.plan_exchange(depth, r, n, need, need) for r in range(n)]
+    for r in range(n):
+        lo, hi = f3d.plan_owned(depth, r, n)
+        got = set()
+        for peer, send, recv in plans[r]:
+            # what I receive from the peer is exactly what the peer says it sends to me, and it owns those planes
+            back = [t for t in plans[peer] if t[0] == r]
+            assert len(back) == 1 and back[0][1] == recv and back[0][2] == send
+            plo, phi = f3d.plan_owned(depth, peer, n)
+            assert recv[0] == recv[1] or (plo <= recv[0] and recv[1] <= phi)
+            assert send[0] == send[1] or (lo <= send[0] and send[1] <= hi)
+            got |= set(range(*recv))
+        wanted = set(range(max(0, lo - need), lo)) | set(range(hi, min(depth, hi + need)))
+        assert got == wanted, (r, sorted(wanted - got), sorted(got - wanted))
+
+
+def test_resample_source_planes_match_the_kernel_rule(f3d):
+    for din, dout in [(512, 70), (70, 74), (5, 4), (128, 122), (19, 19)]:
+        delta = np.float32(din) / np.float32(dout)
+        for lo, hi in [(0, dout), (3, min(9, dout)), (dout - 1, dout), (2, 2)]:
+            got = f3d.plan_resample_source(din, dout, lo, hi)
+            if lo == hi:
+                assert got[0] == got[1]
+                continue
+            left = int(np.floor(np.float32(lo) * delta))
+            right = int(min(np.float32(din), np.ceil(np.float32(hi) * delta)))
+            assert got == (left, right)
+
+
+def test_uninitialised_operator_reports_and_returns(f3d, capfd):
+    op = f3d.Operation("median")
+    assert op.name == "CUDA Median"
+    op.execute(dev_input=1, dev_output=2, data_size=(4, 4, 4), radius=5)
+    flush_c_stdio()
+    assert "was not initialized" in capfd.readouterr().out
+    assert not op.initialize(None)  # Initialize(nullptr): "Initialization parameters are missing."
+    flush_c_stdio()
+    assert "Initialization parameters are missing" in capfd.readouterr().out
+    op.destroy()
+    for name, shown in (("add", "CUDA Add"), ("convolution", "CUDA Convolution 3D"), ("registration", "CUDA Registration"),
+                        ("resample", "CUDA Resample"), ("solve", "CUDA Solve")):
+        o = f3d.Operation(name)
+        assert o.name == shown
+        o.destroy()
+    with pytest.raises(f3d.F3dError):
+        f3d.Operation("fft")

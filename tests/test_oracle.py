@@ -1,0 +1,132 @@
+"""The oracle against the committed golden vectors and against properties the domain offers (no GPU).
+Pinning status: the reference ships no known-answer tests for its kernels, so apart from the level schedule and the
+volume I/O (tests/test_host_logic.py, checked against the reference's own sources) the oracle's kernel numerics are
+'parity unpinned' (DESIGN.md); these tests keep it self-consistent and keep the fixtures honest."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bit_same, box_in_container
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    e = np.load(os.path.join(GOLD, "expected_oracle.npz"))
+    i128 = np.load(os.path.join(GOLD, "inputs_128.npz"))
+    irub = np.load(os.path.join(GOLD, "inputs_rub.npz"))
+    return dict(e=e, f0=i128["frame_0"].astype(np.float32), f1=i128["frame_1"].astype(np.float32),
+                r0=np.repeat(irub["slice_0"][None], 5, 0).astype(np.float32),
+                r1=np.repeat(irub["slice_1"][None], 5, 0).astype(np.float32))
+
+
+def test_fixture_inputs_are_the_shipped_volumes(gold):
+    import hashlib
+    # sha256 of the reference's data files, recomputed from the stored fixtures
+    i128 = np.load(os.path.join(GOLD, "inputs_128.npz"))
+    irub = np.load(os.path.join(GOLD, "inputs_rub.npz"))
+    assert hashlib.sha256(i128["frame_0"].tobytes()).hexdigest() == "a795cd6a36609f53e4839716a606546a85a555bad9760bf9b0275559e7753220"
+    assert hashlib.sha256(i128["frame_1"].tobytes()).hexdigest() == "f2f7b1fbe77ba64a3bb6a794213c2b8d3a42c575cc729b67b10e1307c39bc06b"
+    rub1 = np.repeat(irub["slice_0"][None], 5, 0)
+    rub2 = np.repeat(irub["slice_1"][None], 5, 0)
+    assert hashlib.sha256(rub1.tobytes()).hexdigest() == "fa83c985aa137cccd46f537d949e09e80b5b0bf9511a695b5982f9b921735e8c"
+    assert hashlib.sha256(rub2.tobytes()).hexdigest() == "b3e7ba3ef3b821d13eaa0d1fd2be5db1a426a631c0d5cb00a0731273b930d56d"
+
+
+def test_oracle_reproduces_the_golden_crops(oracle, gold):
+    crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+    (u, v, w), levels = oracle.compute_flow(gold["f0"][crop].copy(), gold["f1"][crop].copy())
+    assert levels == int(gold["e"]["crop128_levels"])
+    assert bit_same(np.stack([u, v, w]), gold["e"]["crop128_flow"])
+    rc = (slice(0, 5), slice(100, 164), slice(200, 296))
+    (u, v, w), levels = oracle.compute_flow(gold["r0"][rc].copy(), gold["r1"][rc].copy())
+    assert bit_same(np.stack([u, v, w]), gold["e"]["croprub_flow"])
+
+
+def test_padded_container_gives_the_same_flow(oracle, gold):
+    crop = (slice(50, 62), slice(40, 64), slice(40, 72))
+    a, _ = oracle.compute_flow(gold["f0"][crop].copy(), gold["f1"][crop].copy(), warp_levels_count=6, outer_iterations_count=3)
+    b, _ = oracle.compute_flow(gold["f0"][crop].copy(), gold["f1"][crop].copy(), pitch_f=48, warp_levels_count=6,
+                               outer_iterations_count=3)
+    for x, y in zip(a, b):
+        assert bit_same(x, y)  # NaN-poisoned padding never reaches the sub-box
+
+
+def test_known_translation_is_recovered(oracle, f3d):
+    f0, f1 = f3d.synth_pair(40, 36, 32)
+    (u, v, w), _ = oracle.compute_flow(f0, f1)
+    inner = (slice(8, -8),) * 3
+    assert abs(float(u[inner].mean()) - 2.0) < 0.15
+    assert abs(float(v[inner].mean()) + 1.0) < 0.15
+    assert abs(float(w[inner].mean()) - 0.5) < 0.15
+
+
+def test_identical_frames_give_zero_flow(oracle, f3d):
+    f0, _ = f3d.synth_pair(32, 24, 16)
+    (u, v, w), _ = oracle.compute_flow(f0, f0.copy(), warp_levels_count=5, outer_iterations_count=3)
+    assert not np.abs(u).any() and not np.abs(v).any() and not np.abs(w).any()
+
+
+def test_median_is_the_window_median(oracle):
+    rng = np.random.default_rng(1)
+    dims = (11, 9, 7)
+    W, H, D = dims
+    vol = rng.normal(size=(D, H, W)).astype(np.float32)
+    for r in (3, 5, 7):
+        h = r // 2
+        pad = np.pad(vol, h, mode="reflect")  # mirror without repeating the edge, like the reference's halo loads
+        win = np.lib.stride_tricks.sliding_window_view(pad, (r, r, r)).reshape(D, H, W, -1)
+        expected = np.sort(win, axis=-1)[..., (r ** 3) // 2]
+        assert np.array_equal(oracle.median(vol, dims, r), expected)
+
+
+def test_resample_warp_and_blur_invariants(oracle):
+    dims, cdims = (21, 13, 9), (32, 16, 12)
+    W, H, D = dims
+    const = np.full((cdims[2], cdims[1], cdims[0]), np.nan, np.float32)
+    const[:D, :H, :W] = 3.25
+    out = oracle.resample(const, dims, (17, 11, 8))
+    assert np.allclose(out[:8, :11, :17], 3.25, rtol=2e-5)          # area resampling preserves constants
+    out = oracle.resample(const, dims, (24, 15, 11))
+    assert np.allclose(out[:11, :15, :24], 3.25, rtol=2e-5)
+    rng = np.random.default_rng(2)
+    f0 = box_in_container(rng, dims, cdims, 0, 255)
+    f1 = box_in_container(rng, dims, cdims, 0, 255)
+    zero = np.full_like(f0, np.nan)
+    zero[:D, :H, :W] = 0
+    assert bit_same(oracle.warp(f0, f1, zero, zero, zero, dims, (1.5, 1.0, 2.0))[:D, :H, :W], f1[:D, :H, :W])
+    far = zero.copy()
+    far[:D, :H, :W] = 1e6                                             # every target leaves the domain -> frame_0
+    assert bit_same(oracle.warp(f0, f1, far, zero, zero, dims, (1.0, 1.0, 1.0))[:D, :H, :W], f0[:D, :H, :W])
+    blur_dims, blur_c = (40, 16, 30), (44, 16, 30)
+    c2 = np.full((blur_c[2], blur_c[1], blur_c[0]), np.nan, np.float32)
+    c2[:, :, :40] = 10.0
+    g = oracle.gaussian(c2, blur_dims, 2.0)
+    assert np.allclose(g[6:-6, 6:-6, 6:34], 10.0, rtol=1e-5)       # interior untouched, borders darkened by zero padding
+    assert float(g[0, 0, 0]) < 10.0 * 0.6 ** 3 + 1.0
+
+
+def test_kernels_on_a_z_window_equal_the_whole_volume(oracle):
+    """The slab parameterisation the multi-GPU driver relies on, on the oracle itself."""
+    rng = np.random.default_rng(4)
+    dims, cdims = (19, 11, 14), (24, 12, 14)
+    W, H, D = dims
+    h = (1.2, 0.9, 1.7)
+    arrs = [box_in_container(rng, dims, cdims, lo, hi) for lo, hi in
+            [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2), (-.5, .5), (-.5, .5), (-.5, .5)]]
+    phi, ksi = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    whole = oracle.solve_sweep(*arrs, phi, ksi, dims, h, 7.5)
+    z_lo, z_hi, z_base = 4, 9, 3                        # container plane 0 holds global plane 3
+    sub = lambda a: np.ascontiguousarray(a[z_base:z_hi + 1])
+    g = oracle.Geom(cdims[1], cdims[0], z_base, z_lo, z_hi)
+    p2, k2 = oracle.phi_ksi(*[sub(a) for a in arrs], dims, h, 0.001, 0.001, g=g)
+    assert bit_same(p2[z_lo - z_base:z_hi - z_base, :H, :W], phi[z_lo:z_hi, :H, :W])
+    part = oracle.solve_sweep(*[sub(a) for a in arrs], sub(phi), sub(ksi), dims, h, 7.5, g=g)
+    for a, b in zip(part, whole):
+        assert bit_same(a[z_lo - z_base:z_hi - z_base, :H, :W], b[z_lo:z_hi, :H, :W])
+    med = oracle.median(arrs[2], dims, 5)
+    g5 = oracle.Geom(cdims[1], cdims[0], 2, 4, 9)
+    part = oracle.median(np.ascontiguousarray(arrs[2][2:11]), dims, 5, g=g5)
+    assert bit_same(part[2:7, :H, :W], med[4:9, :H, :W])

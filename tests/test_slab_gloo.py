@@ -1,0 +1,120 @@
+"""The N > 1 path on CPU: two processes over torch.distributed (gloo) run the solver stage and the median of the
+z-slab decomposition with the ORACLE as the compute and the PRODUCT's plan (f3d_plan_owned / f3d_plan_exchange, the
+communication-avoiding windows of OpticalFlowSlab) deciding who owns what, which planes travel and which widened
+windows every sweep covers.  Rank 0 gathers the slabs and compares them with the unsplit oracle, bit for bit."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.environ["F3D_ROOT"])
+    os.environ["OMP_NUM_THREADS"] = "2"
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    from oracle import oracle as orc
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H, D = 23, 14, int(os.environ["F3D_DEPTH"])
+    K, OUTER, HALO = 5, 3, 8
+    dims, h = (W, H, D), (1.3, 0.8, 1.6)
+    rng = np.random.default_rng(7)
+    full = [rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32)
+            for lo, hi in [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2)]]           # f0, f1w, u, v, w
+    lo, hi = pkg.plan_owned(D, rank, world)
+    base = lo - HALO
+    depth_c = (D + world - 1) // world + 1 + 2 * HALO
+
+    def container(vol=None):
+        c = np.full((depth_c, H, W), np.nan, np.float32)
+        if vol is not None and hi > lo:
+            c[lo - base:hi - base] = vol[lo:hi]
+        return c
+
+    def exchange(fields, need):
+        """Make `need` planes around the slab valid, exactly as OpticalFlowSlab::Exchange plans it."""
+        reqs = []
+        for peer, send, recv in pkg.plan_exchange(D, rank, world, need, need):
+            for f in fields:
+                if send[1] > send[0]:
+                    reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(f[send[0] - base:send[1] - base])), peer))
+            for f in fields:
+                if recv[1] > recv[0]:
+                    buf = torch.empty((recv[1] - recv[0], H, W), dtype=torch.float32)
+                    dist.recv(buf, peer)
+                    f[recv[0] - base:recv[1] - base] = buf.numpy()
+        for r in reqs:
+            r.wait()
+
+    def window(grow):
+        return orc.Geom(H, W, base, max(0, lo - grow), min(D, hi + grow)) if hi > lo else orc.Geom(H, W, base, lo, lo)
+
+    f0, f1, u, v, w = (container(x) for x in full)
+    exchange([f0, f1, u, v, w], K + 1)                                                 # level-static halos
+    du, dv, dw = (container() for _ in range(3))
+    for c in (du, dv, dw):
+        c[:] = 0
+    tmp = [container() for _ in range(3)]
+    for it in range(OUTER):
+        phi, ksi = orc.phi_ksi(f0, f1, u, v, w, du, dv, dw, dims, h, 0.001, 0.001, g=window(K))
+        for j in range(K):
+            orc.solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, 7.5, g=window(K - 1 - j), out=tuple(tmp))
+            (du, dv, dw), tmp = tuple(tmp), [du, dv, dw]
+        if it + 1 < OUTER:
+            exchange([du, dv, dw], K + 1)
+    own = window(0)
+    for a, b in ((u, du), (v, dv), (w, dw)):
+        orc.add(a, b, dims, g=own)
+    exchange([u, v, w], 2)
+    med = [orc.median(x, dims, 5, g=own) for x in (u, v, w)]
+
+    mine = np.stack([m[lo - base:hi - base] for m in med]) if hi > lo else np.zeros((3, 0, H, W), np.float32)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, mine))
+    if rank == 0:
+        out = np.zeros((3, D, H, W), np.float32)
+        for a, b, m in gathered:
+            out[:, a:b] = m
+        # the unsplit oracle
+        du = np.zeros((D, H, W), np.float32); dv = du.copy(); dw = du.copy()
+        for it in range(OUTER):
+            phi, ksi = orc.phi_ksi(*full, du, dv, dw, dims, h, 0.001, 0.001)
+            for j in range(K):
+                du, dv, dw = orc.solve_sweep(*full, du, dv, dw, phi, ksi, dims, h, 7.5)
+        u2, v2, w2 = full[2].copy(), full[3].copy(), full[4].copy()
+        for a, b in ((u2, du), (v2, dv), (w2, dw)):
+            orc.add(a, b, dims)
+        ref = np.stack([orc.median(x, dims, 5) for x in (u2, v2, w2)])
+        same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        print("SLAB_OK" if same else "SLAB_MISMATCH max %g" % np.abs(out - ref).max(), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("depth", [17, 6])   # 6 planes on 2 ranks: slabs thinner than the 6-plane solver halo
+def test_two_ranks_over_gloo_match_the_unsplit_oracle(tmp_path, depth):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, F3D_ROOT=ROOT, F3D_DEPTH=str(depth), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "SLAB_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
