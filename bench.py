@@ -202,6 +202,10 @@ def run_multi(args):
 
 
 def main():
+    # the native side prints its init/progress lines with printf: keep stdout for the ONE JSON line
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real_stdout, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_round.sh output directory into profiles/<tag>_*.{csv,json,md} (the committed evidence)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
+bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_bench512_rocprofv3_kernel_stats.csv"))
+lines = [f"# {tag}: rocprofv3 evidence for `python bench.py` (512^3, full default pyramid, 1x MI355X)", ""]
+lines += ["## bench line", "```json", json.dumps(bench), "```", ""]
+lines += ["## rocprofv3 --kernel-trace --stats  -- python3 bench.py --steps 1 --warmup 0 --no-cpu", "",
+          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+for r in csv.DictReader(open(stats)):
+    lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+lines += ["", "## PMC passes on tools/kbench.py --size 512 (one 512^3 level; separate rocprofv3 --pmc runs), averages per launch", "",
+          "| kernel | counter | value |", "|---|---|---|"]
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if "k_sweep3" in r["Kernel_Name"] or "k_phiksi3" in r["Kernel_Name"] or "k_cal" in r["Kernel_Name"]:
+            name = "k_sweep3" if "k_sweep3" in r["Kernel_Name"] else ("k_phiksi3" if "k_phiksi3" in r["Kernel_Name"] else r["Kernel_Name"][:40])
+            agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in sorted(agg.items()):
+        lines.append(f"| {k} | {c} | {sum(v) / len(v):.6g} |")
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[-30:]))
