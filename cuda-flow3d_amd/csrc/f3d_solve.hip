@@ -664,6 +664,196 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo 
   }
 }
 
+// ---- variant 4 (sweep): k_sweep3 with every halo load issued TWO planes ahead, like the row loads ----------------
+// The y-halo rows and x-halo columns of a tile are the interior of the neighbouring tiles, which the XCD-contiguous
+// tile order runs at the same time on the same L2.  They only hit that L2 if they are requested when the owner streams
+// the same plane, so all three kinds of loads of a step target plane z+2; halo data then waits two steps in a small
+// per-wave LDS ring (raw rows / column pairs) instead of in registers, which also frees 22 VGPRs.
+__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep4(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                            int xcd_remap)
+{
+  __shared__ float img[2][kNL][kTY3 + 2][kLanes];   // face image of the current plane, double buffered
+  __shared__ float hrow[3][2][9][kLanes];           // raw y-halo rows of planes z, z+1, z+2 (edge waves)
+  __shared__ float hcol[3][9][kTY3][2];             // raw x-halo column pairs of planes z, z+1, z+2 (every wave)
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * kTY3;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kLanes + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool owner = x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;  // which x-halo column this lane fetches / uses
+  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
+  const bool edge = (r == 0) || (r == kTY3 - 1);
+  const int which = r == 0 ? 0 : 1;
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
+
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
+  __amdgpu_buffer_rsrc_t rs[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](PlaneRegs& p, unsigned lane_bytes, int yrow, int zz) {
+    const unsigned ro = rowoff(yrow, zz);
+    p.f0 = buf_ld(rs[F0], lane_bytes, ro);
+    p.f1 = buf_ld(rs[F1], lane_bytes, ro);
+    p.u = buf_ld(rs[U], lane_bytes, ro);
+    p.v = buf_ld(rs[V], lane_bytes, ro);
+    p.w = buf_ld(rs[Wf], lane_bytes, ro);
+    p.su = buf_ld(rs[DU], lane_bytes, ro);
+    p.dv = buf_ld(rs[DV], lane_bytes, ro);
+    p.dw = buf_ld(rs[DW], lane_bytes, ro);
+    p.phi = buf_ld(rs[PHI], lane_bytes, ro);
+  };
+  // raw plane <-> LDS ring slots (per-wave private storage: written and read by the same wave)
+  auto put_row = [&](const PlaneRegs& p, int slot) {
+    float* d = &hrow[slot][which][0][lane];
+    d[0 * kLanes] = p.f0; d[1 * kLanes] = p.f1; d[2 * kLanes] = p.u; d[3 * kLanes] = p.v; d[4 * kLanes] = p.w;
+    d[5 * kLanes] = p.su; d[6 * kLanes] = p.dv; d[7 * kLanes] = p.dw; d[8 * kLanes] = p.phi;
+  };
+  auto get_row = [&](PlaneRegs& p, int slot) {
+    const float* d = &hrow[slot][which][0][lane];
+    p.f0 = d[0 * kLanes]; p.f1 = d[1 * kLanes]; p.u = d[2 * kLanes]; p.v = d[3 * kLanes]; p.w = d[4 * kLanes];
+    p.su = d[5 * kLanes]; p.dv = d[6 * kLanes]; p.dw = d[7 * kLanes]; p.phi = d[8 * kLanes];
+  };
+  auto put_col = [&](const PlaneRegs& p, int slot) {
+    if (lane == 0 || lane == 32) {
+      float* d = &hcol[slot][0][r][side];
+      constexpr int st = kTY3 * 2;
+      d[0 * st] = p.f0; d[1 * st] = p.f1; d[2 * st] = p.u; d[3 * st] = p.v; d[4 * st] = p.w;
+      d[5 * st] = p.su; d[6 * st] = p.dv; d[7 * st] = p.dw; d[8 * st] = p.phi;
+    }
+  };
+  auto get_col = [&](PlaneRegs& p, int slot) {
+    const float* d = &hcol[slot][0][r][side];
+    constexpr int st = kTY3 * 2;
+    p.f0 = d[0 * st]; p.f1 = d[1 * st]; p.u = d[2 * st]; p.v = d[3 * st]; p.w = d[4 * st];
+    p.su = d[5 * st]; p.dv = d[6 * st]; p.dw = d[7 * st]; p.phi = d[8 * st];
+  };
+
+  auto step = [&](const PlaneRegs& M, const PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, int z) {
+    const bool more = z + 1 < z1;       // plane z+1 will be computed: its neighbours (z+2) must be fetched
+    PlaneRegs XQ, HQ;
+    if (more) {
+      const int zq = f3d_mir(z + 2, g.D);
+      load_plane(Q, xb, yy, zq);
+      P.ksi = buf_ld(rs[9], xb, rowoff(yy, z + 1));
+      // halos of plane z+2 are only needed if that plane is computed by this chunk
+      if (z + 2 < z1) {
+        load_plane(XQ, xhb, yy, z + 2);
+        if (edge) load_plane(HQ, xb, yh_row, z + 2);
+      }
+    }
+    const int b = z & 1;
+    const int slot = z % 3;
+    const Face6 cf = plane_face(C);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) img[b][i][r + 1][lane] = cf.v[i];
+    if (edge) {
+      PlaneRegs Hc;
+      get_row(Hc, slot);
+      plane_finish(Hc);
+      const Face6 hf = plane_face(Hc);
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) img[b][i][lds_halo][lane] = hf.v[i];
+    }
+    PlaneRegs X;
+    get_col(X, slot);
+    __syncthreads();
+
+    Face6 ym, yp, xm, xp;
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      ym.v[i] = img[b][i][r][lane];
+      yp.v[i] = img[b][i][r + 2][lane];
+    }
+    plane_finish(X);
+    const Face6 xf = plane_face(X);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+      xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+    }
+    float r_du, r_dv, r_dw;
+    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this step (and the previous step's stores)
+    if (more) {
+      plane_finish(Q);
+      if (z + 2 < z1) {
+        const int s2 = (z + 2) % 3;
+        put_col(XQ, s2);
+        if (edge) put_row(HQ, s2);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (owner) {
+      const size_t o = f3d_row(g, yy, z) + xi;
+      a.out[0][o] = r_du;
+      a.out[1][o] = r_dv;
+      a.out[2][o] = r_dw;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  PlaneRegs A, B, C, D;
+  {
+    PlaneRegs T0, T1;
+    load_plane(A, xb, yy, f3d_mir(z0 - 1, g.D));
+    load_plane(B, xb, yy, z0);
+    B.ksi = buf_ld(rs[9], xb, rowoff(yy, z0));
+    load_plane(C, xb, yy, f3d_mir(z0 + 1, g.D));
+    load_plane(T0, xhb, yy, z0);
+    if (z0 + 1 < z1) load_plane(T1, xhb, yy, z0 + 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    put_col(T0, z0 % 3);
+    if (z0 + 1 < z1) put_col(T1, (z0 + 1) % 3);
+    if (edge) {
+      load_plane(T0, xb, yh_row, z0);
+      if (z0 + 1 < z1) load_plane(T1, xb, yh_row, z0 + 1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      put_row(T0, z0 % 3);
+      if (z0 + 1 < z1) put_row(T1, (z0 + 1) % 3);
+    }
+    plane_finish(A);
+    plane_finish(B);
+    plane_finish(C);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  for (int z = z0; z < z1; z += 4) {
+    step(A, B, C, D, z);
+    if (z + 1 < z1) step(B, C, D, A, z + 1);
+    if (z + 2 < z1) step(C, D, A, B, z + 2);
+    if (z + 3 < z1) step(D, A, B, C, z + 3);
+  }
+}
+
 // ---- variant 3, phi/ksi: same data movement as k_sweep3 (aligned 64-wide tiles, rows of the current plane through a
 // double-buffered LDS image, edge waves stream the y-halo rows, four rotating plane register sets); all eight inputs
 // are stencilled here (the central differences of A.3 do not factor), and there is nothing to pre-combine.
@@ -789,6 +979,7 @@ struct Tuning {
   int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds), 3 = k_sweep3 (sweep) + 2 (phi/ksi)
   int aligned;     // variant 3: 64-aligned x tiles with narrow x-halo loads instead of overlapping 62-wide tiles
   int cleanwait;   // variant 3: explicit end-of-step vmcnt(0)
+  int variant4;    // sweep: halo loads two planes ahead through LDS rings (k_sweep4)
   int xcd_remap;
   int zchunk;      // 0 = automatic
   long want_wg;
@@ -797,11 +988,12 @@ struct Tuning {
 const Tuning& tuning()
 {
   static const Tuning t = [] {
-    Tuning v = {3, 1, 1, 1, 0, 4096};
+    Tuning v = {3, 1, 1, 1, 1, 0, 4096};
     if (const char* e = std::getenv("F3D_SOLVER_VARIANT")) v.variant = std::atoi(e);
     if (const char* e = std::getenv("F3D_XCD_REMAP")) v.xcd_remap = std::atoi(e);
     if (const char* e = std::getenv("F3D_ALIGNED")) v.aligned = std::atoi(e);
     if (const char* e = std::getenv("F3D_CLEANWAIT")) v.cleanwait = std::atoi(e);
+    if (const char* e = std::getenv("F3D_SWEEP4")) v.variant4 = std::atoi(e);
     if (const char* e = std::getenv("F3D_ZCHUNK")) v.zchunk = std::atoi(e);
     if (const char* e = std::getenv("F3D_WANT_WG")) v.want_wg = std::atol(e);
     return v;
@@ -841,7 +1033,9 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
     if (v3) {
       const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
       auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
-      if (t.aligned) {
+      if (t.variant4) {
+        go(k_sweep4);
+      } else if (t.aligned) {
         if (t.cleanwait) go(k_sweep3<true, true>); else go(k_sweep3<true, false>);
       } else {
         if (t.cleanwait) go(k_sweep3<false, true>); else go(k_sweep3<false, false>);
