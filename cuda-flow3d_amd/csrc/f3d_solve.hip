@@ -13,6 +13,7 @@
 //     moment, so they are served by the CU's L1/the XCD's L2; mirror (Neumann) halos are index arithmetic.
 //   * loads for the next z step are issued before the arithmetic of the current one (software pipelining).
 #include <cstdlib>
+#include <type_traits>
 
 #include "f3d_internal.h"
 
@@ -854,6 +855,451 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep4(SolveArgs a, F3dGeo 
   }
 }
 
+// ---- variant 5 (sweep): halos by LDS-DMA, own rows prefetched TWO steps ahead ------------------------------------
+// The sweep is latency-bound at 16 waves/CU x ~3 KB in flight.  Here the halo traffic of k_sweep4 no longer passes
+// through VGPRs at all (`buffer_load_dword ... lds` lands it in the per-wave LDS rings directly), which frees the
+// registers for a fifth rotating plane set: the row of plane z+3 is requested at step z and only has to be there at
+// the end of step z+1 (counted `s_waitcnt vmcnt(N)` leaves the youngest step's loads in flight).
+constexpr int kRing = 4;  // planes z .. z+3
+
+// `buffer_load_dword ... lds`: 64 lanes x 4 B land at LDS address m0 + 4 * lane (masked lanes write nothing, measured
+// with tools/lab/dma_probe.hip).  Issued through inline asm on purpose: hipcc makes every later ds_read wait for
+// vmcnt(0) once it knows of an LDS-DMA in flight, which would serialise the prefetch.  The waits are ours (below).
+typedef __attribute__((address_space(3))) float LdsFloat;
+__device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rs, float* lds_dst, unsigned lane_bytes, unsigned row_bytes)
+{
+  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
+  asm volatile("buffer_load_dword %0, %1, %2 offen lds" ::"v"(lane_bytes), "s"(rs), "s"(row_bytes), "{m0}"(m0v) : "memory");
+}
+
+__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep5(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                            int xcd_remap)
+{
+  __shared__ float img[2][kNL][kTY3 + 2][kLanes];  // face image of the current plane, double buffered
+  __shared__ float hrow[kRing][2][9][kLanes];      // raw y-halo rows (edge waves), filled by LDS-DMA
+  __shared__ float hcol[kRing][3][kLanes];         // raw x-halo pairs: entry e = array*8 + row -> [e/32][side*32 + e%32]
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * kTY3;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kLanes + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool owner = x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;
+  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
+  const bool col_lane = lane == 0 || lane == 32;
+  const bool edge = (r == 0) || (r == kTY3 - 1);
+  const int which = r == 0 ? 0 : 1;
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
+
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
+  __amdgpu_buffer_rsrc_t rs[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  constexpr int kOrder[9] = {F0, F1, U, V, Wf, DU, DV, DW, PHI};  // slot order inside the rings = PlaneRegs order below
+  auto load_plane = [&](PlaneRegs& p, int zz) {  // own row, incl. ksi
+    const unsigned ro = rowoff(yy, zz);
+    p.f0 = buf_ld(rs[F0], xb, ro);
+    p.f1 = buf_ld(rs[F1], xb, ro);
+    p.u = buf_ld(rs[U], xb, ro);
+    p.v = buf_ld(rs[V], xb, ro);
+    p.w = buf_ld(rs[Wf], xb, ro);
+    p.su = buf_ld(rs[DU], xb, ro);
+    p.dv = buf_ld(rs[DV], xb, ro);
+    p.dw = buf_ld(rs[DW], xb, ro);
+    p.phi = buf_ld(rs[PHI], xb, ro);
+    p.ksi = buf_ld(rs[9], xb, ro);
+  };
+  // LDS-DMA of the halos of plane zz into ring slot zz & 3: no VGPR is written
+  auto dma_halos = [&](int zz) {
+    const int slot = zz & (kRing - 1);
+    const unsigned ro = rowoff(yy, zz);
+    if (col_lane) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int e = i * kTY3 + r;
+        dma_to_lds(rs[kOrder[i]], &hcol[slot][e >> 5][e & 31], xhb, ro);
+      }
+    }
+    if (edge) {
+      const unsigned rh = rowoff(yh_row, zz);
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+        dma_to_lds(rs[kOrder[i]], &hrow[slot][which][i][0], xb, rh);
+    }
+  };
+  auto ring_row = [&](PlaneRegs& p, int slot) {
+    const float* d = &hrow[slot][which][0][lane];
+    p.f0 = d[0 * kLanes]; p.f1 = d[1 * kLanes]; p.u = d[2 * kLanes]; p.v = d[3 * kLanes]; p.w = d[4 * kLanes];
+    p.su = d[5 * kLanes]; p.dv = d[6 * kLanes]; p.dw = d[7 * kLanes]; p.phi = d[8 * kLanes];
+  };
+  auto ring_col = [&](PlaneRegs& p, int slot) {
+    auto at = [&](int i) {
+      const int e = i * kTY3 + r;
+      return hcol[slot][e >> 5][side * 32 + (e & 31)];
+    };
+    p.f0 = at(0); p.f1 = at(1); p.u = at(2); p.v = at(3); p.w = at(4);
+    p.su = at(5); p.dv = at(6); p.dw = at(7); p.phi = at(8);
+  };
+
+  // M, C, P: finished planes z-1, z, z+1.  Q1: raw plane z+2, requested one step ago.  Q2: receives plane z+3.
+  // FULL: steady state (z + 3 < z1), no conditions, so the load counts the compiler tracks stay exact
+  auto step = [&](auto full, const PlaneRegs& M, const PlaneRegs& C, const PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int z) {
+    constexpr bool FULL = decltype(full)::value;
+    const bool row3 = FULL || z + 3 <= z1;   // plane z+3 is somebody's z-neighbour
+    const bool halo3 = FULL || z + 3 < z1;   // plane z+3 is computed by this chunk
+    // halos first: the compiler counts only the register loads, so its (and our) vmcnt(10) at the end of the step
+    // retires everything older than this step's ten row loads -- the DMA of this step included
+    if (halo3) dma_halos(z + 3);
+    if (row3) load_plane(Q2, f3d_mir(z + 3, g.D));
+
+    const int b = z & 1;
+    const int slot = z & (kRing - 1);
+    const Face6 cf = plane_face(C);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) img[b][i][r + 1][lane] = cf.v[i];
+    if (edge) {
+      PlaneRegs Hc;
+      ring_row(Hc, slot);
+      plane_finish(Hc);
+      const Face6 hf = plane_face(Hc);
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) img[b][i][lds_halo][lane] = hf.v[i];
+    }
+    PlaneRegs X;
+    ring_col(X, slot);
+    __syncthreads();
+
+    Face6 ym, yp, xm, xp;
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      ym.v[i] = img[b][i][r][lane];
+      yp.v[i] = img[b][i][r + 2][lane];
+    }
+    plane_finish(X);
+    const Face6 xf = plane_face(X);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+      xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+    }
+    float r_du, r_dv, r_dw;
+    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
+    __builtin_amdgcn_sched_barrier(0);
+    // everything requested BEFORE this step must have landed (plane z+2 and its halos, last step's stores); what this
+    // step requested stays in flight: counted wait, the counter retires in order
+    if (row3) __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10): this step's row loads stay in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+    if (FULL || z + 2 <= z1) plane_finish(Q1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (owner) {
+      const size_t o = f3d_row(g, yy, z) + xi;
+      a.out[0][o] = r_du;
+      a.out[1][o] = r_dv;
+      a.out[2][o] = r_dw;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  PlaneRegs A, B, C, D, E;
+  load_plane(A, f3d_mir(z0 - 1, g.D));
+  load_plane(B, z0);
+  load_plane(C, f3d_mir(z0 + 1, g.D));
+  dma_halos(z0);
+  if (z0 + 1 < z1) dma_halos(z0 + 1);
+  if (z0 + 2 < z1) dma_halos(z0 + 2);
+  if (z0 + 2 <= z1) load_plane(D, f3d_mir(z0 + 2, g.D));
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  plane_finish(A);
+  plane_finish(B);
+  plane_finish(C);
+  __syncthreads();  // the rings are private to their wave, but let the DMA-written LDS settle for everybody once
+  __builtin_amdgcn_sched_barrier(0);
+  int z = z0;
+  for (; z + 7 < z1; z += 5) {  // five steady-state steps: the last one (z+4) still has z+4+3 < z1
+    step(std::true_type{}, A, B, C, D, E, z);
+    step(std::true_type{}, B, C, D, E, A, z + 1);
+    step(std::true_type{}, C, D, E, A, B, z + 2);
+    step(std::true_type{}, D, E, A, B, C, z + 3);
+    step(std::true_type{}, E, A, B, C, D, z + 4);
+  }
+  for (; z < z1; z += 5) {      // tail (and chunks shorter than 8 planes): same rotation, guarded loads
+    step(std::false_type{}, A, B, C, D, E, z);
+    if (z + 1 < z1) step(std::false_type{}, B, C, D, E, A, z + 1);
+    if (z + 2 < z1) step(std::false_type{}, C, D, E, A, B, z + 2);
+    if (z + 3 < z1) step(std::false_type{}, D, E, A, B, C, z + 3);
+    if (z + 4 < z1) step(std::false_type{}, E, A, B, C, D, z + 4);
+  }
+}
+
+// ---- variant 6 (sweep): k_sweep5 with the whole load path issued by hand -------------------------------------------
+// PMC on k_sweep4 (profiles/): the TA address FIFO is full a third of the time and the scalar unit issues half as many
+// instructions as the vector unit, most of them `s_mov_b32` shuffling the ten buffer descriptors into aligned SGPR quads.
+// Here every load is a `global_load_dword vdst, voff, s[base:base+1]` (two SGPRs per array, no descriptor, one VALU add
+// per plane for the shared row offset), the 18 x-halo values of a row are fetched by ONE instruction (lane i / 32+i reads
+// array i, landing in LDS by DMA), and since the compiler no longer sees any load it inserts no waits: the two
+// `s_waitcnt vmcnt(N)` per step below are the only ones, tied to the registers they guard by "+v" operands.
+__device__ __forceinline__ float gld(const float* base, unsigned byte_off)
+{
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+  return v;
+}
+__device__ __forceinline__ void gst(float* base, unsigned byte_off, float v)
+{
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gld_lds(const float* base, unsigned byte_off, float* lds_dst)
+{
+  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
+  asm volatile("global_load_lds_dword %0, %1" ::"v"(byte_off), "s"(base), "{m0}"(m0v) : "memory");
+}
+__device__ __forceinline__ void gld_lds_lane(const float* lane_addr, float* lds_dst)
+{
+  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
+  asm volatile("global_load_lds_dword %0, off" ::"v"(lane_addr), "{m0}"(m0v) : "memory");
+}
+#define F3D_WAIT_PLANE(N, P)                                                                                           \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
+               : "+v"((P).f0), "+v"((P).f1), "+v"((P).phi), "+v"((P).u), "+v"((P).v), "+v"((P).w), "+v"((P).su),       \
+                 "+v"((P).dv), "+v"((P).dw), "+v"((P).ksi)::"memory")
+
+// ABLATE (timing experiments only, results are wrong): 1 = no arithmetic, 2 = no halo traffic, 3 = no LDS exchange
+template <int ABLATE, int TY>
+__global__ __launch_bounds__(kLanes* TY, 4) void k_sweep6(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                            int xcd_remap)
+{
+  __shared__ float img[2][kNL][TY + 2][kLanes];  // face image of the current plane, double buffered
+  __shared__ float hrow[kRing][2][9][kLanes];      // raw y-halo rows (edge waves), by LDS-DMA
+  __shared__ float hcol[kRing][TY][kLanes];      // raw x-halo values of a row: [array] left, [32 + array] right
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * TY;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kLanes + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool owner = x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;
+  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const bool edge = (r == 0) || (r == TY - 1);
+  const int which = r == 0 ? 0 : 1;
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + TY, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : TY + 1;
+
+  // array bases moved to the first plane this chunk touches: every byte offset below is small and positive
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  constexpr int kOrder[9] = {F0, F1, U, V, Wf, DU, DV, DW, PHI};  // order inside the halo rings
+  const float* base[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) base[i] = a.in[i] + base_off;
+  float* obase[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) obase[i] = a.out[i] + base_off;
+  // lane i (and 32 + i), i < 9, gathers the x-halo of array kOrder[i]: its own 64-bit base
+  const bool col_lane = (lane & 31) < 9;
+  const float* lane_base = base[0];
+#pragma unroll
+  for (int i = 1; i < 9; ++i)
+    if ((lane & 31) == i) lane_base = base[kOrder[i]];
+  lane_base += xh;
+
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](PlaneRegs& p, int zz) {
+    const unsigned off = xb + rowoff(yy, zz);
+    p.f0 = gld(base[F0], off);
+    p.f1 = gld(base[F1], off);
+    p.u = gld(base[U], off);
+    p.v = gld(base[V], off);
+    p.w = gld(base[Wf], off);
+    p.su = gld(base[DU], off);
+    p.dv = gld(base[DV], off);
+    p.dw = gld(base[DW], off);
+    p.phi = gld(base[PHI], off);
+    p.ksi = gld(base[9], off);
+  };
+  auto dma_halos = [&](int zz) {  // 1 instruction per wave + 9 for the two edge waves
+    const int slot = zz & (kRing - 1);
+    if (col_lane) gld_lds_lane(lane_base + (rowoff(yy, zz) >> 2), &hcol[slot][r][0]);
+    if (edge) {
+      const unsigned off = xb + rowoff(yh_row, zz);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gld_lds(base[kOrder[i]], off, &hrow[slot][which][i][0]);
+    }
+  };
+  auto ring_row = [&](PlaneRegs& p, int slot) {
+    const float* d = &hrow[slot][which][0][lane];
+    p.f0 = d[0 * kLanes]; p.f1 = d[1 * kLanes]; p.u = d[2 * kLanes]; p.v = d[3 * kLanes]; p.w = d[4 * kLanes];
+    p.su = d[5 * kLanes]; p.dv = d[6 * kLanes]; p.dw = d[7 * kLanes]; p.phi = d[8 * kLanes];
+  };
+  auto ring_col = [&](PlaneRegs& p, int slot) {
+    const float* d = &hcol[slot][r][side * 32];
+    p.f0 = d[0]; p.f1 = d[1]; p.u = d[2]; p.v = d[3]; p.w = d[4]; p.su = d[5]; p.dv = d[6]; p.dw = d[7]; p.phi = d[8];
+  };
+
+  // write the face image of a finished plane (own row, and the halo row an edge wave keeps in its ring) into buffer nb
+  auto publish = [&](const PlaneRegs& pl, int nb, int ring_slot) {
+    const Face6 f = plane_face(pl);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) img[nb][i][r + 1][lane] = f.v[i];
+    if (edge) {
+      PlaneRegs Hc;
+      ring_row(Hc, ring_slot);
+      plane_finish(Hc);
+      const Face6 hf = plane_face(Hc);
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) img[nb][i][lds_halo][lane] = hf.v[i];
+    }
+  };
+
+  // M, C, P: finished planes z-1, z, z+1.  Q1: raw plane z+2, requested one step ago.  Q2: receives plane z+3.
+  auto step = [&](auto full, const PlaneRegs& M, const PlaneRegs& C, const PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int z) {
+    constexpr bool FULL = decltype(full)::value;
+    const bool row3 = FULL || z + 3 <= z1;   // plane z+3 is somebody's z-neighbour
+    const bool halo3 = FULL || z + 3 < z1;   // plane z+3 is computed by this chunk
+    if (row3) load_plane(Q2, f3d_mir(z + 3, g.D));
+    if (halo3 && ABLATE != 2) dma_halos(z + 3);
+
+    const int b = z & 1;
+    const int slot = z & (kRing - 1);
+    const Face6 cf = plane_face(C);
+    if (ABLATE != 3) __syncthreads();  // the image of plane z is complete: it was written during step z-1 (or the prologue)
+
+    Face6 ym, yp, xm, xp;
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      ym.v[i] = img[b][i][r][lane];
+      yp.v[i] = img[b][i][r + 2][lane];
+    }
+    PlaneRegs X;
+    ring_col(X, slot);
+    // Publish the NEXT plane now, off the critical path of the next barrier: buffer b^1 was last read during step z-1,
+    // i.e. before the barrier every wave has just passed.
+    if ((FULL || z + 1 < z1) && ABLATE != 3) publish(P, b ^ 1, (z + 1) & (kRing - 1));
+    plane_finish(X);
+    const Face6 xf = plane_face(X);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) {
+      xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+      xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+    }
+    float r_du, r_dv, r_dw;
+    if (ABLATE == 1) {
+      r_du = xm.v[0] + xp.v[1] + ym.v[2] + yp.v[3] + M.su + P.sv + C.ksi;
+      r_dv = xm.v[4] + xp.v[5] + ym.v[0] + yp.v[1] + M.f0 + P.f1 + C.u;
+      r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
+    } else {
+      sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                    a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
+    }
+    asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
+    __builtin_amdgcn_sched_barrier(0);
+    // All that was requested BEFORE this step must have landed (plane z+2, its halos, the last stores); what this step
+    // requested stays in flight: the counter retires in order, so allow exactly this step's loads.
+    if (FULL && ABLATE == 2) {
+      F3D_WAIT_PLANE(10, Q1);
+    } else if (FULL) {
+      if (edge) F3D_WAIT_PLANE(20, Q1);  // 10 row + 1 column gather + 9 halo-row loads
+      else F3D_WAIT_PLANE(11, Q1);
+    } else {
+      F3D_WAIT_PLANE(0, Q1);
+    }
+    if (FULL || z + 2 <= z1) plane_finish(Q1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (owner) {
+      const unsigned off = xb + rowoff(yy, z);
+      gst(obase[0], off, r_du);
+      gst(obase[1], off, r_dv);
+      gst(obase[2], off, r_dw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  PlaneRegs A, B, C, D, E;
+  E = PlaneRegs{};
+  D = PlaneRegs{};
+  load_plane(A, f3d_mir(z0 - 1, g.D));
+  load_plane(B, z0);
+  load_plane(C, f3d_mir(z0 + 1, g.D));
+  if (z0 + 2 <= z1) load_plane(D, f3d_mir(z0 + 2, g.D));
+  dma_halos(z0);
+  if (z0 + 1 < z1) dma_halos(z0 + 1);
+  if (z0 + 2 < z1) dma_halos(z0 + 2);
+  F3D_WAIT_PLANE(0, A);
+  F3D_WAIT_PLANE(0, B);
+  F3D_WAIT_PLANE(0, C);
+  F3D_WAIT_PLANE(0, D);
+  plane_finish(A);
+  plane_finish(B);
+  plane_finish(C);
+  __syncthreads();  // DMA-written rings are visible
+  publish(B, z0 & 1, z0 & (kRing - 1));
+  __builtin_amdgcn_sched_barrier(0);
+  int z = z0;
+  for (; z + 7 < z1; z += 5) {
+    step(std::true_type{}, A, B, C, D, E, z);
+    step(std::true_type{}, B, C, D, E, A, z + 1);
+    step(std::true_type{}, C, D, E, A, B, z + 2);
+    step(std::true_type{}, D, E, A, B, C, z + 3);
+    step(std::true_type{}, E, A, B, C, D, z + 4);
+  }
+  for (; z < z1; z += 5) {
+    step(std::false_type{}, A, B, C, D, E, z);
+    if (z + 1 < z1) step(std::false_type{}, B, C, D, E, A, z + 1);
+    if (z + 2 < z1) step(std::false_type{}, C, D, E, A, B, z + 2);
+    if (z + 3 < z1) step(std::false_type{}, D, E, A, B, C, z + 3);
+    if (z + 4 < z1) step(std::false_type{}, E, A, B, C, D, z + 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
+}
+
 // ---- variant 3, phi/ksi: same data movement as k_sweep3 (aligned 64-wide tiles, rows of the current plane through a
 // double-buffered LDS image, edge waves stream the y-halo rows, four rotating plane register sets); all eight inputs
 // are stencilled here (the central differences of A.3 do not factor), and there is nothing to pre-combine.
@@ -975,11 +1421,179 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi3(SolveArgs a, F3dGeo
   }
 }
 
+// ---- variant 6, phi/ksi: the load path of k_sweep6 (hand-issued global loads, one-instruction x-halo gather, LDS-DMA
+// halo rows, rows requested two steps ahead, next plane published right after the barrier) for the eight inputs of A.3.
+#define F3D_WAIT_PLANE8(N, P)                                                                                          \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
+               : "+v"((P).v[0]), "+v"((P).v[1]), "+v"((P).v[2]), "+v"((P).v[3]), "+v"((P).v[4]), "+v"((P).v[5]),       \
+                 "+v"((P).v[6]), "+v"((P).v[7])::"memory")
+
+__global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                             int xcd_remap)
+{
+  constexpr int NA = 8;
+  __shared__ float img[2][NA][kTY3 + 2][kLanes];
+  __shared__ float hrow[kRing][2][NA][kLanes];
+  __shared__ float hcol[kRing][kTY3][kLanes];
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int y0 = ty * kTY3;
+  const int y = y0 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = tx * kLanes + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool owner = x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;
+  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
+  const bool edge = (r == 0) || (r == kTY3 - 1);
+  const int which = r == 0 ? 0 : 1;
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
+
+  const int zb = z0 > 0 ? z0 - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const float* base[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) base[i] = a.in[i] + base_off;
+  float* obase[2] = {a.out[0] + base_off, a.out[1] + base_off};
+  const bool col_lane = (lane & 31) < NA;
+  const float* lane_base = base[0];
+#pragma unroll
+  for (int i = 1; i < NA; ++i)
+    if ((lane & 31) == i) lane_base = base[i];
+  lane_base += xh;
+
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](Plane8& p, int zz) {
+    const unsigned off = xb + rowoff(yy, zz);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) p.v[i] = gld(base[i], off);
+  };
+  auto dma_halos = [&](int zz) {
+    const int slot = zz & (kRing - 1);
+    if (col_lane) gld_lds_lane(lane_base + (rowoff(yy, zz) >> 2), &hcol[slot][r][0]);
+    if (edge) {
+      const unsigned off = xb + rowoff(yh_row, zz);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) gld_lds(base[i], off, &hrow[slot][which][i][0]);
+    }
+  };
+  auto publish = [&](const Plane8& pl, int nb, int ring_slot) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) img[nb][i][r + 1][lane] = pl.v[i];
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) img[nb][i][lds_halo][lane] = hrow[ring_slot][which][i][lane];
+    }
+  };
+
+  auto step = [&](auto full, const Plane8& M, const Plane8& C, const Plane8& P, Plane8& Q1, Plane8& Q2, int z) {
+    constexpr bool FULL = decltype(full)::value;
+    const bool row3 = FULL || z + 3 <= z1;
+    const bool halo3 = FULL || z + 3 < z1;
+    if (row3) load_plane(Q2, f3d_mir(z + 3, g.D));
+    if (halo3) dma_halos(z + 3);
+
+    const int b = z & 1;
+    const int slot = z & (kRing - 1);
+    __syncthreads();
+
+    Hood<8> n;
+    float xcol[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      n.c[i] = C.v[i];
+      n.ym[i] = img[b][i][r][lane];
+      n.yp[i] = img[b][i][r + 2][lane];
+      n.zm[i] = M.v[i];
+      n.zp[i] = P.v[i];
+      xcol[i] = hcol[slot][r][side * 32 + i];
+    }
+    if (FULL || z + 1 < z1) publish(P, b ^ 1, (z + 1) & (kRing - 1));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      n.xm[i] = lane_left_or(C.v[i], xcol[i]);
+      n.xp[i] = lane_right_or(C.v[i], xcol[i]);
+    }
+    float phi, ksi;
+    phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
+    asm volatile("" ::"v"(phi), "v"(ksi));
+    __builtin_amdgcn_sched_barrier(0);
+    if (FULL) {
+      if (edge) F3D_WAIT_PLANE8(17, Q1);  // 8 row loads + 1 column gather + 8 halo-row loads of this step stay in flight
+      else F3D_WAIT_PLANE8(9, Q1);
+    } else {
+      F3D_WAIT_PLANE8(0, Q1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (owner) {
+      const unsigned off = xb + rowoff(yy, z);
+      gst(obase[0], off, phi);
+      gst(obase[1], off, ksi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  Plane8 A, B, C, D, E;
+  D = Plane8{};
+  E = Plane8{};
+  load_plane(A, f3d_mir(z0 - 1, g.D));
+  load_plane(B, z0);
+  load_plane(C, f3d_mir(z0 + 1, g.D));
+  if (z0 + 2 <= z1) load_plane(D, f3d_mir(z0 + 2, g.D));
+  dma_halos(z0);
+  if (z0 + 1 < z1) dma_halos(z0 + 1);
+  if (z0 + 2 < z1) dma_halos(z0 + 2);
+  F3D_WAIT_PLANE8(0, A);
+  F3D_WAIT_PLANE8(0, B);
+  F3D_WAIT_PLANE8(0, C);
+  F3D_WAIT_PLANE8(0, D);
+  __syncthreads();
+  publish(B, z0 & 1, z0 & (kRing - 1));
+  __builtin_amdgcn_sched_barrier(0);
+  int z = z0;
+  for (; z + 7 < z1; z += 5) {
+    step(std::true_type{}, A, B, C, D, E, z);
+    step(std::true_type{}, B, C, D, E, A, z + 1);
+    step(std::true_type{}, C, D, E, A, B, z + 2);
+    step(std::true_type{}, D, E, A, B, C, z + 3);
+    step(std::true_type{}, E, A, B, C, D, z + 4);
+  }
+  for (; z < z1; z += 5) {
+    step(std::false_type{}, A, B, C, D, E, z);
+    if (z + 1 < z1) step(std::false_type{}, B, C, D, E, A, z + 1);
+    if (z + 2 < z1) step(std::false_type{}, C, D, E, A, B, z + 2);
+    if (z + 3 < z1) step(std::false_type{}, D, E, A, B, C, z + 3);
+    if (z + 4 < z1) step(std::false_type{}, E, A, B, C, D, z + 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 struct Tuning {
   int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds), 3 = k_sweep3 (sweep) + 2 (phi/ksi)
   int aligned;     // variant 3: 64-aligned x tiles with narrow x-halo loads instead of overlapping 62-wide tiles
   int cleanwait;   // variant 3: explicit end-of-step vmcnt(0)
-  int variant4;    // sweep: halo loads two planes ahead through LDS rings (k_sweep4)
+  int variant4;    // sweep: 1 = k_sweep4, 2 = k_sweep5, 3 = k_sweep6
+  int ty16;        // k_sweep6 with 16-row workgroups
   int xcd_remap;
   int zchunk;      // 0 = automatic
   long want_wg;
@@ -988,12 +1602,13 @@ struct Tuning {
 const Tuning& tuning()
 {
   static const Tuning t = [] {
-    Tuning v = {3, 1, 1, 1, 1, 0, 4096};
+    Tuning v = {3, 1, 1, 3, 0, 1, 0, 4096};
     if (const char* e = std::getenv("F3D_SOLVER_VARIANT")) v.variant = std::atoi(e);
     if (const char* e = std::getenv("F3D_XCD_REMAP")) v.xcd_remap = std::atoi(e);
     if (const char* e = std::getenv("F3D_ALIGNED")) v.aligned = std::atoi(e);
     if (const char* e = std::getenv("F3D_CLEANWAIT")) v.cleanwait = std::atoi(e);
     if (const char* e = std::getenv("F3D_SWEEP4")) v.variant4 = std::atoi(e);
+    if (const char* e = std::getenv("F3D_TY16")) v.ty16 = std::atoi(e);
     if (const char* e = std::getenv("F3D_ZCHUNK")) v.zchunk = std::atoi(e);
     if (const char* e = std::getenv("F3D_WANT_WG")) v.want_wg = std::atol(e);
     return v;
@@ -1018,7 +1633,8 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   }
   const bool v3 = t.variant == 3;
   const int ntx = (v3 && SWEEP && !t.aligned) ? (g.W + kOutX - 1) / kOutX : (g.W + kLanes - 1) / kLanes;
-  const int nty = v3 ? (g.H + kTY3 - 1) / kTY3 : (g.H + kOutRows - 1) / kOutRows;
+  const int rows_per_wg = (v3 && SWEEP && t.variant4 == 3 && t.ty16) ? 16 : kTY3;
+  const int nty = v3 ? (g.H + rows_per_wg - 1) / rows_per_wg : (g.H + kOutRows - 1) / kOutRows;
   long nzc = (t.want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
   const long max_chunks = planes / 4 > 0 ? planes / 4 : 1;
   if (nzc > max_chunks) nzc = max_chunks;
@@ -1033,7 +1649,16 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
     if (v3) {
       const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
       auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
-      if (t.variant4) {
+      if (t.variant4 == 3) {
+        static const int ablate = std::getenv("F3D_ABLATE") ? std::atoi(std::getenv("F3D_ABLATE")) : 0;
+        if (ablate == 1) go(k_sweep6<1, kTY3>);
+        else if (ablate == 2) go(k_sweep6<2, kTY3>);
+        else if (ablate == 3) go(k_sweep6<3, kTY3>);
+        else if (t.ty16) hipLaunchKernelGGL((k_sweep6<0, 16>), grid, dim3(kLanes, 16, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap);
+        else go(k_sweep6<0, kTY3>);
+      } else if (t.variant4 == 2) {
+        go(k_sweep5);
+      } else if (t.variant4) {
         go(k_sweep4);
       } else if (t.aligned) {
         if (t.cleanwait) go(k_sweep3<true, true>); else go(k_sweep3<true, false>);
@@ -1045,8 +1670,12 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   }
   if constexpr (!SWEEP) {
     if (v3) {
-      hipLaunchKernelGGL(k_phiksi3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
-                         n_tiles, t.xcd_remap);
+      if (t.variant4 == 3)
+        hipLaunchKernelGGL(k_phiksi6, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
+                           n_tiles, t.xcd_remap);
+      else
+        hipLaunchKernelGGL(k_phiksi3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
+                           n_tiles, t.xcd_remap);
       return;
     }
   }

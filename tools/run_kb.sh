@@ -1,8 +1,7 @@
-set -e
 mkdir -p gpurun_out
-for dims in "70 70 70" "128 128 128" "200 200 200" "256 256 256" "360 360 360"; do
-  for zc in 0 8 16 32 64; do
-    echo -n "dims=$dims zchunk=$zc : "
-    F3D_ZCHUNK=$zc python tools/kbench.py --dims $dims --reps 30 --kernel sweep | tail -1
-  done
-done 2>&1 | tee gpurun_out/kb7.log
+timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python tools/kbench.py --size 512 --reps 10 | tee gpurun_out/kb12.log
+F3D_SWEEP4=1 python tools/kbench.py --size 512 --reps 10 --kernel phi
+python tools/kbench.py --size 256 --reps 20
+python tools/kbench.py --dims 584 388 5 --reps 20
+python bench.py --steps 2 --warmup 1 --no-cpu 2>/dev/null | tee gpurun_out/b512_3.json
