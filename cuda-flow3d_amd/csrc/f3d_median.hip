@@ -45,30 +45,52 @@ __device__ __forceinline__ float rank_middle(float (&v)[N])
   return v[N / 2];
 }
 
+// LDS-staged variant: a workgroup of 64 x 4 lanes marches along z over a chunk of planes.  The (64 + 2h) x (4 + 2h)
+// mirrored footprint of every plane is fetched once into a ring of R planes in LDS (a few loads per lane and step);
+// the R^3 window of a voxel is then R^3 LDS reads instead of R^3 cached global loads with 64-bit address arithmetic.
 template <int R>
-__global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict__ in, float* __restrict__ out, F3dGeo g)
+__global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
+                                                        int zchunk)
 {
   constexpr int HALF = R / 2;
-  const int x = blockIdx.x * kBX + threadIdx.x;
-  const int y = blockIdx.y * kBY + threadIdx.y;
-  const int z = g.z_lo + blockIdx.z;
-  if (x >= g.W || y >= g.H) return;
-  int xs[R];
-  size_t rows[R][R];
+  constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
+  __shared__ float ring[R][TH][TW];
+  const int tid = threadIdx.y * kBX + threadIdx.x;
+  const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
+  const int x = x0 + threadIdx.x;
+  const int y = y0 + threadIdx.y;
+  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const bool owner = x < g.W && y < g.H;
+
+  // plane zz (any integer: mirrored) -> ring slot (zz mod R), cooperatively
+  auto fetch = [&](int zz) {
+    const int zm = f3d_clampi(f3d_mir(zz, g.D), 0, g.D - 1);
+    float(*dst)[TW] = ring[((zz % R) + R) % R];
+    for (int i = tid; i < TW * TH; i += kBX * kBY) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const int xs = f3d_clampi(f3d_mir(x0 + tx - HALF, g.W), 0, g.W - 1);
+      const int ys = f3d_clampi(f3d_mir(y0 + ty - HALF, g.H), 0, g.H - 1);
+      dst[ty][tx] = in[f3d_row(g, ys, zm) + xs];
+    }
+  };
+  for (int zz = z0 - HALF; zz < z0 + HALF; ++zz) fetch(zz);
+  for (int z = z0; z < z1; ++z) {
+    fetch(z + HALF);
+    __syncthreads();
+    float v[R * R * R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) xs[i] = f3d_mir(x + i - HALF, g.W);
+    for (int iz = 0; iz < R; ++iz) {
+      const float(*pl)[TW] = ring[(((z + iz - HALF) % R) + R) % R];
 #pragma unroll
-  for (int iz = 0; iz < R; ++iz)
+      for (int iy = 0; iy < R; ++iy)
 #pragma unroll
-    for (int iy = 0; iy < R; ++iy) rows[iz][iy] = f3d_row(g, f3d_mir(y + iy - HALF, g.H), f3d_mir(z + iz - HALF, g.D));
-  float v[R * R * R];
-#pragma unroll
-  for (int iz = 0; iz < R; ++iz)
-#pragma unroll
-    for (int iy = 0; iy < R; ++iy)
-#pragma unroll
-      for (int ix = 0; ix < R; ++ix) v[(iz * R + iy) * R + ix] = in[rows[iz][iy] + xs[ix]];
-  out[f3d_row(g, y, z) + x] = rank_middle<R * R * R>(v);
+        for (int ix = 0; ix < R; ++ix) v[(iz * R + iy) * R + ix] = pl[threadIdx.y + iy][threadIdx.x + ix];
+    }
+    const float med = rank_middle<R * R * R>(v);
+    if (owner) out[f3d_row(g, y, z) + x] = med;
+    __syncthreads();  // the slot of plane z - HALF is overwritten by the next fetch
+  }
 }
 
 __device__ __forceinline__ unsigned order_key(float f)
@@ -132,12 +154,24 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
     if (lo < g.z_base || hi - g.z_base > dc)
       return f3d::fail("f3d_median: planes [%d,%d) needed but the container holds [%d,%d)", lo, hi, g.z_base, g.z_base + dc);
   }
-  const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo), block(kBX, kBY, 1);
+  const dim3 block(kBX, kBY, 1);
   const float* in = f3d_ptr<const float>(input);
   float* out = f3d_ptr<float>(output);
-  if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g);
-  if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g);
-  if (radius == 7) hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), in, out, g);
+  if (radius == 7) {
+    const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo);
+    hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), in, out, g);
+  } else {
+    // z-chunks: enough workgroups to fill the chip, long enough to amortise the ring prologue
+    const int planes = g.z_hi - g.z_lo;
+    const long tiles = static_cast<long>((g.W + kBX - 1) / kBX) * ((g.H + kBY - 1) / kBY);
+    long nz = (8192 + tiles - 1) / tiles;
+    if (nz > planes) nz = planes;
+    if (nz < 1) nz = 1;
+    const int zchunk = static_cast<int>((planes + nz - 1) / nz);
+    const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
+    if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+  }
   F3D_HIP(hipGetLastError());
   return 0;
 }
