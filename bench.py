@@ -100,7 +100,7 @@ def run_single(args):
                                "frames resident in HBM", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
         "roofline": {
-            "bound": "hbm", "kernel": "k_sweep3 (solver sweep, f3d_solve_sweep)",
+            "bound": "hbm", "kernel": "k_sweep6 (solver sweep, f3d_solve_sweep)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None, "launches": sw_n, "avg_launch_us": round(sw_ms / sw_n * 1e3, 3) if sw_n else None,
             "avg_voxels_per_launch": round(sw_vox / sw_n, 1) if sw_n else None,
@@ -192,7 +192,7 @@ def run_multi(args):
                                    "frames resident in HBM",
                        "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
                                       "iteration (6 planes of du, dv, dw)"},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep3 (solver sweep) on rank 0's slab incl. widened windows",
+            "roofline": {"bound": "hbm", "kernel": "k_sweep6 (solver sweep) on rank 0's slab incl. widened windows",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": n.value},
         }

@@ -98,6 +98,8 @@ def hip():
         "f3d_pack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_unpack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_copy_planes": [_dp, C.c_int, _dp, C.c_int, C.c_int, _sz, _sz],
+        "f3d_pack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
+        "f3d_unpack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
         "f3d_comm_allreduce_max_f32": [_fp],
     }
@@ -300,6 +302,14 @@ class Containers:
 
 def sync():
     check(hip().f3d_stream_sync(), "f3d_stream_sync")
+
+
+def mem_info():
+    """(free, total) bytes of device memory."""
+    check(hip().f3d_init(-1), "f3d_init")
+    free, total = _sz(), _sz()
+    check(hip().f3d_mem_info(C.byref(free), C.byref(total)), "f3d_mem_info")
+    return free.value, total.value
 
 
 # ---- operator layer (CudaOperation* through the string-keyed bag) -------------------------------------------------

@@ -72,6 +72,33 @@ __global__ __launch_bounds__(256) void k_planes(float* __restrict__ field, float
   else field[c] = dense[d];
 }
 
+// One launch for a whole exchange: up to kMaxSeg (field, plane range) segments, each packed densely at its offset.
+constexpr int kMaxSeg = 32;
+struct SegTable {
+  float* field[kMaxSeg];
+  int plane0[kMaxSeg];
+  int count[kMaxSeg];
+  unsigned long long offset[kMaxSeg];  // floats into the dense buffer
+  int n;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_planes_batched(SegTable t, float* __restrict__ dense, int width, int height, int Hc,
+                                                        int pitch, int max_count)
+{
+  const int seg = blockIdx.z / max_count;
+  const int p = blockIdx.z - seg * max_count;
+  if (p >= t.count[seg]) return;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= width || y >= height) return;
+  float* field = t.field[seg];
+  const size_t c = (static_cast<size_t>(t.plane0[seg] + p) * Hc + y) * pitch + x;
+  const size_t d = t.offset[seg] + (static_cast<size_t>(p) * height + y) * width + x;
+  if (PACK) dense[d] = field[c];
+  else field[c] = dense[d];
+}
+
 __global__ __launch_bounds__(256) void k_copy_planes(float* __restrict__ dst, const float* __restrict__ src, int dst_plane0,
                                                      int src_plane0, int width, int height, int Hc, int pitch)
 {
@@ -177,6 +204,46 @@ int f3d_unpack_planes(f3d_devptr field, int plane0, int count, size_t width, siz
   return 0;
 }
 
+static int planes_batched(bool pack, const f3d_devptr* fields, const int* plane0, const int* count, const size_t* offset,
+                          int n_segments, size_t width, size_t height, f3d_devptr staging, const char* who)
+{
+  F3D_REQUIRE_READY(who);
+  if (n_segments < 0 || n_segments > kMaxSeg) return f3d::fail("%s: at most %d segments per call", who, kMaxSeg);
+  SegTable t;
+  t.n = n_segments;
+  int max_count = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (check_planes(plane0[i], count[i], width, height, who)) return 1;
+    t.field[i] = f3d_ptr<float>(fields[i]);
+    t.plane0[i] = plane0[i];
+    t.count[i] = count[i];
+    t.offset[i] = offset[i];
+    if (count[i] > max_count) max_count = count[i];
+  }
+  if (n_segments == 0 || max_count == 0) return 0;
+  const f3d_size4& c = f3d::container();
+  const dim3 grid((width + 63) / 64, (height + 3) / 4, n_segments * max_count), block(64, 4, 1);
+  float* dense = f3d_ptr<float>(staging);
+  const int w = static_cast<int>(width), h = static_cast<int>(height), hc = static_cast<int>(c.height),
+            pf = static_cast<int>(c.pitch / sizeof(float));
+  if (pack) hipLaunchKernelGGL(k_planes_batched<true>, grid, block, 0, f3d::stream(), t, dense, w, h, hc, pf, max_count);
+  else hipLaunchKernelGGL(k_planes_batched<false>, grid, block, 0, f3d::stream(), t, dense, w, h, hc, pf, max_count);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_pack_segments(const f3d_devptr* fields, const int* plane0, const int* count, const size_t* offset_floats,
+                      int n_segments, size_t width, size_t height, f3d_devptr staging)
+{
+  return planes_batched(true, fields, plane0, count, offset_floats, n_segments, width, height, staging, "f3d_pack_segments");
+}
+
+int f3d_unpack_segments(const f3d_devptr* fields, const int* plane0, const int* count, const size_t* offset_floats,
+                        int n_segments, size_t width, size_t height, f3d_devptr staging)
+{
+  return planes_batched(false, fields, plane0, count, offset_floats, n_segments, width, height, staging, "f3d_unpack_segments");
+}
+
 int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width, size_t height)
 {
   F3D_REQUIRE_READY("f3d_copy_planes");
@@ -200,7 +267,7 @@ int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size
   if (!R.comm) return f3d::fail("f3d_comm_sendrecv: f3d_comm_init() has not been called");
   F3D_NCCL(R.GroupStart());
   for (int i = 0; i < n_peers; ++i) {
-    if (peers[i] < 0 || peers[i] >= R.n_ranks || peers[i] == R.rank) {
+    if (peers[i] < 0 || peers[i] >= R.n_ranks) {  // the own rank is a legal peer: RCCL pairs the send with the recv locally
       (void)R.GroupEnd();
       return f3d::fail("f3d_comm_sendrecv: bad peer %d", peers[i]);
     }

@@ -119,22 +119,33 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
   const std::vector<HaloTransfer> plan = PlanHaloExchange(depth, me.rank, n_ranks_, need_lo, need_hi);
   std::vector<size_t> s_off, s_cnt, r_off, r_cnt;
   std::vector<int> peers;
+  // one pack launch, one grouped send/recv, one unpack launch per exchange
+  std::vector<f3d_devptr> pk_field, up_field;
+  std::vector<int> pk_plane, pk_count, up_plane, up_count;
+  std::vector<size_t> pk_off, up_off;
   size_t s_pos = 0, r_pos = 0;
   for (const HaloTransfer& t : plan) {
     peers.push_back(t.peer);
     s_off.push_back(s_pos);
     r_off.push_back(r_pos);
-    const size_t sc = static_cast<size_t>(t.send.size()) * plane * roles.size();
-    const size_t rc = static_cast<size_t>(t.recv.size()) * plane * roles.size();
-    s_cnt.push_back(sc);
-    r_cnt.push_back(rc);
-    size_t at = s_pos;
     for (Role role : roles) {
-      if (!Check(f3d_pack_planes(me.buf[role], t.send.lo - my_base, t.send.size(), width, height, stage_send_, at))) return false;
-      at += static_cast<size_t>(t.send.size()) * plane;
+      if (!t.send.empty()) {
+        pk_field.push_back(me.buf[role]);
+        pk_plane.push_back(t.send.lo - my_base);
+        pk_count.push_back(t.send.size());
+        pk_off.push_back(s_pos);
+        s_pos += static_cast<size_t>(t.send.size()) * plane;
+      }
+      if (!t.recv.empty()) {
+        up_field.push_back(me.buf[role]);
+        up_plane.push_back(t.recv.lo - my_base);
+        up_count.push_back(t.recv.size());
+        up_off.push_back(r_pos);
+        r_pos += static_cast<size_t>(t.recv.size()) * plane;
+      }
     }
-    s_pos += sc;
-    r_pos += rc;
+    s_cnt.push_back(s_pos - s_off.back());
+    r_cnt.push_back(r_pos - r_off.back());
   }
   if (s_pos > stage_floats_ || r_pos > stage_floats_) {
     std::printf("'%s': staging buffer too small for this exchange.\n", GetName());
@@ -142,16 +153,17 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
     return false;
   }
   if (peers.empty()) return true;
+  constexpr size_t kBatch = 32;  // segments per launch (f3d_pack_segments limit)
+  for (size_t i = 0; i < pk_field.size(); i += kBatch) {
+    const int n = static_cast<int>(std::min(kBatch, pk_field.size() - i));
+    if (!Check(f3d_pack_segments(&pk_field[i], &pk_plane[i], &pk_count[i], &pk_off[i], n, width, height, stage_send_))) return false;
+  }
   if (!Check(f3d_comm_sendrecv(stage_send_, s_off.data(), s_cnt.data(), stage_recv_, r_off.data(), r_cnt.data(), peers.data(),
                                static_cast<int>(peers.size()))))
     return false;
-  for (size_t i = 0; i < plan.size(); ++i) {
-    size_t at = r_off[i];
-    for (Role role : roles) {
-      if (!Check(f3d_unpack_planes(me.buf[role], plan[i].recv.lo - my_base, plan[i].recv.size(), width, height, stage_recv_, at)))
-        return false;
-      at += static_cast<size_t>(plan[i].recv.size()) * plane;
-    }
+  for (size_t i = 0; i < up_field.size(); i += kBatch) {
+    const int n = static_cast<int>(std::min(kBatch, up_field.size() - i));
+    if (!Check(f3d_unpack_segments(&up_field[i], &up_plane[i], &up_count[i], &up_off[i], n, width, height, stage_recv_))) return false;
   }
   return true;
 }

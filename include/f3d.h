@@ -163,6 +163,12 @@ int f3d_pack_planes(f3d_devptr field, int plane0, int count, size_t width, size_
                     size_t offset_floats);
 int f3d_unpack_planes(f3d_devptr field, int plane0, int count, size_t width, size_t height, f3d_devptr staging,
                       size_t offset_floats);
+/* the same for up to 32 (field, plane range) segments in ONE launch: segment i covers count[i] planes of fields[i]
+ * from container plane plane0[i] and sits at staging[offset_floats[i] ...] */
+int f3d_pack_segments(const f3d_devptr* fields, const int* plane0, const int* count, const size_t* offset_floats,
+                      int n_segments, size_t width, size_t height, f3d_devptr staging);
+int f3d_unpack_segments(const f3d_devptr* fields, const int* plane0, const int* count, const size_t* offset_floats,
+                        int n_segments, size_t width, size_t height, f3d_devptr staging);
 /* same-device plane copy between two containers (one-GPU rehearsal of the slab decomposition) */
 int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width,
                     size_t height);

@@ -65,3 +65,56 @@ def test_single_rank_rccl_init_and_allreduce(f3d):
     f3d.check(f3d.hip().f3d_comm_allreduce_max_f32(C.byref(v)))
     assert v.value == 3.5
     f3d.comm_destroy()
+
+
+def test_exchange_legs_pack_rccl_self_unpack(f3d):
+    """The three legs of one halo exchange as the slab driver issues them (optical_flow_slab.cpp, Exchange): ONE pack
+    launch over several (field, plane range) segments, a grouped ncclSend/ncclRecv -- here to the rank itself, which is
+    all one GPU offers -- and ONE unpack launch; the planes must arrive bit for bit where the segment table says."""
+    import ctypes as C
+    W, H, D = 70, 13, 9
+    rng = np.random.default_rng(7)
+    vols = [rng.standard_normal((D, H, W)).astype(np.float32) for _ in range(3)]
+    box = f3d.Containers(W, H, D)
+    src = [box.alloc() for _ in range(3)]
+    dst = [box.alloc(fill=0xFF) for _ in range(3)]
+    box.set_current()
+    for p, v in zip(src, vols):
+        box.upload(p, v)
+    segs = [(0, 1, 3), (1, 0, 2), (2, 6, 3), (0, 7, 1)]           # (field, first plane, planes)
+    shift = [4, 5, 0, 2]                                         # destination first plane per segment
+    plane = W * H
+    total = sum(s[2] for s in segs) * plane
+    stage_s, stage_r, pitch = C.c_uint64(), C.c_uint64(), C.c_size_t()
+    hip = f3d.hip()
+    f3d.check(hip.f3d_alloc_pitched(C.byref(stage_s), C.byref(pitch), total * 4, 1))
+    f3d.check(hip.f3d_alloc_pitched(C.byref(stage_r), C.byref(pitch), total * 4, 1))
+    n = len(segs)
+    dp, ci, sz = C.c_uint64 * n, C.c_int * n, C.c_size_t * n
+    offs, pos = [], 0
+    for s in segs:
+        offs.append(pos)
+        pos += s[2] * plane
+    f3d.comm_init(f3d.comm_unique_id(), 0, 1)
+    try:
+        f3d.check(hip.f3d_pack_segments(dp(*[src[s[0]] for s in segs]), ci(*[s[1] for s in segs]), ci(*[s[2] for s in segs]),
+                                        sz(*offs), n, W, H, stage_s.value))
+        one = C.c_size_t * 1
+        f3d.check(hip.f3d_comm_sendrecv(stage_s.value, one(0), one(total), stage_r.value, one(0), one(total),
+                                        (C.c_int * 1)(0), 1))
+        f3d.check(hip.f3d_unpack_segments(dp(*[dst[s[0]] for s in segs]), ci(*shift), ci(*[s[2] for s in segs]),
+                                          sz(*offs), n, W, H, stage_r.value))
+        f3d.sync()
+    finally:
+        f3d.comm_destroy()
+    got = [box.download(p, (W, H, D)) for p in dst]
+    exp = [np.full((D, H, W), np.nan, np.float32) for _ in range(3)]
+    for (f, p0, cnt), d0 in zip(segs, shift):
+        exp[f][d0:d0 + cnt] = vols[f][p0:p0 + cnt]
+    for g, e in zip(got, exp):
+        filled = ~np.isnan(e)
+        assert np.array_equal(g[filled], e[filled])
+        assert np.isnan(g[~filled]).all(), "unpack wrote outside its segments"
+    for p in (stage_s.value, stage_r.value):
+        f3d.check(hip.f3d_free(p))
+    box.free()

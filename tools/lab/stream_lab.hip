@@ -4,6 +4,7 @@
 //  D: C + the y-neighbour row loads of 9 arrays (28 loads), like k_solver v1
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -70,15 +71,19 @@ __global__ __launch_bounds__(64 * TY) void k_march(Args a, int W, int H, int D, 
   }
 }
 
-int main()
+int main(int argc, char** argv)
 {
+  const size_t skew = argc > 1 ? strtoull(argv[1], nullptr, 0) : 0;  // bytes between the bases of successive arrays (mod the array size)
+  const int nstream = argc > 2 ? atoi(argv[2]) : 0;
+  printf("skew %zu bytes\n", skew);
   const int W = 512, H = 512, D = 512, pitch = 512;
   const size_t n = size_t(W) * H * D;
   Args a;
   std::vector<float> host(n);
   for (size_t i = 0; i < n; ++i) host[i] = float(i % 977) * 1e-3f;
-  for (int i = 0; i < 10; ++i) { float* p; CK(hipMalloc(&p, n * 4 + 256)); CK(hipMemcpy(p, host.data(), n * 4, hipMemcpyHostToDevice)); a.in[i] = p; }
-  for (int i = 0; i < 3; ++i) { float* p; CK(hipMalloc(&p, n * 4 + 256)); a.out[i] = p; }
+  for (int i = 0; i < 10; ++i) { char* p; CK(hipMalloc(&p, n * 4 + 16 * skew + 256)); p += i * skew; CK(hipMemcpy(p, host.data(), n * 4, hipMemcpyHostToDevice)); a.in[i] = (float*)p; }
+  for (int i = 0; i < 3; ++i) { char* p; CK(hipMalloc(&p, n * 4 + 16 * skew + 256)); p += (10 + i) * skew; a.out[i] = (float*)p; }
+  (void)nstream;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto time = [&](const char* name, auto launch) {
     launch(); CK(hipDeviceSynchronize());
