@@ -33,6 +33,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def measured_traffic(kernel):
+    """HBM bytes per 512^3 launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs, tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  bench.py cannot collect counters itself; the numbers are read from profiles/*_pmc_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1])).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    return {"traffic": rec["hbm_bytes_per_launch"],
+            "traffic_scope": f"one 512^3 launch of {kernel}; algorithmic bytes of that launch: {rec['algorithmic_bytes_per_launch']}; "
+                             f"source {os.path.basename(files[-1])}"}
+
+
 def cpu_baseline(size):
     """Oracle (CPU port of the same numerics) on a size^3 pair of the same synthetic family, all host cores."""
     import numpy as np  # noqa: F401
@@ -80,15 +99,27 @@ def run_single(args):
         pkg.check(hip.f3d_prof_read(kernel, min_vox, C.byref(ms), C.byref(n), C.byref(vox)))
         return ms.value, n.value, vox.value
 
-    sw_ms, sw_n, sw_vox = prof(1, 0)
-    fin_ms, fin_n, fin_vox = prof(1, S ** 3)
+    s1_ms, s1_n, s1_vox = prof(1, 0)          # single sweeps (the odd fifth of every outer iteration)
+    s2_ms, s2_n, s2_vox = prof(2, 0)          # fused pairs: two sweeps of algorithmic work per launch
+    f2_ms, f2_n, f2_vox = prof(2, S ** 3)
+    f1_ms, f1_n, f1_vox = prof(1, S ** 3)
     pk_ms, pk_n, pk_vox = prof(0, 0)
     hip.f3d_prof_reset()
     flow.destroy()
 
-    achieved = SWEEP_BYTES_PER_VOXEL * sw_vox / (sw_ms * 1e-3) / 1e9 if sw_ms else 0.0
-    finest = SWEEP_BYTES_PER_VOXEL * fin_vox / (fin_ms * 1e-3) / 1e9 if fin_ms else 0.0
-    phi_gbs = PHI_KSI_BYTES_PER_VOXEL * pk_vox / (pk_ms * 1e-3) / 1e9 if pk_ms else 0.0
+    def gbs(bytes_per_voxel, vox, ms):
+        return bytes_per_voxel * vox / (ms * 1e-3) / 1e9 if ms else 0.0
+
+    fused = s2_n > 0
+    if fused:   # dominant kernel: k_sweep7
+        dom_name, dom_b, dom_ms, dom_n, dom_vox = "k_sweep7 (two fused solver sweeps, f3d_solve_sweep2)", 2 * SWEEP_BYTES_PER_VOXEL, s2_ms, s2_n, s2_vox
+        fin_ms, fin_n, fin_vox = f2_ms, f2_n, f2_vox
+    else:
+        dom_name, dom_b, dom_ms, dom_n, dom_vox = "k_sweep6 (solver sweep, f3d_solve_sweep)", SWEEP_BYTES_PER_VOXEL, s1_ms, s1_n, s1_vox
+        fin_ms, fin_n, fin_vox = f1_ms, f1_n, f1_vox
+    achieved = gbs(dom_b, dom_vox, dom_ms)
+    finest = gbs(dom_b, fin_vox, fin_ms)
+    all_sweeps = gbs(SWEEP_BYTES_PER_VOXEL, s1_vox + 2 * s2_vox, s1_ms + s2_ms)
     ms_per_step = wall / args.steps * 1e3
     out = {
         "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
@@ -100,15 +131,24 @@ def run_single(args):
                                "frames resident in HBM", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
         "roofline": {
-            "bound": "hbm", "kernel": "k_sweep6 (solver sweep, f3d_solve_sweep)",
+            "bound": "hbm", "kernel": dom_name,
+            "algorithmic_bytes_per_voxel_per_launch": dom_b,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches": sw_n, "avg_launch_us": round(sw_ms / sw_n * 1e3, 3) if sw_n else None,
-            "avg_voxels_per_launch": round(sw_vox / sw_n, 1) if sw_n else None,
+            "traffic": None, "launches": dom_n, "avg_launch_us": round(dom_ms / dom_n * 1e3, 3) if dom_n else None,
+            "avg_voxels_per_launch": round(dom_vox / dom_n, 1) if dom_n else None,
             "finest_level": {"achieved": round(finest, 1), "frac": round(finest / HBM_PEAK_GBS, 4), "launches": fin_n,
                              "avg_launch_us": round(fin_ms / fin_n * 1e3, 3) if fin_n else None},
-            "phi_ksi": {"achieved": round(phi_gbs, 1), "frac": round(phi_gbs / HBM_PEAK_GBS, 4), "launches": pk_n},
+            "all_sweeps": {"achieved": round(all_sweeps, 1), "frac": round(all_sweeps / HBM_PEAK_GBS, 4),
+                           "note": "52 B per voxel-sweep over every sweep launch, fused or single"},
+            "single_sweep": {"kernel": "k_sweep6", "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL, s1_vox, s1_ms), 1),
+                             "launches": s1_n},
+            "phi_ksi": {"kernel": "k_phiksi6", "achieved": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms), 1),
+                        "frac": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms) / HBM_PEAK_GBS, 4), "launches": pk_n},
         },
     }
+    traffic = measured_traffic(dom_name.split()[0])
+    if traffic:
+        out["roofline"].update(traffic)
     if not args.no_cpu:
         log("[bench] timing the CPU baseline (oracle) ...")
         out["cpu_baseline"] = cpu_baseline(args.cpu_size)
@@ -176,9 +216,14 @@ def run_multi(args):
     dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     wall = tw.item()
 
-    ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
-    pkg.check(hip.f3d_prof_read(1, 0, C.byref(ms), C.byref(n), C.byref(vox)))
-    achieved = SWEEP_BYTES_PER_VOXEL * vox.value / (ms.value * 1e-3) / 1e9 if ms.value else 0.0
+    tot_ms, tot_bytes, launches = 0.0, 0.0, 0
+    for kid, bpv in ((1, SWEEP_BYTES_PER_VOXEL), (2, 2 * SWEEP_BYTES_PER_VOXEL)):
+        ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
+        pkg.check(hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox)))
+        tot_ms += ms.value
+        tot_bytes += bpv * vox.value
+        launches += n.value
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
     flow.destroy()
     pkg.comm_destroy()
     if rank == 0:
@@ -192,9 +237,10 @@ def run_multi(args):
                                    "frames resident in HBM",
                        "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
                                       "iteration (6 planes of du, dv, dw)"},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep6 (solver sweep) on rank 0's slab incl. widened windows",
+            "roofline": {"bound": "hbm", "kernel": "k_sweep7 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
+                                                   "slab incl. widened windows",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": n.value},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches},
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

@@ -30,9 +30,9 @@ struct Prof {
   bool enabled = false;
   std::vector<ProfRec> pending;
   std::vector<hipEvent_t> pool;
-  double ms[F3D_K_COUNT][2] = {{0, 0}, {0, 0}};  // [kernel][0 = all, 1 = filtered] is rebuilt on read
-  hipEvent_t open_start[F3D_K_COUNT] = {nullptr, nullptr};
-  size_t open_voxels[F3D_K_COUNT] = {0, 0};
+  double ms[F3D_K_COUNT][2] = {};  // [kernel][0 = all, 1 = filtered] is rebuilt on read
+  hipEvent_t open_start[F3D_K_COUNT] = {};
+  size_t open_voxels[F3D_K_COUNT] = {};
 } P;
 
 hipEvent_t take_event()

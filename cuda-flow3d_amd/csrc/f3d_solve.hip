@@ -1588,6 +1588,413 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- variant 7: TWO sweeps in one launch (temporal blocking) ---------------------------------------------------------
+// A sweep streams 52 B per voxel for ~150 flops, and the 13-stream ceiling of the memory system (tools/lab/stream_lab)
+// is ~5.0-5.6 TB/s, so a one-sweep kernel cannot pass ~65 % of the 8 TB/s peak.  Two consecutive sweeps read the same
+// f0, f1, u, v, w, phi, ksi; only du, dv, dw change in between.  This kernel keeps the intermediate field on chip:
+//
+//   * the workgroup owns TY core rows of an aligned 64-column tile and marches along z as k_sweep6 does, but with
+//     TY + 2 row waves (rows y0-1 .. y0+TY): every row wave computes sweep 1 ("stage 1") of its row for plane q; the TY
+//     core waves then compute sweep 2 ("stage 2") for plane q-1 from the stage-1 results of planes q-2, q-1 (kept in
+//     registers), q (just computed), of the rows above and below (LDS image img1) and of the lanes left and right (DPP);
+//   * one more wave, the column wave, computes stage 1 for the 2 x TY voxels just left and right of the tile (columns
+//     x0-1 and x0+64), which the tile's edge lanes need in stage 2.  It works from LDS only: the row waves gather TWO
+//     columns on each side (and ksi) with their one x-halo instruction, and those raw values are all it needs;
+//   * stage 2 reuses everything of stage 1 that does not depend on du, dv, dw (the J terms, the six face weights, the three
+//     denominators), carried in registers from one z step to the next;
+//   * at the faces of the volume the reference's mirror rule makes the missing neighbour equal the opposite one
+//     (index -1 -> 1, n -> n-2), so stage 2 substitutes xm := xp etc. there and never looks at stage-1 values of
+//     voxels outside the volume (which the halo waves compute from mirrored data, i.e. with the operands in another
+//     order).
+// HBM traffic for two sweeps: 10 reads + 3 writes per voxel instead of 20 + 6.
+struct Carry {
+  float J12, J13, J23, J14, J24, J34, d1, d2, d3, ksi, pw[6], U, V, W;
+};
+struct S3 {
+  float u, v, w;
+};
+
+// sweep_voxel_s, additionally handing out what stage 2 of the same voxel reuses (same operations, same order)
+__device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, const Face6& ym, const Face6& yp,
+                                             const Face6& zm, const Face6& zp, const float (&c)[kNL], float Uc, float Vc,
+                                             float Wc, float dVc, float dWc, float ksi, float hx, float hy, float hz,
+                                             float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym, bool has_zp,
+                                             bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k)
+{
+  const float fx = (xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1]) / (4.f * hx);
+  const float fy = (yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1]) / (4.f * hy);
+  const float fz = (zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]) / (4.f * hz);
+  const float ft = c[LF1] - c[LF0];
+
+  const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
+  k.J12 = fx * fy; k.J13 = fx * fz; k.J23 = fy * fz;
+  k.J14 = fx * ft; k.J24 = fy * ft; k.J34 = fz * ft;
+
+  const float hx_2 = alpha / (hx * hx);
+  const float hy_2 = alpha / (hy * hy);
+  const float hz_2 = alpha / (hz * hz);
+  const float wxp = static_cast<float>(has_xp) * hx_2;
+  const float wxm = static_cast<float>(has_xm) * hx_2;
+  const float wyp = static_cast<float>(has_yp) * hy_2;
+  const float wym = static_cast<float>(has_ym) * hy_2;
+  const float wzp = static_cast<float>(has_zp) * hz_2;
+  const float wzm = static_cast<float>(has_zm) * hz_2;
+
+  // phi_f * w_f: the product the reference forms first in every term of sumU/V/W and (commuted) in sumH
+  k.pw[0] = (xp.v[LPHI] + c[LPHI]) / 2.f * wxp;
+  k.pw[1] = (xm.v[LPHI] + c[LPHI]) / 2.f * wxm;
+  k.pw[2] = (yp.v[LPHI] + c[LPHI]) / 2.f * wyp;
+  k.pw[3] = (ym.v[LPHI] + c[LPHI]) / 2.f * wym;
+  k.pw[4] = (zp.v[LPHI] + c[LPHI]) / 2.f * wzp;
+  k.pw[5] = (zm.v[LPHI] + c[LPHI]) / 2.f * wzm;
+  const float sumH = (k.pw[0] + k.pw[1] + k.pw[2] + k.pw[3] + k.pw[4] + k.pw[5]);
+  const float sumU = k.pw[0] * (xp.v[LSU] - Uc) + k.pw[1] * (xm.v[LSU] - Uc) + k.pw[2] * (yp.v[LSU] - Uc) +
+                     k.pw[3] * (ym.v[LSU] - Uc) + k.pw[4] * (zp.v[LSU] - Uc) + k.pw[5] * (zm.v[LSU] - Uc);
+  const float sumV = k.pw[0] * (xp.v[LSV] - Vc) + k.pw[1] * (xm.v[LSV] - Vc) + k.pw[2] * (yp.v[LSV] - Vc) +
+                     k.pw[3] * (ym.v[LSV] - Vc) + k.pw[4] * (zp.v[LSV] - Vc) + k.pw[5] * (zm.v[LSV] - Vc);
+  const float sumW = k.pw[0] * (xp.v[LSW] - Wc) + k.pw[1] * (xm.v[LSW] - Wc) + k.pw[2] * (yp.v[LSW] - Wc) +
+                     k.pw[3] * (ym.v[LSW] - Wc) + k.pw[4] * (zp.v[LSW] - Wc) + k.pw[5] * (zm.v[LSW] - Wc);
+  k.d1 = ksi * J11 + sumH;
+  k.d2 = ksi * J22 + sumH;
+  k.d3 = ksi * J33 + sumH;
+  k.ksi = ksi;
+  k.U = Uc; k.V = Vc; k.W = Wc;
+  r_du = (ksi * (-k.J14 - k.J12 * dVc - k.J13 * dWc) + sumU) / k.d1;
+  r_dv = (ksi * (-k.J24 - k.J12 * r_du - k.J23 * dWc) + sumV) / k.d2;
+  r_dw = (ksi * (-k.J34 - k.J13 * r_du - k.J23 * r_dv) + sumW) / k.d3;
+}
+
+// the second sweep of a voxel: neighbours' S = U + dU after sweep 1, own dv, dw after sweep 1
+__device__ __forceinline__ void sweep_stage2(const Carry& k, const S3& xm, const S3& xp, const S3& ym, const S3& yp,
+                                             const S3& zm, const S3& zp, float dVc, float dWc, float& r_du, float& r_dv,
+                                             float& r_dw)
+{
+  const float sumU = k.pw[0] * (xp.u - k.U) + k.pw[1] * (xm.u - k.U) + k.pw[2] * (yp.u - k.U) + k.pw[3] * (ym.u - k.U) +
+                     k.pw[4] * (zp.u - k.U) + k.pw[5] * (zm.u - k.U);
+  const float sumV = k.pw[0] * (xp.v - k.V) + k.pw[1] * (xm.v - k.V) + k.pw[2] * (yp.v - k.V) + k.pw[3] * (ym.v - k.V) +
+                     k.pw[4] * (zp.v - k.V) + k.pw[5] * (zm.v - k.V);
+  const float sumW = k.pw[0] * (xp.w - k.W) + k.pw[1] * (xm.w - k.W) + k.pw[2] * (yp.w - k.W) + k.pw[3] * (ym.w - k.W) +
+                     k.pw[4] * (zp.w - k.W) + k.pw[5] * (zm.w - k.W);
+  r_du = (k.ksi * (-k.J14 - k.J12 * dVc - k.J13 * dWc) + sumU) / k.d1;
+  r_dv = (k.ksi * (-k.J24 - k.J12 * r_du - k.J23 * dWc) + sumV) / k.d2;
+  r_dw = (k.ksi * (-k.J34 - k.J13 * r_du - k.J23 * r_dv) + sumW) / k.d3;
+}
+
+// ABL (timing experiments only, wrong results): bit 0 = no stage-1 arithmetic, bit 1 = no stage-2 arithmetic,
+// bit 2 = no global loads after the prologue
+template <int TY, int ABL = 0>
+__global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                             int xcd_remap)
+{
+  constexpr int NR = TY + 2;  // row waves: rows y0-1 .. y0+TY
+  constexpr int kR7 = 8;      // ring depth of the DMA-fed halo buffers: a slot is rewritten 8 steps after it was read
+  static_assert(TY <= 32, "the column wave holds one halo voxel per lane: 2 x TY <= 64");
+  __shared__ float img0[2][kNL][NR + 2][kLanes];  // faces of a plane before sweep 1; rows 0 and NR+1: halo rows y0-2, y0+TY+1
+  __shared__ float img1[2][3][NR][kLanes];        // S = U + dU after sweep 1, rows of the row waves
+  __shared__ float hrow[kR7][2][9][kLanes];       // raw halo rows of the edge waves, by LDS-DMA
+  __shared__ float hcol[kR7][NR][kLanes];         // raw x-halo of a row: [side*32 + near*16 + array], near = adjacent column
+  __shared__ float hc1[2][3][2][32];              // S after sweep 1 in the two halo columns: [component][side][core row]
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const bool colw = r == NR;
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int qs = z0 > 0 ? z0 - 1 : 0;        // first and last plane of stage 1
+  const int qe = z1 < g.D ? z1 : g.D - 1;
+  const int q_end = z1 < g.D ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
+  const int x0 = tx * kLanes;
+  const int y0 = ty * TY;
+
+  // row waves
+  const int y = y0 - 1 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = x0 + lane;
+  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
+  const unsigned xb = static_cast<unsigned>(xi) * 4u;
+  const bool core = r >= 1 && r <= TY;
+  const bool owner = core && x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;
+  const bool edge = (r == 0) || (r == NR - 1);
+  const int which = r == 0 ? 0 : 1;
+  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 2 : y0 + TY + 1, g.H), 0, g.H - 1);
+  const int lds_halo = r == 0 ? 0 : NR + 1;
+  // column wave: lane = side * 32 + core row (lanes beyond TY rows repeat the last row and publish nothing)
+  const bool cactive = (lane & 31) < TY;
+  const int crow = cactive ? (lane & 31) : TY - 1;
+  const int cy = y0 + crow;
+  const int cx = side == 0 ? x0 - 1 : x0 + kLanes;
+
+  const int zb = qs > 0 ? qs - 1 : 0;
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  constexpr int kOrder[10] = {F0, F1, U, V, Wf, DU, DV, DW, PHI, 9};  // order inside the halo rings
+  const float* base[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) base[i] = a.in[i] + base_off;
+  float* obase[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) obase[i] = a.out[i] + base_off;
+  // x-halo gather: lane = side*32 + near*16 + array reads one value; columns x0-2, x0-1 | x0+64, x0+65
+  const int garr = lane & 15;
+  const int near = (lane >> 4) & 1;
+  const bool col_lane = garr < 10;
+  const float* lane_base = base[0];
+#pragma unroll
+  for (int i = 1; i < 10; ++i)
+    if (garr == i) lane_base = base[kOrder[i]];
+  lane_base += f3d_clampi(f3d_mir(side == 0 ? x0 - 2 + near : x0 + kLanes + 1 - near, g.W), 0, g.W - 1);
+
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+  auto load_plane = [&](PlaneRegs& p, int zz) {
+    const unsigned off = xb + rowoff(yy, zz);
+    p.f0 = gld(base[F0], off);
+    p.f1 = gld(base[F1], off);
+    p.u = gld(base[U], off);
+    p.v = gld(base[V], off);
+    p.w = gld(base[Wf], off);
+    p.su = gld(base[DU], off);
+    p.dv = gld(base[DV], off);
+    p.dw = gld(base[DW], off);
+    p.phi = gld(base[PHI], off);
+    p.ksi = gld(base[9], off);
+  };
+  auto dma_halos = [&](int q) {  // plane q (mirrored for the address), ring slot q mod 8
+    const int slot = q & (kR7 - 1);
+    const int zz = f3d_mir(q, g.D);
+    if (col_lane) gld_lds_lane(lane_base + (rowoff(yy, zz) >> 2), &hcol[slot][r][0]);
+    if (edge) {
+      const unsigned off = xb + rowoff(yh_row, zz);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gld_lds(base[kOrder[i]], off, &hrow[slot][which][i][0]);
+    }
+  };
+  auto from9 = [&](PlaneRegs& p, const float* d, int stride) {
+    p.f0 = d[0 * stride]; p.f1 = d[1 * stride]; p.u = d[2 * stride]; p.v = d[3 * stride]; p.w = d[4 * stride];
+    p.su = d[5 * stride]; p.dv = d[6 * stride]; p.dw = d[7 * stride]; p.phi = d[8 * stride];
+  };
+  // column wave: raw values of its voxel's column (near = 1) or of the column beyond (near = 0), row wave rw, plane q
+  auto col_raw = [&](PlaneRegs& p, int q, int rw, int nr) {
+    const float* d = &hcol[q & (kR7 - 1)][rw][side * 32 + nr * 16];
+    from9(p, d, 1);
+    p.ksi = d[9];
+  };
+  auto publish = [&](const PlaneRegs& pl, int q) {  // faces of plane q before sweep 1 -> img0[q & 1]
+    const int nb = q & 1;
+    const Face6 f = plane_face(pl);
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) img0[nb][i][r + 1][lane] = f.v[i];
+    if (edge) {
+      PlaneRegs Hc;
+      from9(Hc, &hrow[q & (kR7 - 1)][which][0][lane], kLanes);
+      plane_finish(Hc);
+      const Face6 hf = plane_face(Hc);
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) img0[nb][i][lds_halo][lane] = hf.v[i];
+    }
+  };
+
+  S3 hM = {0.f, 0.f, 0.f}, hC = {0.f, 0.f, 0.f};  // S after sweep 1 of planes q-2 and q-1
+  float hC_dv = 0.f, hC_dw = 0.f;
+  Carry kC = {};
+
+  // M, C, P: finished planes q-1, q, q+1 (the column wave fills P at the start of the step).  Q1: raw plane q+2,
+  // requested one step ago.  Q2: receives plane q+3.
+  auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int q) {
+    const bool more = q + 3 <= qe + 1;  // plane q+3 is still somebody's z-neighbour
+    if (!colw && more && !(ABL & 4)) {
+      load_plane(Q2, f3d_mir(q + 3, g.D));
+      dma_halos(q + 3);
+    }
+    __syncthreads();  // img0 of plane q, img1 / hc1 of plane q-1 and the DMA rings up to plane q+1 are complete
+    const bool do1 = q <= qe;
+    const int b = q & 1;
+
+    float r_du = 0.f, r_dv = 0.f, r_dw = 0.f;
+    Carry kN = kC;
+    if (do1) {
+      Face6 ym, yp, xm, xp;
+      const Face6 cf = plane_face(C);
+      int vx, vy;
+      if (colw) {
+        col_raw(P, q + 1, crow + 1, 1);
+        plane_finish(P);
+        PlaneRegs T;
+        col_raw(T, q, crow, 1);
+        plane_finish(T);
+        ym = plane_face(T);
+        col_raw(T, q, crow + 2, 1);
+        plane_finish(T);
+        yp = plane_face(T);
+        col_raw(T, q, crow + 1, 0);
+        plane_finish(T);
+        const Face6 outer = plane_face(T);
+        Face6 inner;
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) inner.v[i] = img0[b][i][crow + 2][side ? kLanes - 1 : 0];
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) {
+          xm.v[i] = side ? inner.v[i] : outer.v[i];
+          xp.v[i] = side ? outer.v[i] : inner.v[i];
+        }
+        vx = cx;
+        vy = cy;
+      } else {
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) {
+          ym.v[i] = img0[b][i][r][lane];
+          yp.v[i] = img0[b][i][r + 2][lane];
+        }
+        PlaneRegs X;
+        from9(X, &hcol[q & (kR7 - 1)][r][side * 32 + 16], 1);
+        if (q + 1 <= qe) publish(P, q + 1);
+        plane_finish(X);
+        const Face6 xf = plane_face(X);
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) {
+          xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+          xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+        }
+        vx = x;
+        vy = y;
+      }
+      if (ABL & 1) {
+        r_du = xm.v[0] + xp.v[1] + ym.v[2] + yp.v[3] + M.su + P.sv + C.ksi;
+        r_dv = xm.v[4] + xp.v[5] + ym.v[0] + yp.v[1] + M.f0 + P.f1 + C.u;
+        r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
+        kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
+      } else
+      sweep_stage1(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                   a.p0, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
+    }
+    const S3 sN = {C.u + r_du, C.v + r_dv, C.w + r_dw};  // what a neighbour reads after sweep 1: U + dU'
+    if (do1) {
+      if (colw) {
+        if (cactive) {
+          hc1[b][0][side][crow] = sN.u;
+          hc1[b][1][side][crow] = sN.v;
+          hc1[b][2][side][crow] = sN.w;
+        }
+      } else {
+        img1[b][0][r][lane] = sN.u;
+        img1[b][1][r][lane] = sN.v;
+        img1[b][2][r][lane] = sN.w;
+      }
+    }
+
+    // stage 2 of plane t = q - 1
+    const int t = q - 1;
+    const bool do2 = core && t >= z0;
+    float o_du = 0.f, o_dv = 0.f, o_dw = 0.f;
+    if (do2) {
+      const int pb = t & 1;
+      S3 ym, yp, xm, xp, zm, zp;
+      ym.u = img1[pb][0][r - 1][lane]; ym.v = img1[pb][1][r - 1][lane]; ym.w = img1[pb][2][r - 1][lane];
+      yp.u = img1[pb][0][r + 1][lane]; yp.v = img1[pb][1][r + 1][lane]; yp.w = img1[pb][2][r + 1][lane];
+      const float eu = hc1[pb][0][side][r - 1], ev = hc1[pb][1][side][r - 1], ew = hc1[pb][2][side][r - 1];
+      xm.u = lane_left_or(hC.u, eu); xm.v = lane_left_or(hC.v, ev); xm.w = lane_left_or(hC.w, ew);
+      xp.u = lane_right_or(hC.u, eu); xp.v = lane_right_or(hC.v, ev); xp.w = lane_right_or(hC.w, ew);
+      zm = hM;
+      zp = sN;
+      // mirror rule at the faces of the volume: the missing neighbour is the opposite one
+      if (x == 0) xm = xp;
+      if (x == g.W - 1) xp = xm;
+      if (y == 0) ym = yp;
+      if (y == g.H - 1) yp = ym;
+      if (t == 0) zm = zp;
+      if (t == g.D - 1) zp = zm;
+      if (ABL & 2) {
+        o_du = xm.u + xp.v + ym.w + kC.J12;
+        o_dv = yp.u + zm.v + zp.w + kC.d1;
+        o_dw = xm.w + yp.v + zp.u + kC.pw[0] + hC_dv + hC_dw;
+      } else
+      sweep_stage2(kC, xm, xp, ym, yp, zm, zp, hC_dv, hC_dw, o_du, o_dv, o_dw);
+    }
+    asm volatile("" ::"v"(o_du), "v"(o_dv), "v"(o_dw), "v"(sN.u), "v"(sN.v), "v"(sN.w));
+    hM = hC;
+    hC = sN;
+    hC_dv = r_dv;
+    hC_dw = r_dw;
+    kC = kN;
+    __builtin_amdgcn_sched_barrier(0);
+    // everything requested BEFORE this step must have landed (plane q+2, its halos, the last stores); what this step
+    // requested stays in flight
+    if (!colw) {
+      if (more && !(ABL & 4)) {
+        if (edge) F3D_WAIT_PLANE(20, Q1);  // 10 row + 1 column gather + 9 halo-row loads
+        else F3D_WAIT_PLANE(11, Q1);
+      } else {
+        F3D_WAIT_PLANE(0, Q1);
+      }
+      plane_finish(Q1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (do2 && owner) {
+      const unsigned off = xb + rowoff(yy, t);
+      gst(obase[0], off, o_du);
+      gst(obase[1], off, o_dv);
+      gst(obase[2], off, o_dw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  PlaneRegs A = {}, B = {}, C = {}, D = {}, E = {};
+  if (!colw) {
+    load_plane(A, f3d_mir(qs - 1, g.D));
+    load_plane(B, qs);
+    load_plane(C, f3d_mir(qs + 1, g.D));
+    load_plane(D, f3d_mir(qs + 2, g.D));
+    dma_halos(qs - 1);
+    dma_halos(qs);
+    dma_halos(qs + 1);
+    dma_halos(qs + 2);
+    F3D_WAIT_PLANE(0, A);
+    F3D_WAIT_PLANE(0, B);
+    F3D_WAIT_PLANE(0, C);
+    F3D_WAIT_PLANE(0, D);
+    plane_finish(A);
+    plane_finish(B);
+    plane_finish(C);
+  }
+  __syncthreads();  // DMA-written rings are visible
+  if (colw) {
+    col_raw(A, qs - 1, crow + 1, 1);
+    col_raw(B, qs, crow + 1, 1);
+    plane_finish(A);
+    plane_finish(B);
+  } else {
+    publish(B, qs);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int q = qs;
+  for (; q + 4 <= q_end; q += 5) {
+    step(A, B, C, D, E, q);
+    step(B, C, D, E, A, q + 1);
+    step(C, D, E, A, B, q + 2);
+    step(D, E, A, B, C, q + 3);
+    step(E, A, B, C, D, q + 4);
+  }
+  if (q <= q_end) step(A, B, C, D, E, q);
+  if (q + 1 <= q_end) step(B, C, D, E, A, q + 1);
+  if (q + 2 <= q_end) step(C, D, E, A, B, q + 2);
+  if (q + 3 <= q_end) step(D, E, A, B, C, q + 3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
+}
+
 struct Tuning {
   int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds), 3 = k_sweep3 (sweep) + 2 (phi/ksi)
   int aligned;     // variant 3: 64-aligned x tiles with narrow x-halo loads instead of overlapping 62-wide tiles
@@ -1683,6 +2090,45 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
                      nty, n_tiles, t.xcd_remap);
 }
 
+template <int TY>
+void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int force_zchunk, int xcd_remap)
+{
+  const int planes = g.z_hi - g.z_lo;
+  const int ntx = (g.W + kLanes - 1) / kLanes;
+  const int nty = (g.H + TY - 1) / TY;
+  long nzc = (want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
+  const long max_chunks = planes / 8 > 0 ? planes / 8 : 1;  // every chunk repeats stage 1 of two planes
+  if (nzc > max_chunks) nzc = max_chunks;
+  if (nzc < 1) nzc = 1;
+  int zchunk = static_cast<int>((planes + nzc - 1) / nzc);
+  if (force_zchunk > 0) zchunk = force_zchunk;
+  const int nz = (planes + zchunk - 1) / zchunk;
+  const int n_tiles = ntx * nty * nz;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
+  static const int abl = std::getenv("F3D_ABLATE7") ? std::atoi(std::getenv("F3D_ABLATE7")) : 0;
+  const dim3 grid(blocks, 1, 1), block(kLanes, TY + 3, 1);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
+  if constexpr (TY == 9) {
+    if (abl == 1) return go(k_sweep7<TY, 1>);
+    if (abl == 2) return go(k_sweep7<TY, 2>);
+    if (abl == 3) return go(k_sweep7<TY, 3>);
+    if (abl == 4) return go(k_sweep7<TY, 4>);
+    if (abl == 7) return go(k_sweep7<TY, 7>);
+  }
+  go(k_sweep7<TY, 0>);
+}
+
+void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
+{
+  const Tuning& t = tuning();
+  static const int ty = std::getenv("F3D_SWEEP2_TY") ? std::atoi(std::getenv("F3D_SWEEP2_TY")) : 9;
+  static const long want = std::getenv("F3D_SWEEP2_WG") ? std::atol(std::getenv("F3D_SWEEP2_WG")) : 2048;
+  if (ty == 8) launch_sweep2_ty<8>(a, g, want, t.zchunk, t.xcd_remap);
+  else if (ty == 5) launch_sweep2_ty<5>(a, g, want, t.zchunk, t.xcd_remap);
+  else launch_sweep2_ty<9>(a, g, want, t.zchunk, t.xcd_remap);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1738,6 +2184,33 @@ int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f
   f3d::prof_begin(F3D_K_SWEEP, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
   launch_solver<true>(a, g);
   f3d::prof_end(F3D_K_SWEEP);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                     f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                     size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                     f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep2");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep2")) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep2: every dimension must be at least 2");
+  if (g.z_lo == g.z_hi) return 0;
+  if (!slab_reach_ok(g, 2, "f3d_solve_sweep2")) return 1;
+  SolveArgs a;
+  const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
+  for (int i = 0; i < 10; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
+  a.out[0] = f3d_ptr<float>(temp_du);
+  a.out[1] = f3d_ptr<float>(temp_dv);
+  a.out[2] = f3d_ptr<float>(temp_dw);
+  a.hx = hx; a.hy = hy; a.hz = hz;
+  a.p0 = equation_alpha;
+  a.p1 = 0.f;
+  f3d::prof_begin(F3D_K_SWEEP2, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
+  launch_sweep2(a, g);
+  f3d::prof_end(F3D_K_SWEEP2);
   F3D_HIP(hipGetLastError());
   return 0;
 }

@@ -1,5 +1,7 @@
 #include "hip_utils.h"
 
+#include <cstdlib>
+
 bool InitDeviceContextWithFirstAvailableDevice()
 {
   int count = 0;
@@ -25,4 +27,13 @@ void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_he
 {
   CheckDeviceError(f3d_copy3d_d2h(data3d.DataPtr(), data3d.Width(), data3d.Height(), data3d.Depth(), device_ptr,
                                   device_pitch, device_height, 0));
+}
+
+bool FusedSweepsEnabled()
+{
+  static const bool on = [] {
+    const char* e = std::getenv("F3D_FUSED_SWEEPS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }

@@ -24,5 +24,7 @@ inline bool CheckDeviceErrorAt(int status, const char* file, int line)
 bool InitDeviceContextWithFirstAvailableDevice();
 void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_height, size_t device_pitch);
 void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_height, size_t device_pitch);
+// Inner sweeps are launched in fused pairs unless F3D_FUSED_SWEEPS=0 (A/B timing; the results are bit-identical).
+bool FusedSweepsEnabled();
 
 #endif

@@ -281,14 +281,20 @@ void CudaOperationSolve::Execute(OperationParameters& params)
                                      *dw_ptr, w, h, d, hx, hy, hz, equation_smoothness, equation_data, dev_phi,
                                      dev_ksi, slab_)))
       return;
-    for (size_t j = 0; j < inner_iterations_count; ++j) {
-      if (CheckDeviceError(f3d_solve_sweep(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr,
-                                           *dv_ptr, *dw_ptr, dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha,
-                                           *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_)))
-        return;
+    // Sweeps go in fused pairs (f3d_solve_sweep2: the intermediate increment stays on chip, one buffer swap per pair);
+    // an odd count ends with a single sweep.  The result is the same bit pattern either way.
+    for (size_t j = 0; j < inner_iterations_count;) {
+      const bool pair = FusedSweepsEnabled() && j + 2 <= inner_iterations_count;
+      const int status =
+          pair ? f3d_solve_sweep2(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
+                                  dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_)
+               : f3d_solve_sweep(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
+                                 dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      if (CheckDeviceError(status)) return;
       std::swap(*du_ptr, *tdu_ptr);
       std::swap(*dv_ptr, *tdv_ptr);
       std::swap(*dw_ptr, *tdw_ptr);
+      j += pair ? 2 : 1;
     }
     if (!silent) {
       CheckDeviceError(f3d_stream_sync());

@@ -382,15 +382,24 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
         if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy,
                                hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &pw)))
           return false;
-        for (int j = 0; j < K; ++j) {
-          const f3d_slab sw = Window(D, l.rank, K - 1 - j, K - 1 - j);
-          if (!Check(f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
-                                     l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV], l.buf[TDW],
-                                     &sw)))
-            return false;
+        // sweep j runs on the slab widened by K-1-j planes; a fused pair (j, j+1) is launched on the window of sweep
+        // j+1 and computes sweep j on one plane more on either side by itself
+        for (int j = 0; j < K;) {
+          const bool pair = FusedSweepsEnabled() && j + 2 <= K;
+          const int shrink = K - 1 - j - (pair ? 1 : 0);
+          const f3d_slab sw = Window(D, l.rank, shrink, shrink);
+          const int status =
+              pair ? f3d_solve_sweep2(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
+                                      l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
+                                      l.buf[TDW], &sw)
+                   : f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
+                                     l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
+                                     l.buf[TDW], &sw);
+          if (!Check(status)) return false;
           std::swap(l.buf[DU], l.buf[TDU]);
           std::swap(l.buf[DV], l.buf[TDV]);
           std::swap(l.buf[DW], l.buf[TDW]);
+          j += pair ? 2 : 1;
         }
       }
       if (i + 1 < outer_iterations_count && !Exchange(D, W, H, {DU, DV, DW}, wide, wide)) return false;

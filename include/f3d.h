@@ -106,6 +106,15 @@ int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f
                     size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
                     f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
 
+/* TWO consecutive solve_3d sweeps in one launch: temp_d* receive what two f3d_solve_sweep calls with a buffer swap in
+ * between would leave in flow_d* (bit for bit); the intermediate field never goes to HBM, so the pair moves the bytes of
+ * one sweep.  Replaces two iterations of the inner loop of cuda_operation_solve.cpp:222-255; the caller swaps ONCE.
+ * A slab window [z_lo, z_hi) needs planes z_lo-2 .. z_hi+1 of every input inside the container. */
+int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                     f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                     size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                     f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
+
 /* registration_3d, 12 args: cuda_operation_registration.cpp:110-122; kernel src/kernels/registration_3d.cu:28-82 */
 int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
              size_t width, size_t height, size_t depth, float hx, float hy, float hz, f3d_devptr output,
@@ -142,8 +151,8 @@ int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height,
 
 /* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
 
-enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_COUNT = 2 };
-/* enable = 1 brackets every launch of the two solver kernels with events on the library stream */
+enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_COUNT = 3 };
+/* enable = 1 brackets every launch of the solver kernels (phi/ksi, one sweep, two fused sweeps) with events on the library stream */
 int f3d_prof_enable(int enable);
 int f3d_prof_reset(void);
 /* drains the pending events; min_voxels filters launches by level size (0 = all) */

@@ -256,3 +256,58 @@ def test_errors_are_loud(f3d):
         assert b"container" in f3d.hip().f3d_last_error()
     finally:
         dev.close()
+
+
+BIG_CASES = [((200, 45, 40), (256, 48, 40)), ((64, 64, 130), (64, 64, 130)), ((130, 19, 23), (130, 19, 23))]
+
+
+@pytest.mark.parametrize("dims,cdims", CASES + BIG_CASES)
+@pytest.mark.parametrize("h", SPACINGS)
+def test_two_fused_sweeps(f3d, oracle, dims, cdims, h):
+    """f3d_solve_sweep2 = two f3d_solve_sweep calls with a swap in between, bit for bit (and equal to two oracle sweeps):
+    the intermediate du, dv, dw stay on chip, halo rows/columns of the first sweep are recomputed per tile."""
+    rng = np.random.default_rng(hash((dims, h, 2)) % 2**32)
+    W, H, D = dims
+    arrs = solver_inputs(rng, dims, cdims)
+    alpha = 7.5
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+        outs = [dev.out() for _ in range(3)]
+        f3d.check(f3d.hip().f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, alpha, *outs, None))
+        for name, g, e in zip("uvw", outs, s2):
+            got = dev.get(g)[:D, :H, :W]
+            assert bit_same(got, e[:D, :H, :W]), f"d{name}: {np.count_nonzero(got != e[:D, :H, :W])} voxels differ"
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:5] + BIG_CASES[:1])
+def test_two_fused_sweeps_slab_window(f3d, oracle, dims, cdims):
+    """Slab launch of the fused pair: window [z_lo, z_hi) with two halo planes on either side inside the container."""
+    rng = np.random.default_rng(11)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, 7.5)
+    z_lo, z_hi = (1, D - 1) if D < 10 else (3, D - 2)
+    z_base = max(0, z_lo - 2)
+    top = min(D, z_hi + 2)
+    planes = top - z_base
+    sub = lambda a: np.ascontiguousarray(a[z_base:top])
+    dev = Dev(f3d, (cdims[0], cdims[1], planes))
+    try:
+        ptr = [dev.put(sub(a)) for a in arrs] + [dev.put(sub(phi_o)), dev.put(sub(ksi_o))]
+        outs = [dev.out() for _ in range(3)]
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        f3d.check(f3d.hip().f3d_solve_sweep2(*ptr, W, H, D, *h, 7.5, *outs, C.byref(slab)))
+        for g, e in zip(outs, s2):
+            assert bit_same(dev.get(g)[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+    finally:
+        dev.close()
