@@ -12,6 +12,7 @@
 //   * the y-neighbour rows are the rows the adjacent waves of the same workgroup stream at the same
 //     moment, so they are served by the CU's L1/the XCD's L2; mirror (Neumann) halos are index arithmetic.
 //   * loads for the next z step are issued before the arithmetic of the current one (software pipelining).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -40,6 +41,7 @@ struct SolveArgs {
   float* out[3];        // sweep: temp_du, temp_dv, temp_dw; phi_ksi: phi, ksi
   float hx, hy, hz;
   float p0, p1;  // sweep: alpha, unused; phi_ksi: eps_smooth, eps_data
+  unsigned long long* probe = nullptr;  // timing experiments (k_sweep7 with ABL bit 3): [wave][phase] cycle sums
 };
 
 enum { F0 = 0, F1 = 1, U = 2, V = 3, Wf = 4, DU = 5, DV = 6, DW = 7, PHI = 8 };
@@ -1069,17 +1071,20 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep5(SolveArgs a, F3dGeo 
 __device__ __forceinline__ float gld(const float* base, unsigned byte_off)
 {
   float v;
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+  // s_nop 4: if the register allocator ever restores the base pair from spilled lanes (v_readlane) right before this
+  // statement, gfx9 wants 5 wait states between a VALU write of an SGPR and a VMEM read of it, and the hazard
+  // recogniser does not look inside inline assembly
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
   return v;
 }
 __device__ __forceinline__ void gst(float* base, unsigned byte_off, float v)
 {
-  asm volatile("global_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void gld_lds(const float* base, unsigned byte_off, float* lds_dst)
 {
   const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
-  asm volatile("global_load_lds_dword %0, %1" ::"v"(byte_off), "s"(base), "{m0}"(m0v) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_lds_dword %0, %1" ::"v"(byte_off), "s"(base), "{m0}"(m0v) : "memory");
 }
 __device__ __forceinline__ void gld_lds_lane(const float* lane_addr, float* lds_dst)
 {
@@ -1681,7 +1686,8 @@ __device__ __forceinline__ void sweep_stage2(const Carry& k, const S3& xm, const
 }
 
 // ABL (timing experiments only, wrong results): bit 0 = no stage-1 arithmetic, bit 1 = no stage-2 arithmetic,
-// bit 2 = no global loads after the prologue
+// bit 2 = no global loads after the prologue, bit 3 = s_memtime stamps around the phases of a step, summed per wave into
+// SolveArgs::probe (the stamps share lgkmcnt with the LDS traffic and cost SGPRs, so the build is slower than the real one)
 template <int TY, int ABL = 0>
 __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                              int xcd_remap)
@@ -1814,13 +1820,18 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
 
   // M, C, P: finished planes q-1, q, q+1 (the column wave fills P at the start of the step).  Q1: raw plane q+2,
   // requested one step ago.  Q2: receives plane q+3.
+  unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
   auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int q) {
     const bool more = q + 3 <= qe + 1;  // plane q+3 is still somebody's z-neighbour
+    unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (ABL & 8) tk[0] = __builtin_amdgcn_s_memtime();
     if (!colw && more && !(ABL & 4)) {
       load_plane(Q2, f3d_mir(q + 3, g.D));
       dma_halos(q + 3);
     }
+    if (ABL & 8) tk[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // img0 of plane q, img1 / hc1 of plane q-1 and the DMA rings up to plane q+1 are complete
+    if (ABL & 8) tk[2] = __builtin_amdgcn_s_memtime();
     const bool do1 = q <= qe;
     const int b = q & 1;
 
@@ -1896,6 +1907,11 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
       }
     }
 
+    if (ABL & 8) {
+      asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
+      __builtin_amdgcn_sched_barrier(0);
+      tk[3] = __builtin_amdgcn_s_memtime();
+    }
     // stage 2 of plane t = q - 1
     const int t = q - 1;
     const bool do2 = core && t >= z0;
@@ -1931,6 +1947,7 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
     hC_dw = r_dw;
     kC = kN;
     __builtin_amdgcn_sched_barrier(0);
+    if (ABL & 8) tk[4] = __builtin_amdgcn_s_memtime();
     // everything requested BEFORE this step must have landed (plane q+2, its halos, the last stores); what this step
     // requested stays in flight
     if (!colw) {
@@ -1943,6 +1960,7 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
       plane_finish(Q1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (ABL & 8) tk[5] = __builtin_amdgcn_s_memtime();
     if (do2 && owner) {
       const unsigned off = xb + rowoff(yy, t);
       gst(obase[0], off, o_du);
@@ -1950,6 +1968,11 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
       gst(obase[2], off, o_dw);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (ABL & 8) {
+      tk[6] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pr[i] += tk[i + 1] - tk[i];
+    }
   };
 
   PlaneRegs A = {}, B = {}, C = {}, D = {}, E = {};
@@ -1993,6 +2016,11 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
   if (q + 2 <= q_end) step(C, D, E, A, B, q + 2);
   if (q + 3 <= q_end) step(D, E, A, B, C, q + 3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
+  if ((ABL & 8) && a.probe && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&a.probe[r * 8 + i], pr[i]);
+    atomicAdd(&a.probe[r * 8 + 6], static_cast<unsigned long long>(q_end - qs + 1));
+  }
 }
 
 struct Tuning {
@@ -2096,11 +2124,28 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
   const int planes = g.z_hi - g.z_lo;
   const int ntx = (g.W + kLanes - 1) / kLanes;
   const int nty = (g.H + TY - 1) / TY;
-  long nzc = (want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
-  const long max_chunks = planes / 8 > 0 ? planes / 8 : 1;  // every chunk repeats stage 1 of two planes
-  if (nzc > max_chunks) nzc = max_chunks;
-  if (nzc < 1) nzc = 1;
-  int zchunk = static_cast<int>((planes + nzc - 1) / nzc);
+  // One workgroup per CU at a time (LDS, registers), so the chunking is chosen by a round model: a z-chunk costs its
+  // planes plus ~6 steps of prologue and repeated stage-1 planes, and 256 workgroups run per round.
+  const long tiles = static_cast<long>(ntx) * nty;
+  const int max_chunks = planes / 8 > 0 ? planes / 8 : 1;
+  int zchunk = planes;
+  if (want_wg > 0) {  // experiments: aim at a workgroup count
+    long nzc = (want_wg + tiles - 1) / tiles;
+    if (nzc > max_chunks) nzc = max_chunks;
+    if (nzc < 1) nzc = 1;
+    zchunk = static_cast<int>((planes + nzc - 1) / nzc);
+  } else {
+    long best = -1;
+    for (int nzc = 1; nzc <= max_chunks; ++nzc) {
+      const int zc = (planes + nzc - 1) / nzc;
+      const long wgs = tiles * ((planes + zc - 1) / zc);
+      const long cost = ((wgs + 255) / 256) * (zc + 6);
+      if (best < 0 || cost < best) {
+        best = cost;
+        zchunk = zc;
+      }
+    }
+  }
   if (force_zchunk > 0) zchunk = force_zchunk;
   const int nz = (planes + zchunk - 1) / zchunk;
   const int n_tiles = ntx * nty * nz;
@@ -2115,6 +2160,27 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
     if (abl == 3) return go(k_sweep7<TY, 3>);
     if (abl == 4) return go(k_sweep7<TY, 4>);
     if (abl == 7) return go(k_sweep7<TY, 7>);
+    if (abl == 8) {
+      static unsigned long long* probe = nullptr;
+      if (!probe) (void)hipMalloc(reinterpret_cast<void**>(&probe), 16 * 8 * sizeof(unsigned long long));
+      (void)hipMemsetAsync(probe, 0, 16 * 8 * sizeof(unsigned long long), f3d::stream());
+      SolveArgs ap = a;
+      ap.probe = probe;
+      hipLaunchKernelGGL((k_sweep7<TY, 8>), grid, block, 0, f3d::stream(), ap, g, zchunk, ntx, nty, n_tiles, xcd_remap);
+      unsigned long long h[16 * 8];
+      (void)hipMemcpyAsync(h, probe, sizeof(h), hipMemcpyDeviceToHost, f3d::stream());
+      (void)hipStreamSynchronize(f3d::stream());
+      static int shown = 0;
+      if (shown++ < 1) {
+        std::fprintf(stderr, "k_sweep7 probe (avg cycles per step): wave  issue  barrier  stage1  stage2  vmwait  store\n");
+        for (int w = 0; w < TY + 3; ++w) {
+          const double n = static_cast<double>(h[w * 8 + 6]);
+          std::fprintf(stderr, "  %2d  %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f   (%.0f steps)\n", w, h[w * 8] / n, h[w * 8 + 1] / n,
+                       h[w * 8 + 2] / n, h[w * 8 + 3] / n, h[w * 8 + 4] / n, h[w * 8 + 5] / n, n);
+        }
+      }
+      return;
+    }
   }
   go(k_sweep7<TY, 0>);
 }
@@ -2123,7 +2189,7 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   static const int ty = std::getenv("F3D_SWEEP2_TY") ? std::atoi(std::getenv("F3D_SWEEP2_TY")) : 9;
-  static const long want = std::getenv("F3D_SWEEP2_WG") ? std::atol(std::getenv("F3D_SWEEP2_WG")) : 2048;
+  static const long want = std::getenv("F3D_SWEEP2_WG") ? std::atol(std::getenv("F3D_SWEEP2_WG")) : 0;
   if (ty == 8) launch_sweep2_ty<8>(a, g, want, t.zchunk, t.xcd_remap);
   else if (ty == 5) launch_sweep2_ty<5>(a, g, want, t.zchunk, t.xcd_remap);
   else launch_sweep2_ty<9>(a, g, want, t.zchunk, t.xcd_remap);
