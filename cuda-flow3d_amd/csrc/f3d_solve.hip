@@ -871,7 +871,7 @@ typedef __attribute__((address_space(3))) float LdsFloat;
 __device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rs, float* lds_dst, unsigned lane_bytes, unsigned row_bytes)
 {
   const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
-  asm volatile("buffer_load_dword %0, %1, %2 offen lds" ::"v"(lane_bytes), "s"(rs), "s"(row_bytes), "{m0}"(m0v) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(lane_bytes), "s"(rs), "s"(row_bytes), "{m0}"(m0v) : "memory");
 }
 
 __global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep5(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
@@ -1089,7 +1089,9 @@ __device__ __forceinline__ void gld_lds(const float* base, unsigned byte_off, fl
 __device__ __forceinline__ void gld_lds_lane(const float* lane_addr, float* lds_dst)
 {
   const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
-  asm volatile("global_load_lds_dword %0, off" ::"v"(lane_addr), "{m0}"(m0v) : "memory");
+  // s_nop 0: the compiler's write of M0 may sit right in front of this statement, and an LDS-DMA instruction must not
+  // read M0 in the cycle after a scalar write of it (one wait state; nobody inserts it inside inline assembly)
+  asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_addr), "{m0}"(m0v) : "memory");
 }
 #define F3D_WAIT_PLANE(N, P)                                                                                           \
   asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
@@ -1818,16 +1820,18 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
   float hC_dv = 0.f, hC_dw = 0.f;
   Carry kC = {};
 
-  // M, C, P: finished planes q-1, q, q+1 (the column wave fills P at the start of the step).  Q1: raw plane q+2,
-  // requested one step ago.  Q2: receives plane q+3.
+  // M, C, P: finished planes q-1, q, q+1 (the column wave fills P at the start of the step).  Q: receives plane q+2,
+  // requested at the top of the step and awaited at its end.  ONE plane in flight per wave, not two: with a dozen waves
+  // per CU a second plane only parks the waves in the issue stage (tools/lab/issue_lab: 12 waves x 10 loads issue in
+  // 10 cycles each, 12 x 20 in 40-95) and costs 10 registers.
   unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
-  auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int q) {
-    const bool more = q + 3 <= qe + 1;  // plane q+3 is still somebody's z-neighbour
+  auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, int q) {
+    const bool more = q + 2 <= qe + 1;  // plane q+2 is still somebody's z-neighbour
     unsigned long long tk[7] = {0, 0, 0, 0, 0, 0, 0};
     if (ABL & 8) tk[0] = __builtin_amdgcn_s_memtime();
     if (!colw && more && !(ABL & 4)) {
-      load_plane(Q2, f3d_mir(q + 3, g.D));
-      dma_halos(q + 3);
+      load_plane(Q, f3d_mir(q + 2, g.D));
+      dma_halos(q + 2);
     }
     if (ABL & 8) tk[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // img0 of plane q, img1 / hc1 of plane q-1 and the DMA rings up to plane q+1 are complete
@@ -1948,16 +1952,10 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
     kC = kN;
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 8) tk[4] = __builtin_amdgcn_s_memtime();
-    // everything requested BEFORE this step must have landed (plane q+2, its halos, the last stores); what this step
-    // requested stays in flight
+    // plane q+2 and its halos (requested at the top of this step) and the stores of the last step have landed
     if (!colw) {
-      if (more && !(ABL & 4)) {
-        if (edge) F3D_WAIT_PLANE(20, Q1);  // 10 row + 1 column gather + 9 halo-row loads
-        else F3D_WAIT_PLANE(11, Q1);
-      } else {
-        F3D_WAIT_PLANE(0, Q1);
-      }
-      plane_finish(Q1);
+      F3D_WAIT_PLANE(0, Q);
+      plane_finish(Q);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ABL & 8) tk[5] = __builtin_amdgcn_s_memtime();
@@ -1975,20 +1973,17 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
     }
   };
 
-  PlaneRegs A = {}, B = {}, C = {}, D = {}, E = {};
+  PlaneRegs A = {}, B = {}, C = {}, D = {};
   if (!colw) {
     load_plane(A, f3d_mir(qs - 1, g.D));
     load_plane(B, qs);
     load_plane(C, f3d_mir(qs + 1, g.D));
-    load_plane(D, f3d_mir(qs + 2, g.D));
     dma_halos(qs - 1);
     dma_halos(qs);
     dma_halos(qs + 1);
-    dma_halos(qs + 2);
     F3D_WAIT_PLANE(0, A);
     F3D_WAIT_PLANE(0, B);
     F3D_WAIT_PLANE(0, C);
-    F3D_WAIT_PLANE(0, D);
     plane_finish(A);
     plane_finish(B);
     plane_finish(C);
@@ -2004,17 +1999,15 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
   }
   __builtin_amdgcn_sched_barrier(0);
   int q = qs;
-  for (; q + 4 <= q_end; q += 5) {
-    step(A, B, C, D, E, q);
-    step(B, C, D, E, A, q + 1);
-    step(C, D, E, A, B, q + 2);
-    step(D, E, A, B, C, q + 3);
-    step(E, A, B, C, D, q + 4);
+  for (; q + 3 <= q_end; q += 4) {
+    step(A, B, C, D, q);
+    step(B, C, D, A, q + 1);
+    step(C, D, A, B, q + 2);
+    step(D, A, B, C, q + 3);
   }
-  if (q <= q_end) step(A, B, C, D, E, q);
-  if (q + 1 <= q_end) step(B, C, D, E, A, q + 1);
-  if (q + 2 <= q_end) step(C, D, E, A, B, q + 2);
-  if (q + 3 <= q_end) step(D, E, A, B, C, q + 3);
+  if (q <= q_end) step(A, B, C, D, q);
+  if (q + 1 <= q_end) step(B, C, D, A, q + 1);
+  if (q + 2 <= q_end) step(C, D, A, B, q + 2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
   if ((ABL & 8) && a.probe && lane == 0) {
 #pragma unroll
