@@ -4,14 +4,20 @@
 // Same per-voxel expression trees, built with -ffp-contract=off so that every
 // + - * / sqrt is one correctly rounded IEEE binary32 operation; the data movement is redesigned for CDNA4:
 //
-//   * one wave64 = one 64-float row segment (256 B coalesced per load).  Lanes 1..62 own an output voxel,
-//     lanes 0 and 63 only carry the x-halo: x-neighbours come from DPP wave shifts, not from memory or LDS.
-//   * a workgroup is F3D_TY such rows adjacent in y and marches along z with a rolling register window
-//     (z-1, z, z+1, and z+2 in flight), so every plane of every input is pulled from HBM once per sweep
-//     (2.5-D blocking) instead of the reference's (16+2)(8+2)(4+2) LDS tile with 2.25x halo over-fetch.
-//   * the y-neighbour rows are the rows the adjacent waves of the same workgroup stream at the same
-//     moment, so they are served by the CU's L1/the XCD's L2; mirror (Neumann) halos are index arithmetic.
-//   * loads for the next z step are issued before the arithmetic of the current one (software pipelining).
+//   * one wave64 = one 64-float row segment of a 64-aligned x tile (256 B per load instruction); x-neighbours come
+//     from DPP wave shifts with the tile's halo column merged in as the value the edge lane receives;
+//   * a workgroup is 8 (one sweep, phi/ksi) or 9+2 (two fused sweeps) such rows adjacent in y and marches along z with
+//     rotating plane register sets (z-1, z, z+1 and the planes in flight), so every plane of every input is pulled
+//     from HBM once per launch (2.5-D blocking) instead of the reference's (16+2)(8+2)(4+2) LDS tile with 2.25x halo
+//     over-fetch; y-neighbours go through a double-buffered LDS image of the current plane, one barrier per z step;
+//   * y-halo rows and x-halo columns are fetched by LDS-DMA (`global_load_lds_dword`) into small rings, at the moment
+//     the owning neighbour tile streams the same plane, so they hit the XCD's L2; tiles are dealt to the 8 XCDs in
+//     contiguous runs; mirror (Neumann) halos are index arithmetic;
+//   * every memory instruction of the hot loops is issued by hand (inline assembly) with counted `s_waitcnt vmcnt(N)`,
+//     so loads for later planes stay in flight across the arithmetic of the current one.
+// Kernels: k_phiksi6 (A.3), k_sweep6 (one sweep, A.4), k_sweep7 (two consecutive sweeps in one launch).  The ladder
+// of earlier variants (register rows, LDS rows, buffer loads, halos two planes ahead, ...) is in DESIGN.md section 3
+// and in the git history.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -21,8 +27,6 @@
 namespace {
 
 constexpr int kLanes = 64;
-constexpr int kOutX = 62;  // output voxels per wave row (lanes 1..62)
-constexpr int kTY = 4;     // rows (waves) per workgroup
 
 // value held by the lane to the left / right (wave-wide shift by one lane; edge lanes keep their own value)
 __device__ __forceinline__ float lane_left(float v)
@@ -85,169 +89,6 @@ __device__ __forceinline__ void phi_ksi_voxel(const Hood<8>& n, float hx, float 
   ksi = 1.f / (2.f * sqrtf(s + eps_d * eps_d));
 }
 
-// A.4: src/kernels/solve_3d.cu:425-506
-__device__ __forceinline__ void sweep_voxel(const Hood<9>& n, float ksi, float hx, float hy, float hz, float alpha,
-                                            bool has_xp, bool has_xm, bool has_yp, bool has_ym, bool has_zp,
-                                            bool has_zm, float& r_du, float& r_dv, float& r_dw)
-{
-  const float fx = (n.xp[F0] - n.xm[F0] + n.xp[F1] - n.xm[F1]) / (4.f * hx);
-  const float fy = (n.yp[F0] - n.ym[F0] + n.yp[F1] - n.ym[F1]) / (4.f * hy);
-  const float fz = (n.zp[F0] - n.zm[F0] + n.zp[F1] - n.zm[F1]) / (4.f * hz);
-  const float ft = n.c[F1] - n.c[F0];
-
-  const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
-  const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
-  const float J14 = fx * ft, J24 = fy * ft, J34 = fz * ft;
-
-  const float hx_2 = alpha / (hx * hx);
-  const float hy_2 = alpha / (hy * hy);
-  const float hz_2 = alpha / (hz * hz);
-
-  const float xp = static_cast<float>(has_xp) * hx_2;
-  const float xm = static_cast<float>(has_xm) * hx_2;
-  const float yp = static_cast<float>(has_yp) * hy_2;
-  const float ym = static_cast<float>(has_ym) * hy_2;
-  const float zp = static_cast<float>(has_zp) * hz_2;
-  const float zm = static_cast<float>(has_zm) * hz_2;
-
-  const float phi_xp = (n.xp[PHI] + n.c[PHI]) / 2.f;
-  const float phi_xm = (n.xm[PHI] + n.c[PHI]) / 2.f;
-  const float phi_yp = (n.yp[PHI] + n.c[PHI]) / 2.f;
-  const float phi_ym = (n.ym[PHI] + n.c[PHI]) / 2.f;
-  const float phi_zp = (n.zp[PHI] + n.c[PHI]) / 2.f;
-  const float phi_zm = (n.zm[PHI] + n.c[PHI]) / 2.f;
-
-  const float sumH = (xp * phi_xp + xm * phi_xm + yp * phi_yp + ym * phi_ym + zp * phi_zp + zm * phi_zm);
-  const float sumU = phi_xp * xp * (n.xp[U] + n.xp[DU] - n.c[U]) + phi_xm * xm * (n.xm[U] + n.xm[DU] - n.c[U]) +
-                     phi_yp * yp * (n.yp[U] + n.yp[DU] - n.c[U]) + phi_ym * ym * (n.ym[U] + n.ym[DU] - n.c[U]) +
-                     phi_zp * zp * (n.zp[U] + n.zp[DU] - n.c[U]) + phi_zm * zm * (n.zm[U] + n.zm[DU] - n.c[U]);
-  const float sumV = phi_xp * xp * (n.xp[V] + n.xp[DV] - n.c[V]) + phi_xm * xm * (n.xm[V] + n.xm[DV] - n.c[V]) +
-                     phi_yp * yp * (n.yp[V] + n.yp[DV] - n.c[V]) + phi_ym * ym * (n.ym[V] + n.ym[DV] - n.c[V]) +
-                     phi_zp * zp * (n.zp[V] + n.zp[DV] - n.c[V]) + phi_zm * zm * (n.zm[V] + n.zm[DV] - n.c[V]);
-  const float sumW = phi_xp * xp * (n.xp[Wf] + n.xp[DW] - n.c[Wf]) + phi_xm * xm * (n.xm[Wf] + n.xm[DW] - n.c[Wf]) +
-                     phi_yp * yp * (n.yp[Wf] + n.yp[DW] - n.c[Wf]) + phi_ym * ym * (n.ym[Wf] + n.ym[DW] - n.c[Wf]) +
-                     phi_zp * zp * (n.zp[Wf] + n.zp[DW] - n.c[Wf]) + phi_zm * zm * (n.zm[Wf] + n.zm[DW] - n.c[Wf]);
-
-  r_du = (ksi * (-J14 - J12 * n.c[DV] - J13 * n.c[DW]) + sumU) / (ksi * J11 + sumH);
-  r_dv = (ksi * (-J24 - J12 * r_du - J23 * n.c[DW]) + sumV) / (ksi * J22 + sumH);
-  r_dw = (ksi * (-J34 - J13 * r_du - J23 * r_dv) + sumW) / (ksi * J33 + sumH);
-}
-
-// SWEEP = true: solve sweep (9 stencilled inputs + ksi, 3 outputs); false: phi/ksi (8 inputs, 2 outputs).
-template <bool SWEEP>
-__global__ __launch_bounds__(kLanes* kTY) void k_solver(SolveArgs a, F3dGeo g, int zchunk)
-{
-  constexpr int NA = SWEEP ? 9 : 8;
-  const int lane = threadIdx.x;
-  const int y = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.y) * kTY + static_cast<int>(threadIdx.y));
-  if (y >= g.H) return;
-  const int z0 = g.z_lo + static_cast<int>(blockIdx.z) * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-  if (z0 >= z1) return;
-
-  const int x = static_cast<int>(blockIdx.x) * kOutX - 1 + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);  // x-halo lanes read the mirrored column
-  const int ylo = f3d_mir(y - 1, g.H);
-  const int yhi = f3d_mir(y + 1, g.H);
-  const bool owner = lane >= 1 && lane <= kOutX && x < g.W;
-
-  // rolling window: m = plane z-1, c = z, p = z+1, q = z+2 (in flight); yl/yh = rows y-1/y+1 of plane z
-  float m[NA], c[NA], p[NA], q[NA], yl[NA], yh[NA], nyl[NA], nyh[NA];
-  float kc = 0.f, kn = 0.f;
-  {
-    const size_t rm = f3d_row(g, y, f3d_mir(z0 - 1, g.D)) + xi;
-    const size_t rc = f3d_row(g, y, z0) + xi;
-    const size_t rp = f3d_row(g, y, f3d_mir(z0 + 1, g.D)) + xi;
-    const size_t rl = f3d_row(g, ylo, z0) + xi;
-    const size_t rh = f3d_row(g, yhi, z0) + xi;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      m[i] = a.in[i][rm];
-      c[i] = a.in[i][rc];
-      p[i] = a.in[i][rp];
-      yl[i] = a.in[i][rl];
-      yh[i] = a.in[i][rh];
-    }
-    if (SWEEP) kc = a.in[9][rc];
-  }
-
-  for (int z = z0; z < z1; ++z) {
-    const bool more = z + 1 < z1;
-    if (more) {
-      const size_t rq = f3d_row(g, y, f3d_mir(z + 2, g.D)) + xi;
-      const size_t rl = f3d_row(g, ylo, z + 1) + xi;
-      const size_t rh = f3d_row(g, yhi, z + 1) + xi;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        q[i] = a.in[i][rq];
-        nyl[i] = a.in[i][rl];
-        nyh[i] = a.in[i][rh];
-      }
-      if (SWEEP) kn = a.in[9][f3d_row(g, y, z + 1) + xi];
-    }
-
-    Hood<NA> n;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      n.c[i] = c[i];
-      n.xm[i] = lane_left(c[i]);
-      n.xp[i] = lane_right(c[i]);
-      n.ym[i] = yl[i];
-      n.yp[i] = yh[i];
-      n.zm[i] = m[i];
-      n.zp[i] = p[i];
-    }
-
-    const size_t o = f3d_row(g, y, z) + xi;
-    if constexpr (SWEEP) {
-      float r_du, r_dv, r_dw;
-      sweep_voxel(n, kc, a.hx, a.hy, a.hz, a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du,
-                  r_dv, r_dw);
-      if (owner) {
-        a.out[0][o] = r_du;
-        a.out[1][o] = r_dv;
-        a.out[2][o] = r_dw;
-      }
-    } else {
-      float phi, ksi;
-      phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
-      if (owner) {
-        a.out[0][o] = phi;
-        a.out[1][o] = ksi;
-      }
-    }
-
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        m[i] = c[i];
-        c[i] = p[i];
-        p[i] = q[i];
-        yl[i] = nyl[i];
-        yh[i] = nyh[i];
-      }
-      kc = kn;
-    }
-  }
-}
-
-// z-chunks so that even a coarse pyramid level spreads over all 256 CUs
-int pick_zchunk(const F3dGeo& g, dim3* grid)
-{
-  const int ntx = (g.W + kOutX - 1) / kOutX;
-  const int nty = (g.H + kTY - 1) / kTY;
-  const int planes = g.z_hi - g.z_lo;
-  const long want_wg = 2048;
-  long nzc = (want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
-  if (nzc < 1) nzc = 1;
-  long max_chunks = planes / 4 > 0 ? planes / 4 : 1;
-  if (nzc > max_chunks) nzc = max_chunks;
-  int zchunk = static_cast<int>((planes + nzc - 1) / nzc);
-  int nz = (planes + zchunk - 1) / zchunk;
-  *grid = dim3(ntx, nty, nz);
-  return zchunk;
-}
-
 bool slab_reach_ok(const F3dGeo& g, int reach, const char* who)
 {
   const int dc = static_cast<int>(f3d::container().depth);
@@ -265,18 +106,6 @@ bool slab_reach_ok(const F3dGeo& g, int reach, const char* who)
 }
 
 
-// ---- variant 2: rows of the current plane shared through LDS, 64-aligned x tiles, XCD-aware tile order ----------
-//
-// A workgroup is kRows = 8 waves = rows y0-1 .. y0+6 of one aligned 64-column tile: the 6 inner rows compute,
-// the two outer waves only stream the halo rows.  Every wave keeps its own row's z-window (z-1, z, z+1, z+2) in
-// registers, publishes plane z through LDS once per step, and reads its y-neighbours from there, so each row of
-// each plane is requested from L2/HBM once per workgroup.  The two x-halo columns of the row come from one extra
-// load (lanes < 32 fetch column x0-1, the others x0+64) that is merged into the DPP wave shift as the value the
-// edge lane keeps.  Tiles are dealt to the 8 XCDs in contiguous runs, so the halo rows/columns a tile shares
-// with its neighbours are served by the same L2.
-constexpr int kRows = 8;
-constexpr int kOutRows = kRows - 2;
-
 __device__ __forceinline__ float lane_left_or(float v, float edge)
 {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
@@ -288,122 +117,10 @@ __device__ __forceinline__ float lane_right_or(float v, float edge)
                                                                0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
-template <bool SWEEP>
-__global__ __launch_bounds__(kLanes* kRows, 4) void k_solver_lds(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty,
-                                                              int n_tiles, int xcd_remap)
-{
-  constexpr int NA = SWEEP ? 9 : 8;
-  __shared__ float sh[NA][kRows][kLanes];
-
-  // tile order: XCD k (blocks with id % 8 == k) walks tiles [k * per_xcd, (k + 1) * per_xcd) in sequence
-  int tile = static_cast<int>(blockIdx.x);
-  if (xcd_remap) {
-    const int per_xcd = (n_tiles + 7) / 8;
-    tile = (tile % 8) * per_xcd + tile / 8;
-  }
-  if (tile >= n_tiles) return;
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const int tz = tile / (ntx * nty);
-
-  const int lane = threadIdx.x;
-  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-
-  const int y = ty * kOutRows - 1 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x0 = tx * kLanes;
-  const int x = x0 + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
-  const int xh = f3d_clampi(f3d_mir(lane < 32 ? x0 - 1 : x0 + kLanes, g.W), 0, g.W - 1);
-  const bool owner = r >= 1 && r <= kOutRows && y < g.H && x < g.W;
-
-  float m[NA], c[NA], p[NA], q[NA], hc[NA], hn[NA];
-  float kc = 0.f, kn = 0.f;
-  {
-    const size_t rm = f3d_row(g, yy, f3d_mir(z0 - 1, g.D));
-    const size_t rc = f3d_row(g, yy, z0);
-    const size_t rp = f3d_row(g, yy, f3d_mir(z0 + 1, g.D));
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      m[i] = a.in[i][rm + xi];
-      c[i] = a.in[i][rc + xi];
-      p[i] = a.in[i][rp + xi];
-      hc[i] = a.in[i][rc + xh];
-    }
-    if (SWEEP) kc = a.in[9][rc + xi];
-  }
-
-  for (int z = z0; z < z1; ++z) {
-    const bool more = z + 1 < z1;
-    if (more) {
-      const size_t rq = f3d_row(g, yy, f3d_mir(z + 2, g.D));
-      const size_t rn = f3d_row(g, yy, z + 1);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        q[i] = a.in[i][rq + xi];
-        hn[i] = a.in[i][rn + xh];
-      }
-      if (SWEEP) kn = a.in[9][rn + xi];
-    }
-
-    __syncthreads();  // everybody is done reading the previous plane
-#pragma unroll
-    for (int i = 0; i < NA; ++i) sh[i][r][lane] = c[i];
-    __syncthreads();
-
-    if (r >= 1 && r <= kOutRows) {
-      Hood<NA> n;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        n.c[i] = c[i];
-        n.xm[i] = lane_left_or(c[i], hc[i]);
-        n.xp[i] = lane_right_or(c[i], hc[i]);
-        n.ym[i] = sh[i][r - 1][lane];
-        n.yp[i] = sh[i][r + 1][lane];
-        n.zm[i] = m[i];
-        n.zp[i] = p[i];
-      }
-      const size_t o = f3d_row(g, yy, z) + xi;
-      if constexpr (SWEEP) {
-        float r_du, r_dv, r_dw;
-        sweep_voxel(n, kc, a.hx, a.hy, a.hz, a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du,
-                    r_dv, r_dw);
-        if (owner) {
-          a.out[0][o] = r_du;
-          a.out[1][o] = r_dv;
-          a.out[2][o] = r_dw;
-        }
-      } else {
-        float phi, ksi;
-        phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
-        if (owner) {
-          a.out[0][o] = phi;
-          a.out[1][o] = ksi;
-        }
-      }
-    }
-
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        m[i] = c[i];
-        c[i] = p[i];
-        p[i] = q[i];
-        hc[i] = hn[i];
-      }
-      kc = kn;
-    }
-  }
-}
-
-// ---- variant 3 (sweep only): overlapping 62-wide x tiles (DPP halo lanes), all 8 waves compute, y-neighbours of
-// the current plane through a double-buffered LDS image (one barrier per z step), the workgroup's two y-halo rows
-// streamed by its edge waves.  The neighbour sums use S = U + dU formed once per voxel: the reference's
-// (U[nb] + dU[nb]) - U[c] reads the same two operands, so S[nb] - U[c] is bit-identical and saves 15 adds, 6 lane
-// shifts and 3 of the 9 LDS images per voxel.
-constexpr int kTY3 = 8;
+// ---- the sweep's per-voxel arithmetic ------------------------------------------------------------------------------
+// The neighbour sums use S = U + dU formed once per voxel: the reference's (U[nb] + dU[nb]) - U[c] reads the same two
+// operands, so S[nb] - U[c] is bit-identical and saves 15 adds, 6 lane shifts and 3 of the 9 LDS images per voxel.
+constexpr int kTY3 = 8;  // rows (waves) per workgroup of k_sweep6 and k_phiksi6
 enum { LF0 = 0, LF1 = 1, LPHI = 2, LSU = 3, LSV = 4, LSW = 5, kNL = 6 };
 
 struct Face6 {  // the six stencilled quantities of one neighbour
@@ -455,29 +172,6 @@ __device__ __forceinline__ void sweep_voxel_s(const Face6& xm, const Face6& xp, 
   r_dw = (ksi * (-J34 - J13 * r_du - J23 * r_dv) + sumW) / (ksi * J33 + sumH);
 }
 
-// Buffer-resource access (guide T8): a 128-bit descriptor per input array, a wave-uniform row offset in an SGPR
-// (soffset) and the lane's byte offset in one VGPR -- a load costs no VALU address arithmetic at all.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes)
-{
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, static_cast<int>(bytes), 0x00020000);
-}
-__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, unsigned row_bytes)
-{
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_bytes, row_bytes, 0));
-}
-
-// raw 9-array row sample -> the six stencilled quantities
-__device__ __forceinline__ void to_face(const float (&raw)[9], Face6& f)
-{
-  f.v[LF0] = raw[F0];
-  f.v[LF1] = raw[F1];
-  f.v[LPHI] = raw[PHI];
-  f.v[LSU] = raw[U] + raw[DU];
-  f.v[LSV] = raw[V] + raw[DV];
-  f.v[LSW] = raw[Wf] + raw[DW];
-}
-
-// One plane of the z-window of a lane: the nine streamed inputs, rewritten in place into what the stencil needs
 // (du becomes Su = u + du; Sv, Sw are kept beside dv, dw because the in-voxel Gauss-Seidel step still needs those).
 struct PlaneRegs {
   float f0, f1, phi, u, v, w, su, dv, dw, sv, sw, ksi;
@@ -497,576 +191,16 @@ __device__ __forceinline__ Face6 plane_face(const PlaneRegs& p)
   return f;
 }
 
-template <bool ALIGNED, bool CLEANWAIT>
-__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
-                                                            int xcd_remap)
-{
-  __shared__ float sh[2][kNL][kTY3 + 2][kLanes];
-
-  int tile = static_cast<int>(blockIdx.x);
-  if (xcd_remap) {
-    const int per_xcd = (n_tiles + 7) / 8;
-    tile = (tile % 8) * per_xcd + tile / 8;
-  }
-  if (tile >= n_tiles) return;
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const int tz = tile / (ntx * nty);
-
-  const int lane = threadIdx.x;
-  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-  const int y0 = ty * kTY3;
-  const int y = y0 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x = ALIGNED ? tx * kLanes + lane : tx * kOutX - 1 + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
-  const unsigned xb = static_cast<unsigned>(xi) * 4u;
-  const bool owner = (ALIGNED || (lane >= 1 && lane <= kOutX)) && x < g.W && y < g.H;
-  // aligned tiles: the two x-halo columns of the row come from one narrow load per array (lanes < 32 fetch
-  // column x0-1, the others x0+64) that the DPP shift keeps in the edge lane
-  const int xh = f3d_clampi(f3d_mir(lane < 32 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
-  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
-  // edge waves stream the workgroup's y-halo rows: row y0-1 (wave 0) and row y0+TY (last wave)
-  const bool edge = (r == 0) || (r == kTY3 - 1);
-  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
-  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
-
-  // descriptors are based at the first plane this chunk touches, so every offset fits 32 bits
-  const int zb = z0 > 0 ? z0 - 1 : 0;
-  const size_t base_off = f3d_row(g, 0, zb);
-  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
-  __amdgpu_buffer_rsrc_t rs[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
-  auto rowoff = [&](int yrow, int zz) {  // wave-uniform by construction; say so, or hipcc builds waterfall loops (T20)
-    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
-  };
-  auto load_plane = [&](PlaneRegs& p, int yrow, int zz) {  // issue only; plane_finish() after the data is needed
-    const unsigned ro = rowoff(yrow, zz);
-    p.f0 = buf_ld(rs[F0], xb, ro);
-    p.f1 = buf_ld(rs[F1], xb, ro);
-    p.u = buf_ld(rs[U], xb, ro);
-    p.v = buf_ld(rs[V], xb, ro);
-    p.w = buf_ld(rs[Wf], xb, ro);
-    p.su = buf_ld(rs[DU], xb, ro);
-    p.dv = buf_ld(rs[DV], xb, ro);
-    p.dw = buf_ld(rs[DW], xb, ro);
-    p.phi = buf_ld(rs[PHI], xb, ro);
-  };
-
-  // One z step.  M, C, P hold planes z-1, z, z+1 (finished); Q receives plane z+2; Hc is the finished halo row of
-  // plane z (edge waves only), Hn receives the halo row of plane z+1.
-  auto step = [&](const PlaneRegs& M, const PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, const PlaneRegs& Hc, PlaneRegs& Hn,
-                  int z) {
-    const bool more = z + 1 < z1;
-    PlaneRegs X;  // x-halo columns of plane z (aligned tiles only)
-    if (ALIGNED) {
-      const unsigned ro = rowoff(yy, z);
-      X.f0 = buf_ld(rs[F0], xhb, ro);
-      X.f1 = buf_ld(rs[F1], xhb, ro);
-      X.u = buf_ld(rs[U], xhb, ro);
-      X.v = buf_ld(rs[V], xhb, ro);
-      X.w = buf_ld(rs[Wf], xhb, ro);
-      X.su = buf_ld(rs[DU], xhb, ro);
-      X.dv = buf_ld(rs[DV], xhb, ro);
-      X.dw = buf_ld(rs[DW], xhb, ro);
-      X.phi = buf_ld(rs[PHI], xhb, ro);
-    }
-    if (more) {
-      load_plane(Q, yy, f3d_mir(z + 2, g.D));
-      P.ksi = buf_ld(rs[9], xb, rowoff(yy, z + 1));
-      if (edge) load_plane(Hn, yh_row, z + 1);
-    }
-    const int b = z & 1;
-    const Face6 cf = plane_face(C);
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) sh[b][i][r + 1][lane] = cf.v[i];
-    if (edge) {
-      const Face6 hf = plane_face(Hc);
-#pragma unroll
-      for (int i = 0; i < kNL; ++i) sh[b][i][lds_halo][lane] = hf.v[i];
-    }
-    __syncthreads();
-
-    Face6 ym, yp, xm, xp;
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) {
-      ym.v[i] = sh[b][i][r][lane];
-      yp.v[i] = sh[b][i][r + 2][lane];
-    }
-    if (ALIGNED) {
-      if (CLEANWAIT) {  // wait for the x-halo loads only: they were issued before this step's plane loads
-        if (!more) __builtin_amdgcn_s_waitcnt(0x0F70);
-        else if (edge) __builtin_amdgcn_s_waitcnt(0x4F73);  // vmcnt(19)
-        else __builtin_amdgcn_s_waitcnt(0x0F7A);            // vmcnt(10)
-      }
-      plane_finish(X);
-      const Face6 xf = plane_face(X);
-#pragma unroll
-      for (int i = 0; i < kNL; ++i) {
-        xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
-        xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < kNL; ++i) {
-        xm.v[i] = lane_left(cf.v[i]);
-        xp.v[i] = lane_right(cf.v[i]);
-      }
-    }
-    float r_du, r_dv, r_dw;
-    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
-    // Consume this step's loads HERE: the wait lands after the arithmetic (the loads had the whole step to
-    // arrive) and before the stores are issued, so it never waits for a store, and nothing issued in the next
-    // step sits between these loads and their first use (vmcnt counts in order).
-    if (CLEANWAIT) {
-      // pin the arithmetic before the wait (otherwise it is sunk into the `if (owner)` store block behind it)
-      asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this step (and the previous step's stores)
-    }
-    if (more) {
-      plane_finish(Q);
-      if (edge) plane_finish(Hn);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (owner) {
-      const size_t o = f3d_row(g, yy, z) + xi;
-      a.out[0][o] = r_du;
-      a.out[1][o] = r_dv;
-      a.out[2][o] = r_dw;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  PlaneRegs A, B, C, D, H0, H1;
-  load_plane(A, yy, f3d_mir(z0 - 1, g.D));
-  load_plane(B, yy, z0);
-  B.ksi = buf_ld(rs[9], xb, rowoff(yy, z0));
-  load_plane(C, yy, f3d_mir(z0 + 1, g.D));
-  if (edge) load_plane(H0, yh_row, z0);
-  if (CLEANWAIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing in flight
-  plane_finish(A);
-  plane_finish(B);
-  plane_finish(C);
-  if (edge) plane_finish(H0);
-
-  __builtin_amdgcn_sched_barrier(0);
-  // the four plane register sets take the roles (z-1, z, z+1, z+2) in rotation: no register moves per step
-  for (int z = z0; z < z1; z += 4) {
-    step(A, B, C, D, H0, H1, z);
-    if (z + 1 < z1) step(B, C, D, A, H1, H0, z + 1);
-    if (z + 2 < z1) step(C, D, A, B, H0, H1, z + 2);
-    if (z + 3 < z1) step(D, A, B, C, H1, H0, z + 3);
-  }
-}
-
-// ---- variant 4 (sweep): k_sweep3 with every halo load issued TWO planes ahead, like the row loads ----------------
-// The y-halo rows and x-halo columns of a tile are the interior of the neighbouring tiles, which the XCD-contiguous
-// tile order runs at the same time on the same L2.  They only hit that L2 if they are requested when the owner streams
-// the same plane, so all three kinds of loads of a step target plane z+2; halo data then waits two steps in a small
-// per-wave LDS ring (raw rows / column pairs) instead of in registers, which also frees 22 VGPRs.
-__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep4(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
-                                                            int xcd_remap)
-{
-  __shared__ float img[2][kNL][kTY3 + 2][kLanes];   // face image of the current plane, double buffered
-  __shared__ float hrow[3][2][9][kLanes];           // raw y-halo rows of planes z, z+1, z+2 (edge waves)
-  __shared__ float hcol[3][9][kTY3][2];             // raw x-halo column pairs of planes z, z+1, z+2 (every wave)
-
-  int tile = static_cast<int>(blockIdx.x);
-  if (xcd_remap) {
-    const int per_xcd = (n_tiles + 7) / 8;
-    tile = (tile % 8) * per_xcd + tile / 8;
-  }
-  if (tile >= n_tiles) return;
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const int tz = tile / (ntx * nty);
-
-  const int lane = threadIdx.x;
-  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-  const int y0 = ty * kTY3;
-  const int y = y0 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x = tx * kLanes + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
-  const unsigned xb = static_cast<unsigned>(xi) * 4u;
-  const bool owner = x < g.W && y < g.H;
-  const int side = lane < 32 ? 0 : 1;  // which x-halo column this lane fetches / uses
-  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
-  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
-  const bool edge = (r == 0) || (r == kTY3 - 1);
-  const int which = r == 0 ? 0 : 1;
-  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
-  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
-
-  const int zb = z0 > 0 ? z0 - 1 : 0;
-  const size_t base_off = f3d_row(g, 0, zb);
-  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
-  __amdgpu_buffer_rsrc_t rs[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
-  auto rowoff = [&](int yrow, int zz) {
-    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
-  };
-  auto load_plane = [&](PlaneRegs& p, unsigned lane_bytes, int yrow, int zz) {
-    const unsigned ro = rowoff(yrow, zz);
-    p.f0 = buf_ld(rs[F0], lane_bytes, ro);
-    p.f1 = buf_ld(rs[F1], lane_bytes, ro);
-    p.u = buf_ld(rs[U], lane_bytes, ro);
-    p.v = buf_ld(rs[V], lane_bytes, ro);
-    p.w = buf_ld(rs[Wf], lane_bytes, ro);
-    p.su = buf_ld(rs[DU], lane_bytes, ro);
-    p.dv = buf_ld(rs[DV], lane_bytes, ro);
-    p.dw = buf_ld(rs[DW], lane_bytes, ro);
-    p.phi = buf_ld(rs[PHI], lane_bytes, ro);
-  };
-  // raw plane <-> LDS ring slots (per-wave private storage: written and read by the same wave)
-  auto put_row = [&](const PlaneRegs& p, int slot) {
-    float* d = &hrow[slot][which][0][lane];
-    d[0 * kLanes] = p.f0; d[1 * kLanes] = p.f1; d[2 * kLanes] = p.u; d[3 * kLanes] = p.v; d[4 * kLanes] = p.w;
-    d[5 * kLanes] = p.su; d[6 * kLanes] = p.dv; d[7 * kLanes] = p.dw; d[8 * kLanes] = p.phi;
-  };
-  auto get_row = [&](PlaneRegs& p, int slot) {
-    const float* d = &hrow[slot][which][0][lane];
-    p.f0 = d[0 * kLanes]; p.f1 = d[1 * kLanes]; p.u = d[2 * kLanes]; p.v = d[3 * kLanes]; p.w = d[4 * kLanes];
-    p.su = d[5 * kLanes]; p.dv = d[6 * kLanes]; p.dw = d[7 * kLanes]; p.phi = d[8 * kLanes];
-  };
-  auto put_col = [&](const PlaneRegs& p, int slot) {
-    if (lane == 0 || lane == 32) {
-      float* d = &hcol[slot][0][r][side];
-      constexpr int st = kTY3 * 2;
-      d[0 * st] = p.f0; d[1 * st] = p.f1; d[2 * st] = p.u; d[3 * st] = p.v; d[4 * st] = p.w;
-      d[5 * st] = p.su; d[6 * st] = p.dv; d[7 * st] = p.dw; d[8 * st] = p.phi;
-    }
-  };
-  auto get_col = [&](PlaneRegs& p, int slot) {
-    const float* d = &hcol[slot][0][r][side];
-    constexpr int st = kTY3 * 2;
-    p.f0 = d[0 * st]; p.f1 = d[1 * st]; p.u = d[2 * st]; p.v = d[3 * st]; p.w = d[4 * st];
-    p.su = d[5 * st]; p.dv = d[6 * st]; p.dw = d[7 * st]; p.phi = d[8 * st];
-  };
-
-  auto step = [&](const PlaneRegs& M, const PlaneRegs& C, PlaneRegs& P, PlaneRegs& Q, int z) {
-    const bool more = z + 1 < z1;       // plane z+1 will be computed: its neighbours (z+2) must be fetched
-    PlaneRegs XQ, HQ;
-    if (more) {
-      const int zq = f3d_mir(z + 2, g.D);
-      load_plane(Q, xb, yy, zq);
-      P.ksi = buf_ld(rs[9], xb, rowoff(yy, z + 1));
-      // halos of plane z+2 are only needed if that plane is computed by this chunk
-      if (z + 2 < z1) {
-        load_plane(XQ, xhb, yy, z + 2);
-        if (edge) load_plane(HQ, xb, yh_row, z + 2);
-      }
-    }
-    const int b = z & 1;
-    const int slot = z % 3;
-    const Face6 cf = plane_face(C);
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) img[b][i][r + 1][lane] = cf.v[i];
-    if (edge) {
-      PlaneRegs Hc;
-      get_row(Hc, slot);
-      plane_finish(Hc);
-      const Face6 hf = plane_face(Hc);
-#pragma unroll
-      for (int i = 0; i < kNL; ++i) img[b][i][lds_halo][lane] = hf.v[i];
-    }
-    PlaneRegs X;
-    get_col(X, slot);
-    __syncthreads();
-
-    Face6 ym, yp, xm, xp;
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) {
-      ym.v[i] = img[b][i][r][lane];
-      yp.v[i] = img[b][i][r + 2][lane];
-    }
-    plane_finish(X);
-    const Face6 xf = plane_face(X);
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) {
-      xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
-      xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
-    }
-    float r_du, r_dv, r_dw;
-    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
-    asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this step (and the previous step's stores)
-    if (more) {
-      plane_finish(Q);
-      if (z + 2 < z1) {
-        const int s2 = (z + 2) % 3;
-        put_col(XQ, s2);
-        if (edge) put_row(HQ, s2);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (owner) {
-      const size_t o = f3d_row(g, yy, z) + xi;
-      a.out[0][o] = r_du;
-      a.out[1][o] = r_dv;
-      a.out[2][o] = r_dw;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  PlaneRegs A, B, C, D;
-  {
-    PlaneRegs T0, T1;
-    load_plane(A, xb, yy, f3d_mir(z0 - 1, g.D));
-    load_plane(B, xb, yy, z0);
-    B.ksi = buf_ld(rs[9], xb, rowoff(yy, z0));
-    load_plane(C, xb, yy, f3d_mir(z0 + 1, g.D));
-    load_plane(T0, xhb, yy, z0);
-    if (z0 + 1 < z1) load_plane(T1, xhb, yy, z0 + 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    put_col(T0, z0 % 3);
-    if (z0 + 1 < z1) put_col(T1, (z0 + 1) % 3);
-    if (edge) {
-      load_plane(T0, xb, yh_row, z0);
-      if (z0 + 1 < z1) load_plane(T1, xb, yh_row, z0 + 1);
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      put_row(T0, z0 % 3);
-      if (z0 + 1 < z1) put_row(T1, (z0 + 1) % 3);
-    }
-    plane_finish(A);
-    plane_finish(B);
-    plane_finish(C);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  for (int z = z0; z < z1; z += 4) {
-    step(A, B, C, D, z);
-    if (z + 1 < z1) step(B, C, D, A, z + 1);
-    if (z + 2 < z1) step(C, D, A, B, z + 2);
-    if (z + 3 < z1) step(D, A, B, C, z + 3);
-  }
-}
-
-// ---- variant 5 (sweep): halos by LDS-DMA, own rows prefetched TWO steps ahead ------------------------------------
-// The sweep is latency-bound at 16 waves/CU x ~3 KB in flight.  Here the halo traffic of k_sweep4 no longer passes
-// through VGPRs at all (`buffer_load_dword ... lds` lands it in the per-wave LDS rings directly), which frees the
-// registers for a fifth rotating plane set: the row of plane z+3 is requested at step z and only has to be there at
-// the end of step z+1 (counted `s_waitcnt vmcnt(N)` leaves the youngest step's loads in flight).
-constexpr int kRing = 4;  // planes z .. z+3
-
-// `buffer_load_dword ... lds`: 64 lanes x 4 B land at LDS address m0 + 4 * lane (masked lanes write nothing, measured
-// with tools/lab/dma_probe.hip).  Issued through inline asm on purpose: hipcc makes every later ds_read wait for
-// vmcnt(0) once it knows of an LDS-DMA in flight, which would serialise the prefetch.  The waits are ours (below).
+constexpr int kRing = 4;  // LDS ring of the DMA-fed halos in k_sweep6 / k_phiksi6: planes z .. z+3
 typedef __attribute__((address_space(3))) float LdsFloat;
-__device__ __forceinline__ void dma_to_lds(__amdgpu_buffer_rsrc_t rs, float* lds_dst, unsigned lane_bytes, unsigned row_bytes)
-{
-  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
-  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(lane_bytes), "s"(rs), "s"(row_bytes), "{m0}"(m0v) : "memory");
-}
 
-__global__ __launch_bounds__(kLanes* kTY3, 4) void k_sweep5(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
-                                                            int xcd_remap)
-{
-  __shared__ float img[2][kNL][kTY3 + 2][kLanes];  // face image of the current plane, double buffered
-  __shared__ float hrow[kRing][2][9][kLanes];      // raw y-halo rows (edge waves), filled by LDS-DMA
-  __shared__ float hcol[kRing][3][kLanes];         // raw x-halo pairs: entry e = array*8 + row -> [e/32][side*32 + e%32]
-
-  int tile = static_cast<int>(blockIdx.x);
-  if (xcd_remap) {
-    const int per_xcd = (n_tiles + 7) / 8;
-    tile = (tile % 8) * per_xcd + tile / 8;
-  }
-  if (tile >= n_tiles) return;
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const int tz = tile / (ntx * nty);
-
-  const int lane = threadIdx.x;
-  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-  const int y0 = ty * kTY3;
-  const int y = y0 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x = tx * kLanes + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
-  const unsigned xb = static_cast<unsigned>(xi) * 4u;
-  const bool owner = x < g.W && y < g.H;
-  const int side = lane < 32 ? 0 : 1;
-  const int xh = f3d_clampi(f3d_mir(side == 0 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
-  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
-  const bool col_lane = lane == 0 || lane == 32;
-  const bool edge = (r == 0) || (r == kTY3 - 1);
-  const int which = r == 0 ? 0 : 1;
-  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
-  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
-
-  const int zb = z0 > 0 ? z0 - 1 : 0;
-  const size_t base_off = f3d_row(g, 0, zb);
-  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
-  __amdgpu_buffer_rsrc_t rs[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
-  auto rowoff = [&](int yrow, int zz) {
-    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
-  };
-  constexpr int kOrder[9] = {F0, F1, U, V, Wf, DU, DV, DW, PHI};  // slot order inside the rings = PlaneRegs order below
-  auto load_plane = [&](PlaneRegs& p, int zz) {  // own row, incl. ksi
-    const unsigned ro = rowoff(yy, zz);
-    p.f0 = buf_ld(rs[F0], xb, ro);
-    p.f1 = buf_ld(rs[F1], xb, ro);
-    p.u = buf_ld(rs[U], xb, ro);
-    p.v = buf_ld(rs[V], xb, ro);
-    p.w = buf_ld(rs[Wf], xb, ro);
-    p.su = buf_ld(rs[DU], xb, ro);
-    p.dv = buf_ld(rs[DV], xb, ro);
-    p.dw = buf_ld(rs[DW], xb, ro);
-    p.phi = buf_ld(rs[PHI], xb, ro);
-    p.ksi = buf_ld(rs[9], xb, ro);
-  };
-  // LDS-DMA of the halos of plane zz into ring slot zz & 3: no VGPR is written
-  auto dma_halos = [&](int zz) {
-    const int slot = zz & (kRing - 1);
-    const unsigned ro = rowoff(yy, zz);
-    if (col_lane) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const int e = i * kTY3 + r;
-        dma_to_lds(rs[kOrder[i]], &hcol[slot][e >> 5][e & 31], xhb, ro);
-      }
-    }
-    if (edge) {
-      const unsigned rh = rowoff(yh_row, zz);
-#pragma unroll
-      for (int i = 0; i < 9; ++i)
-        dma_to_lds(rs[kOrder[i]], &hrow[slot][which][i][0], xb, rh);
-    }
-  };
-  auto ring_row = [&](PlaneRegs& p, int slot) {
-    const float* d = &hrow[slot][which][0][lane];
-    p.f0 = d[0 * kLanes]; p.f1 = d[1 * kLanes]; p.u = d[2 * kLanes]; p.v = d[3 * kLanes]; p.w = d[4 * kLanes];
-    p.su = d[5 * kLanes]; p.dv = d[6 * kLanes]; p.dw = d[7 * kLanes]; p.phi = d[8 * kLanes];
-  };
-  auto ring_col = [&](PlaneRegs& p, int slot) {
-    auto at = [&](int i) {
-      const int e = i * kTY3 + r;
-      return hcol[slot][e >> 5][side * 32 + (e & 31)];
-    };
-    p.f0 = at(0); p.f1 = at(1); p.u = at(2); p.v = at(3); p.w = at(4);
-    p.su = at(5); p.dv = at(6); p.dw = at(7); p.phi = at(8);
-  };
-
-  // M, C, P: finished planes z-1, z, z+1.  Q1: raw plane z+2, requested one step ago.  Q2: receives plane z+3.
-  // FULL: steady state (z + 3 < z1), no conditions, so the load counts the compiler tracks stay exact
-  auto step = [&](auto full, const PlaneRegs& M, const PlaneRegs& C, const PlaneRegs& P, PlaneRegs& Q1, PlaneRegs& Q2, int z) {
-    constexpr bool FULL = decltype(full)::value;
-    const bool row3 = FULL || z + 3 <= z1;   // plane z+3 is somebody's z-neighbour
-    const bool halo3 = FULL || z + 3 < z1;   // plane z+3 is computed by this chunk
-    // halos first: the compiler counts only the register loads, so its (and our) vmcnt(10) at the end of the step
-    // retires everything older than this step's ten row loads -- the DMA of this step included
-    if (halo3) dma_halos(z + 3);
-    if (row3) load_plane(Q2, f3d_mir(z + 3, g.D));
-
-    const int b = z & 1;
-    const int slot = z & (kRing - 1);
-    const Face6 cf = plane_face(C);
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) img[b][i][r + 1][lane] = cf.v[i];
-    if (edge) {
-      PlaneRegs Hc;
-      ring_row(Hc, slot);
-      plane_finish(Hc);
-      const Face6 hf = plane_face(Hc);
-#pragma unroll
-      for (int i = 0; i < kNL; ++i) img[b][i][lds_halo][lane] = hf.v[i];
-    }
-    PlaneRegs X;
-    ring_col(X, slot);
-    __syncthreads();
-
-    Face6 ym, yp, xm, xp;
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) {
-      ym.v[i] = img[b][i][r][lane];
-      yp.v[i] = img[b][i][r + 2][lane];
-    }
-    plane_finish(X);
-    const Face6 xf = plane_face(X);
-#pragma unroll
-    for (int i = 0; i < kNL; ++i) {
-      xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
-      xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
-    }
-    float r_du, r_dv, r_dw;
-    sweep_voxel_s(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                  a.p0, x < g.W - 1, x > 0, y < g.H - 1, y > 0, z < g.D - 1, z > 0, r_du, r_dv, r_dw);
-    asm volatile("" ::"v"(r_du), "v"(r_dv), "v"(r_dw));
-    __builtin_amdgcn_sched_barrier(0);
-    // everything requested BEFORE this step must have landed (plane z+2 and its halos, last step's stores); what this
-    // step requested stays in flight: counted wait, the counter retires in order
-    if (row3) __builtin_amdgcn_s_waitcnt(0x0F7A);  // vmcnt(10): this step's row loads stay in flight
-    else __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
-    if (FULL || z + 2 <= z1) plane_finish(Q1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (owner) {
-      const size_t o = f3d_row(g, yy, z) + xi;
-      a.out[0][o] = r_du;
-      a.out[1][o] = r_dv;
-      a.out[2][o] = r_dw;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  PlaneRegs A, B, C, D, E;
-  load_plane(A, f3d_mir(z0 - 1, g.D));
-  load_plane(B, z0);
-  load_plane(C, f3d_mir(z0 + 1, g.D));
-  dma_halos(z0);
-  if (z0 + 1 < z1) dma_halos(z0 + 1);
-  if (z0 + 2 < z1) dma_halos(z0 + 2);
-  if (z0 + 2 <= z1) load_plane(D, f3d_mir(z0 + 2, g.D));
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  plane_finish(A);
-  plane_finish(B);
-  plane_finish(C);
-  __syncthreads();  // the rings are private to their wave, but let the DMA-written LDS settle for everybody once
-  __builtin_amdgcn_sched_barrier(0);
-  int z = z0;
-  for (; z + 7 < z1; z += 5) {  // five steady-state steps: the last one (z+4) still has z+4+3 < z1
-    step(std::true_type{}, A, B, C, D, E, z);
-    step(std::true_type{}, B, C, D, E, A, z + 1);
-    step(std::true_type{}, C, D, E, A, B, z + 2);
-    step(std::true_type{}, D, E, A, B, C, z + 3);
-    step(std::true_type{}, E, A, B, C, D, z + 4);
-  }
-  for (; z < z1; z += 5) {      // tail (and chunks shorter than 8 planes): same rotation, guarded loads
-    step(std::false_type{}, A, B, C, D, E, z);
-    if (z + 1 < z1) step(std::false_type{}, B, C, D, E, A, z + 1);
-    if (z + 2 < z1) step(std::false_type{}, C, D, E, A, B, z + 2);
-    if (z + 3 < z1) step(std::false_type{}, D, E, A, B, C, z + 3);
-    if (z + 4 < z1) step(std::false_type{}, E, A, B, C, D, z + 4);
-  }
-}
-
-// ---- variant 6 (sweep): k_sweep5 with the whole load path issued by hand -------------------------------------------
-// PMC on k_sweep4 (profiles/): the TA address FIFO is full a third of the time and the scalar unit issues half as many
-// instructions as the vector unit, most of them `s_mov_b32` shuffling the ten buffer descriptors into aligned SGPR quads.
-// Here every load is a `global_load_dword vdst, voff, s[base:base+1]` (two SGPRs per array, no descriptor, one VALU add
-// per plane for the shared row offset), the 18 x-halo values of a row are fetched by ONE instruction (lane i / 32+i reads
-// array i, landing in LDS by DMA), and since the compiler no longer sees any load it inserts no waits: the two
+// ---- one sweep per launch: k_sweep6 ------------------------------------------------------------------------------------
+// Every load is a `global_load_dword vdst, voff, s[base:base+1]` (two SGPRs per array, no descriptor, one VALU add per
+// plane for the shared row offset); the 18 x-halo values of a row are fetched by ONE instruction (lane i / 32+i reads
+// array i, landing in LDS by DMA: `global_load_lds_dword` writes lane L's dword to M0 + 4 L, masked lanes write nothing,
+// tools/lab/dma_probe.hip); the edge waves' halo rows land in LDS the same way.  Own rows are requested TWO planes ahead
+// (five rotating register sets).  Issued through inline assembly on purpose: hipcc makes every later ds_read wait for
+// vmcnt(0) once it knows of an LDS-DMA in flight, and it cannot count loads it does not see, so the two
 // `s_waitcnt vmcnt(N)` per step below are the only ones, tied to the registers they guard by "+v" operands.
 __device__ __forceinline__ float gld(const float* base, unsigned byte_off)
 {
@@ -1307,129 +441,14 @@ __global__ __launch_bounds__(kLanes* TY, 4) void k_sweep6(SolveArgs a, F3dGeo g,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
 }
 
-// ---- variant 3, phi/ksi: same data movement as k_sweep3 (aligned 64-wide tiles, rows of the current plane through a
-// double-buffered LDS image, edge waves stream the y-halo rows, four rotating plane register sets); all eight inputs
-// are stencilled here (the central differences of A.3 do not factor), and there is nothing to pre-combine.
 struct Plane8 {
   float v[8];
 };
 
-__global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi3(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
-                                                             int xcd_remap)
-{
-  __shared__ float sh[2][8][kTY3 + 2][kLanes];
-
-  int tile = static_cast<int>(blockIdx.x);
-  if (xcd_remap) {
-    const int per_xcd = (n_tiles + 7) / 8;
-    tile = (tile % 8) * per_xcd + tile / 8;
-  }
-  if (tile >= n_tiles) return;
-  const int tx = tile % ntx;
-  const int ty = (tile / ntx) % nty;
-  const int tz = tile / (ntx * nty);
-
-  const int lane = threadIdx.x;
-  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
-  const int y0 = ty * kTY3;
-  const int y = y0 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
-  const int x = tx * kLanes + lane;
-  const int xi = f3d_clampi(f3d_mir(x, g.W), 0, g.W - 1);
-  const unsigned xb = static_cast<unsigned>(xi) * 4u;
-  const bool owner = x < g.W && y < g.H;
-  const int xh = f3d_clampi(f3d_mir(lane < 32 ? tx * kLanes - 1 : tx * kLanes + kLanes, g.W), 0, g.W - 1);
-  const unsigned xhb = static_cast<unsigned>(xh) * 4u;
-  const bool edge = (r == 0) || (r == kTY3 - 1);
-  const int yh_row = f3d_clampi(f3d_mir(r == 0 ? y0 - 1 : y0 + kTY3, g.H), 0, g.H - 1);
-  const int lds_halo = r == 0 ? 0 : kTY3 + 1;
-
-  const int zb = z0 > 0 ? z0 - 1 : 0;
-  const size_t base_off = f3d_row(g, 0, zb);
-  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned span = static_cast<unsigned>(min(z1 + 1, g.D) - zb) * plane_b;
-  __amdgpu_buffer_rsrc_t rs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) rs[i] = make_rsrc(a.in[i] + base_off, span);
-  auto rowoff = [&](int yrow, int zz) {
-    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
-        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
-  };
-  auto load_plane = [&](Plane8& p, unsigned lane_bytes, int yrow, int zz) {
-    const unsigned ro = rowoff(yrow, zz);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p.v[i] = buf_ld(rs[i], lane_bytes, ro);
-  };
-
-  auto step = [&](const Plane8& M, const Plane8& C, const Plane8& P, Plane8& Q, const Plane8& Hc, Plane8& Hn, int z) {
-    const bool more = z + 1 < z1;
-    Plane8 X;
-    load_plane(X, xhb, yy, z);
-    if (more) {
-      load_plane(Q, xb, yy, f3d_mir(z + 2, g.D));
-      if (edge) load_plane(Hn, xb, yh_row, z + 1);
-    }
-    const int b = z & 1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sh[b][i][r + 1][lane] = C.v[i];
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sh[b][i][lds_halo][lane] = Hc.v[i];
-    }
-    __syncthreads();
-
-    Hood<8> n;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      n.c[i] = C.v[i];
-      n.ym[i] = sh[b][i][r][lane];
-      n.yp[i] = sh[b][i][r + 2][lane];
-      n.zm[i] = M.v[i];
-      n.zp[i] = P.v[i];
-    }
-    // wait for the x-halo loads only: they were issued before this step's plane loads
-    if (!more) __builtin_amdgcn_s_waitcnt(0x0F70);
-    else if (edge) __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16)
-    else __builtin_amdgcn_s_waitcnt(0x0F78);            // vmcnt(8)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      n.xm[i] = lane_left_or(C.v[i], X.v[i]);
-      n.xp[i] = lane_right_or(C.v[i], X.v[i]);
-    }
-    float phi, ksi;
-    phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
-    asm volatile("" ::"v"(phi), "v"(ksi));
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this step's plane loads (and the previous step's stores)
-    __builtin_amdgcn_sched_barrier(0);
-    if (owner) {
-      const size_t o = f3d_row(g, yy, z) + xi;
-      a.out[0][o] = phi;
-      a.out[1][o] = ksi;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  Plane8 A, B, C, D, H0, H1;
-  load_plane(A, xb, yy, f3d_mir(z0 - 1, g.D));
-  load_plane(B, xb, yy, z0);
-  load_plane(C, xb, yy, f3d_mir(z0 + 1, g.D));
-  if (edge) load_plane(H0, xb, yh_row, z0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __builtin_amdgcn_sched_barrier(0);
-  for (int z = z0; z < z1; z += 4) {
-    step(A, B, C, D, H0, H1, z);
-    if (z + 1 < z1) step(B, C, D, A, H1, H0, z + 1);
-    if (z + 2 < z1) step(C, D, A, B, H0, H1, z + 2);
-    if (z + 3 < z1) step(D, A, B, C, H1, H0, z + 3);
-  }
-}
-
-// ---- variant 6, phi/ksi: the load path of k_sweep6 (hand-issued global loads, one-instruction x-halo gather, LDS-DMA
-// halo rows, rows requested two steps ahead, next plane published right after the barrier) for the eight inputs of A.3.
+// ---- phi/ksi: k_phiksi6 -----------------------------------------------------------------------------------------------
+// The load path of k_sweep6 (hand-issued global loads, one-instruction x-halo gather, LDS-DMA halo rows, rows requested
+// two steps ahead, next plane published right after the barrier) for the eight inputs of A.3, all of them stencilled
+// (the central differences of A.3 do not factor, there is nothing to pre-combine).
 #define F3D_WAIT_PLANE8(N, P)                                                                                          \
   asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
                : "+v"((P).v[0]), "+v"((P).v[1]), "+v"((P).v[2]), "+v"((P).v[3]), "+v"((P).v[4]), "+v"((P).v[5]),       \
@@ -1595,7 +614,7 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- variant 7: TWO sweeps in one launch (temporal blocking) ---------------------------------------------------------
+// ---- two sweeps per launch: k_sweep7 (temporal blocking) ----------------------------------------------------------------
 // A sweep streams 52 B per voxel for ~150 flops, and the 13-stream ceiling of the memory system (tools/lab/stream_lab)
 // is ~5.0-5.6 TB/s, so a one-sweep kernel cannot pass ~65 % of the 8 TB/s peak.  Two consecutive sweeps read the same
 // f0, f1, u, v, w, phi, ksi; only du, dv, dw change in between.  This kernel keeps the intermediate field on chip:
@@ -2017,26 +1036,16 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
 }
 
 struct Tuning {
-  int variant;     // 1 = register rows (k_solver), 2 = LDS rows (k_solver_lds), 3 = k_sweep3 (sweep) + 2 (phi/ksi)
-  int aligned;     // variant 3: 64-aligned x tiles with narrow x-halo loads instead of overlapping 62-wide tiles
-  int cleanwait;   // variant 3: explicit end-of-step vmcnt(0)
-  int variant4;    // sweep: 1 = k_sweep4, 2 = k_sweep5, 3 = k_sweep6
-  int ty16;        // k_sweep6 with 16-row workgroups
-  int xcd_remap;
-  int zchunk;      // 0 = automatic
-  long want_wg;
+  int xcd_remap;   // deal tiles to the 8 XCDs in contiguous runs (1) or leave the hardware's round robin (0)
+  int zchunk;      // planes per z-chunk, 0 = automatic
+  long want_wg;    // k_sweep6 / k_phiksi6: workgroups to aim at when cutting z-chunks
 };
 
 const Tuning& tuning()
 {
   static const Tuning t = [] {
-    Tuning v = {3, 1, 1, 3, 0, 1, 0, 4096};
-    if (const char* e = std::getenv("F3D_SOLVER_VARIANT")) v.variant = std::atoi(e);
+    Tuning v = {1, 0, 4096};
     if (const char* e = std::getenv("F3D_XCD_REMAP")) v.xcd_remap = std::atoi(e);
-    if (const char* e = std::getenv("F3D_ALIGNED")) v.aligned = std::atoi(e);
-    if (const char* e = std::getenv("F3D_CLEANWAIT")) v.cleanwait = std::atoi(e);
-    if (const char* e = std::getenv("F3D_SWEEP4")) v.variant4 = std::atoi(e);
-    if (const char* e = std::getenv("F3D_TY16")) v.ty16 = std::atoi(e);
     if (const char* e = std::getenv("F3D_ZCHUNK")) v.zchunk = std::atoi(e);
     if (const char* e = std::getenv("F3D_WANT_WG")) v.want_wg = std::atol(e);
     return v;
@@ -2044,25 +1053,14 @@ const Tuning& tuning()
   return t;
 }
 
+// k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
 template <bool SWEEP>
 void launch_solver(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   const int planes = g.z_hi - g.z_lo;
-  if (t.variant == 1) {
-    dim3 grid;
-    int zchunk = pick_zchunk(g, &grid);
-    if (t.zchunk > 0) {
-      zchunk = t.zchunk;
-      grid.z = (planes + zchunk - 1) / zchunk;
-    }
-    hipLaunchKernelGGL(k_solver<SWEEP>, grid, dim3(kLanes, kTY, 1), 0, f3d::stream(), a, g, zchunk);
-    return;
-  }
-  const bool v3 = t.variant == 3;
-  const int ntx = (v3 && SWEEP && !t.aligned) ? (g.W + kOutX - 1) / kOutX : (g.W + kLanes - 1) / kLanes;
-  const int rows_per_wg = (v3 && SWEEP && t.variant4 == 3 && t.ty16) ? 16 : kTY3;
-  const int nty = v3 ? (g.H + rows_per_wg - 1) / rows_per_wg : (g.H + kOutRows - 1) / kOutRows;
+  const int ntx = (g.W + kLanes - 1) / kLanes;
+  const int nty = (g.H + kTY3 - 1) / kTY3;
   long nzc = (t.want_wg + static_cast<long>(ntx) * nty - 1) / (static_cast<long>(ntx) * nty);
   const long max_chunks = planes / 4 > 0 ? planes / 4 : 1;
   if (nzc > max_chunks) nzc = max_chunks;
@@ -2073,42 +1071,17 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = t.xcd_remap ? per_xcd * 8 : n_tiles;
+  const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
   if constexpr (SWEEP) {
-    if (v3) {
-      const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
-      auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
-      if (t.variant4 == 3) {
-        static const int ablate = std::getenv("F3D_ABLATE") ? std::atoi(std::getenv("F3D_ABLATE")) : 0;
-        if (ablate == 1) go(k_sweep6<1, kTY3>);
-        else if (ablate == 2) go(k_sweep6<2, kTY3>);
-        else if (ablate == 3) go(k_sweep6<3, kTY3>);
-        else if (t.ty16) hipLaunchKernelGGL((k_sweep6<0, 16>), grid, dim3(kLanes, 16, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap);
-        else go(k_sweep6<0, kTY3>);
-      } else if (t.variant4 == 2) {
-        go(k_sweep5);
-      } else if (t.variant4) {
-        go(k_sweep4);
-      } else if (t.aligned) {
-        if (t.cleanwait) go(k_sweep3<true, true>); else go(k_sweep3<true, false>);
-      } else {
-        if (t.cleanwait) go(k_sweep3<false, true>); else go(k_sweep3<false, false>);
-      }
-      return;
-    }
+    static const int ablate = std::getenv("F3D_ABLATE") ? std::atoi(std::getenv("F3D_ABLATE")) : 0;
+    if (ablate == 1) go(k_sweep6<1, kTY3>);
+    else if (ablate == 2) go(k_sweep6<2, kTY3>);
+    else if (ablate == 3) go(k_sweep6<3, kTY3>);
+    else go(k_sweep6<0, kTY3>);
+  } else {
+    go(k_phiksi6);
   }
-  if constexpr (!SWEEP) {
-    if (v3) {
-      if (t.variant4 == 3)
-        hipLaunchKernelGGL(k_phiksi6, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
-                           n_tiles, t.xcd_remap);
-      else
-        hipLaunchKernelGGL(k_phiksi3, dim3(blocks, 1, 1), dim3(kLanes, kTY3, 1), 0, f3d::stream(), a, g, zchunk, ntx, nty,
-                           n_tiles, t.xcd_remap);
-      return;
-    }
-  }
-  hipLaunchKernelGGL(k_solver_lds<SWEEP>, dim3(blocks, 1, 1), dim3(kLanes, kRows, 1), 0, f3d::stream(), a, g, zchunk, ntx,
-                     nty, n_tiles, t.xcd_remap);
 }
 
 template <int TY>

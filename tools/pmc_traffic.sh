@@ -1,6 +1,7 @@
 #!/bin/bash
-# HBM traffic of the whole bench run (per-dispatch FETCH_SIZE / WRITE_SIZE, separate passes) + calibration of FETCH_SIZE
-# on lab kernels with a known byte count (10 x 512^3 floats read once, 3 x written once).
+# HBM traffic of the solver kernels on one 512^3 level (tools/kbench.py): FETCH_SIZE and WRITE_SIZE in separate
+# rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section), plus the same two counters on lab kernels with a known byte
+# count (tools/lab/stream_lab: 10 x 512^3 floats read once, 3 x written once) as the calibration of the gfx950 factor.
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/traffic
@@ -8,20 +9,25 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- $R/tools/lab/bin/stream_lab > $O/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -- $R/tools/lab/bin/stream_lab > $O/cal_write.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/k_fetch -- python3 $R/tools/kbench.py --size 512 --reps 3 > $O/k_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/k_write -- python3 $R/tools/kbench.py --size 512 --reps 3 > $O/k_write.log 2>&1
 python3 - <<PY
-import csv, glob, collections
-for d in ("cal_fetch", "cal_write", "bench_fetch", "bench_write"):
+import csv, glob, collections, json
+res = {}
+for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
     f = glob.glob("$O/" + d + "/*/*counter_collection.csv")[0]
-    agg = collections.defaultdict(lambda: [0.0, 0])
+    agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"][:60], r["Counter_Name"])
-        agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
-    with open("$O/" + d + "_summary.csv", "w") as out:
-        out.write("kernel,counter,dispatches,sum,avg_per_dispatch\n")
-        for (k, c), (s, n) in sorted(agg.items()):
-            out.write(f'"{k}",{c},{n},{s:.6g},{s / n:.6g}\n')
-    print(open("$O/" + d + "_summary.csv").read())
+        n = r["Kernel_Name"]
+        for key in ("k_sweep7", "k_sweep6", "k_phiksi6", "k_flat", "k_march_packed", "k_march"):
+            if key in n:
+                if key == "k_flat":
+                    key = "k_flat<float4>" if "float4" in n or "HIP_vector" in n else "k_flat<float>"
+                agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                break
+    for (k, c), v in sorted(agg.items()):
+        res.setdefault(k, {})[c] = sum(v) / len(v)
+        print(f"{d:10s} {k:18s} {c:11s} launches {len(v):3d}  avg {sum(v) / len(v):.6g} KiB")
+json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
 PY
-rm -rf $O/bench_fetch $O/bench_write $O/cal_fetch $O/cal_write
+rm -rf $O/cal_fetch $O/cal_write $O/k_fetch $O/k_write
