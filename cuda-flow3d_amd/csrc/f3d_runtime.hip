@@ -131,6 +131,15 @@ void prof_end(int kernel)
 
 }  // namespace f3d
 
+// rows x words dwords of a pitched array set to one 32-bit pattern (grid.y strides over the rows)
+__global__ __launch_bounds__(256) void k_fill_rows(unsigned* __restrict__ p, size_t pitch_words, unsigned word, unsigned words,
+                                                   unsigned rows)
+{
+  const unsigned x = blockIdx.x * 256u + threadIdx.x;
+  if (x >= words) return;
+  for (unsigned r = blockIdx.y; r < rows; r += gridDim.y) p[static_cast<size_t>(r) * pitch_words + x] = word;
+}
+
 extern "C" {
 
 const char* f3d_last_error(void) { return g_error; }
@@ -227,6 +236,20 @@ int f3d_free(f3d_devptr ptr)
 int f3d_memset2d(f3d_devptr ptr, size_t pitch, int value, size_t width_bytes, size_t rows)
 {
   F3D_REQUIRE_READY("f3d_memset2d");
+  if (width_bytes == 0 || rows == 0) return 0;
+  // The driver clears du, dv, dw with this once per level: dword-aligned rows go through a plain fill kernel (the
+  // runtime's 2-D fill reaches ~0.3 TB/s on a 512^3 sub-box), anything else through hipMemset2DAsync.
+  if (pitch % 4 == 0 && width_bytes % 4 == 0 && (static_cast<uintptr_t>(ptr) % 4) == 0 && width_bytes <= pitch &&
+      rows <= 0x7fffffffu) {
+    const unsigned b = static_cast<unsigned>(value) & 0xffu;
+    const unsigned word = b | (b << 8) | (b << 16) | (b << 24);
+    const unsigned words = static_cast<unsigned>(width_bytes / 4);
+    const dim3 block(256, 1, 1), grid((words + 255) / 256, static_cast<unsigned>(rows > 65535 ? 65535 : rows), 1);
+    hipLaunchKernelGGL(k_fill_rows, grid, block, 0, S.stream, f3d_ptr<unsigned>(ptr), static_cast<size_t>(pitch / 4), word, words,
+                       static_cast<unsigned>(rows));
+    F3D_HIP(hipGetLastError());
+    return 0;
+  }
   F3D_HIP(hipMemset2DAsync(f3d_ptr<void>(ptr), pitch, value, width_bytes, rows, S.stream));
   return 0;
 }

@@ -227,10 +227,20 @@ __device__ __forceinline__ void gld_lds_lane(const float* lane_addr, float* lds_
   // read M0 in the cycle after a scalar write of it (one wait state; nobody inserts it inside inline assembly)
   asm volatile("s_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(lane_addr), "{m0}"(m0v) : "memory");
 }
+// The registers a hand-issued load writes are, to the compiler, defined at the load statement: nothing stops it from
+// copying them (a v_mov for a tied asm operand, a control-flow merge, a loop back edge) while the data is still on its way.
+// So the wait is a statement of its own with NO register operands, and only the empty statement after it hands the
+// registers back through "+v": whatever copies the compiler makes for those operands then come after the s_waitcnt.
+// tests/test_isa_hazards.py scans the generated code of every kernel here for any read of a load's destination between
+// the load and the wait that covers it, so a copy inserted elsewhere fails the build check instead of a parity test
+// once in a few hundred launches.
 #define F3D_WAIT_PLANE(N, P)                                                                                           \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
-               : "+v"((P).f0), "+v"((P).f1), "+v"((P).phi), "+v"((P).u), "+v"((P).v), "+v"((P).w), "+v"((P).su),       \
-                 "+v"((P).dv), "+v"((P).dw), "+v"((P).ksi)::"memory")
+  do {                                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                                                              \
+    asm volatile(""                                                                                                    \
+                 : "+v"((P).f0), "+v"((P).f1), "+v"((P).phi), "+v"((P).u), "+v"((P).v), "+v"((P).w), "+v"((P).su),     \
+                   "+v"((P).dv), "+v"((P).dw), "+v"((P).ksi)::"memory");                                              \
+  } while (0)
 
 // ABLATE (timing experiments only, results are wrong): 1 = no arithmetic, 2 = no halo traffic, 3 = no LDS exchange
 template <int ABLATE, int TY>
@@ -450,9 +460,12 @@ struct Plane8 {
 // two steps ahead, next plane published right after the barrier) for the eight inputs of A.3, all of them stencilled
 // (the central differences of A.3 do not factor, there is nothing to pre-combine).
 #define F3D_WAIT_PLANE8(N, P)                                                                                          \
-  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                               \
-               : "+v"((P).v[0]), "+v"((P).v[1]), "+v"((P).v[2]), "+v"((P).v[3]), "+v"((P).v[4]), "+v"((P).v[5]),       \
-                 "+v"((P).v[6]), "+v"((P).v[7])::"memory")
+  do {                                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                                                              \
+    asm volatile(""                                                                                                    \
+                 : "+v"((P).v[0]), "+v"((P).v[1]), "+v"((P).v[2]), "+v"((P).v[3]), "+v"((P).v[4]), "+v"((P).v[5]),     \
+                   "+v"((P).v[6]), "+v"((P).v[7])::"memory");                                                         \
+  } while (0)
 
 __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                              int xcd_remap)

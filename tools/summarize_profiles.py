@@ -31,9 +31,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k_sweep3" in r["Kernel_Name"] or "k_phiksi3" in r["Kernel_Name"] or "k_cal" in r["Kernel_Name"]:
-            name = "k_sweep3" if "k_sweep3" in r["Kernel_Name"] else ("k_phiksi3" if "k_phiksi3" in r["Kernel_Name"] else r["Kernel_Name"][:40])
-            agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for name in ("k_sweep7", "k_sweep6", "k_phiksi6"):
+            if name in r["Kernel_Name"]:
+                agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(agg.items()):
         lines.append(f"| {k} | {c} | {sum(v) / len(v):.6g} |")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
