@@ -166,14 +166,21 @@ def run_multi(args):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    pkg.check(pkg.hip().f3d_init(local_rank), "f3d_init")
+    device = local_rank
+    if os.environ.get("F3D_COMM_BACKEND") == "shm":
+        # rehearsal on a box with fewer GPUs than ranks: the ranks share the devices and the halos travel through
+        # shared memory instead of RCCL (which refuses two ranks on one device); never used for a reported number
+        count = C.c_int()
+        pkg.check(pkg.hip().f3d_device_count(C.byref(count)), "f3d_device_count")
+        device = local_rank % max(1, count.value)
+    pkg.check(pkg.hip().f3d_init(device), "f3d_init")
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     box = [pkg.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    pkg.comm_init(box[0], rank, world, device=local_rank)
+    pkg.comm_init(box[0], rank, world, device=device)
 
     S = args.size
     halo = 16
@@ -236,7 +243,9 @@ def run_multi(args):
                                    "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
                                    "frames resident in HBM",
                        "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
-                                      "iteration (6 planes of du, dv, dw)"},
+                                      "iteration (6 planes of du, dv, dw)"
+                                      + (" -- REHEARSAL: shared-memory transport, ranks share devices"
+                                         if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_sweep7 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
                                                    "slab incl. widened windows",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

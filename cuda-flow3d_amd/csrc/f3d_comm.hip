@@ -1,10 +1,24 @@
 // z-slab communication layer: plane pack/unpack kernels and neighbour exchange on RCCL (ncclSend/ncclRecv over
 // xGMI).  The reference is single-GPU; this is new design.  librccl.so.1 is opened lazily with
 // dlopen so that single-GPU users never load it.  All traffic runs on the library stream, in order with the kernels.
+//
+// Rehearsal transport (F3D_COMM_BACKEND=shm, never the default): RCCL refuses two ranks on one device, so a box with
+// fewer GPUs than ranks cannot run the one-process-per-rank driver at all.  With this backend the same calls move the
+// packed halos through POSIX shared memory (device -> host mailbox of the sender, mailbox -> device of the receiver), which
+// lets N processes share one GPU: it exists to test the multi-process orchestration, not to be fast.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 
 #include "f3d_internal.h"
 
@@ -48,6 +62,158 @@ int load_rccl()
   F3D_SYM(AllReduce, "ncclAllReduce");
   F3D_SYM(GetErrorString, "ncclGetErrorString");
 #undef F3D_SYM
+  return 0;
+}
+
+// ---- shared-memory rehearsal transport ---------------------------------------------------------------------------------
+constexpr int kShmMaxRanks = 16;
+struct ShmHeader {
+  std::atomic<unsigned long long> posted[kShmMaxRanks];  // messages this rank has put into its outbox for rank d
+  std::atomic<unsigned long long> taken[kShmMaxRanks];   // ... and how many of them rank d has copied out
+  std::atomic<unsigned long long> red_seq;               // all-reduce rounds this rank has entered
+  float red_val[2];                                      // its contribution, by round parity
+};
+struct Shm {
+  bool active = false;
+  std::string session;
+  int rank = 0, n_ranks = 1;
+  size_t cap_floats = 0;       // capacity of one outbox
+  size_t bytes = 0;            // size of one rank's segment
+  char* seg[kShmMaxRanks] = {};
+  unsigned long long red_round = 0;
+} M;
+
+std::string shm_name(const std::string& session, int rank) { return "/f3d_" + session + "_" + std::to_string(rank); }
+ShmHeader* shm_header(int rank) { return reinterpret_cast<ShmHeader*>(M.seg[rank]); }
+float* shm_outbox(int owner, int dest)
+{
+  return reinterpret_cast<float*>(M.seg[owner] + 4096) + static_cast<size_t>(dest) * M.cap_floats;
+}
+
+int shm_attach(int rank)  // maps rank's segment, waiting for its owner to create it
+{
+  if (M.seg[rank]) return 0;
+  const std::string name = shm_name(M.session, rank);
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+  for (;;) {
+    const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+    if (fd >= 0) {
+      off_t size = lseek(fd, 0, SEEK_END);
+      if (size >= static_cast<off_t>(M.bytes)) {
+        void* p = mmap(nullptr, M.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return f3d::fail("f3d_comm (shm): cannot map %s", name.c_str());
+        M.seg[rank] = static_cast<char*>(p);
+        return 0;
+      }
+      close(fd);
+    }
+    if (std::chrono::steady_clock::now() > deadline) return f3d::fail("f3d_comm (shm): rank %d never created %s", rank, name.c_str());
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  }
+}
+
+template <typename Pred>
+int shm_wait(Pred done, const char* what, int peer)
+{
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+  for (unsigned spin = 0; !done(); ++spin) {
+    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 0xfff) == 0 && std::chrono::steady_clock::now() > deadline)
+      return f3d::fail("f3d_comm (shm): rank %d timed out waiting for rank %d (%s)", M.rank, peer, what);
+  }
+  return 0;
+}
+
+int shm_init(const char* id128, int rank, int n_ranks)
+{
+  if (n_ranks > kShmMaxRanks) return f3d::fail("f3d_comm (shm): at most %d ranks", kShmMaxRanks);
+  M.session.assign(id128 + 7, strnlen(id128 + 7, 100));
+  M.rank = rank;
+  M.n_ranks = n_ranks;
+  const char* cap = std::getenv("F3D_SHM_CAP_MB");
+  M.cap_floats = static_cast<size_t>(cap ? std::atol(cap) : 64) * (1u << 20) / sizeof(float);
+  M.bytes = 4096 + static_cast<size_t>(n_ranks) * M.cap_floats * sizeof(float);  // pages are committed on first touch
+  const std::string name = shm_name(M.session, rank);
+  shm_unlink(name.c_str());
+  const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return f3d::fail("f3d_comm (shm): cannot create %s", name.c_str());
+  // a peer maps the segment only once it has its final size; a fresh tmpfs file reads as zeros, so every counter in
+  // the header starts at 0 without this rank writing it
+  if (ftruncate(fd, static_cast<off_t>(M.bytes)) != 0) {
+    close(fd);
+    return f3d::fail("f3d_comm (shm): cannot size %s to %zu bytes", name.c_str(), M.bytes);
+  }
+  void* p = mmap(nullptr, M.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return f3d::fail("f3d_comm (shm): cannot map %s", name.c_str());
+  M.seg[rank] = static_cast<char*>(p);  // a fresh tmpfs file reads as zeros: all counters start at 0
+  M.active = true;
+  M.red_round = 0;
+  return 0;
+}
+
+void shm_destroy()
+{
+  if (!M.active) return;
+  for (int r = 0; r < kShmMaxRanks; ++r)
+    if (M.seg[r]) {
+      munmap(M.seg[r], M.bytes);
+      M.seg[r] = nullptr;
+    }
+  shm_unlink(shm_name(M.session, M.rank).c_str());
+  M.active = false;
+}
+
+int shm_sendrecv(const float* send_buf, const size_t* send_offset, const size_t* send_count, float* recv_buf,
+                 const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers)
+{
+  F3D_HIP(hipStreamSynchronize(f3d::stream()));  // the pack kernel has filled the staging buffer
+  ShmHeader* mine = shm_header(M.rank);
+  for (int i = 0; i < n_peers; ++i) {
+    const int d = peers[i];
+    if (d < 0 || d >= M.n_ranks) return f3d::fail("f3d_comm_sendrecv: bad peer %d", d);
+    if (!send_count[i]) continue;
+    if (send_count[i] > M.cap_floats)
+      return f3d::fail("f3d_comm (shm): message of %zu floats exceeds the outbox (%zu); raise F3D_SHM_CAP_MB", send_count[i], M.cap_floats);
+    if (shm_wait([&] { return mine->taken[d].load(std::memory_order_acquire) == mine->posted[d].load(std::memory_order_relaxed); },
+                 "outbox free", d))
+      return 1;
+    F3D_HIP(hipMemcpy(shm_outbox(M.rank, d), send_buf + send_offset[i], send_count[i] * sizeof(float), hipMemcpyDeviceToHost));
+    mine->posted[d].fetch_add(1, std::memory_order_release);
+  }
+  for (int i = 0; i < n_peers; ++i) {
+    const int s = peers[i];
+    if (!recv_count[i]) continue;
+    if (shm_attach(s)) return 1;
+    ShmHeader* theirs = shm_header(s);
+    if (shm_wait([&] { return theirs->posted[M.rank].load(std::memory_order_acquire) > theirs->taken[M.rank].load(std::memory_order_relaxed); },
+                 "message", s))
+      return 1;
+    F3D_HIP(hipMemcpy(recv_buf + recv_offset[i], shm_outbox(s, M.rank), recv_count[i] * sizeof(float), hipMemcpyHostToDevice));
+    theirs->taken[M.rank].fetch_add(1, std::memory_order_release);
+  }
+  return 0;
+}
+
+int shm_allreduce_max(float* value)
+{
+  ShmHeader* mine = shm_header(M.rank);
+  const unsigned long long round = ++M.red_round;
+  mine->red_val[round & 1] = *value;
+  mine->red_seq.store(round, std::memory_order_release);
+  float m = *value;
+  for (int r = 0; r < M.n_ranks; ++r) {
+    if (r == M.rank) continue;
+    if (shm_attach(r)) return 1;
+    ShmHeader* theirs = shm_header(r);
+    // a rank can be at most one round ahead (it needs everybody's value of this round to leave it), so the slot of this
+    // round's parity still holds this round's value when we read it
+    if (shm_wait([&] { return theirs->red_seq.load(std::memory_order_acquire) >= round; }, "all-reduce", r)) return 1;
+    const float v = theirs->red_val[round & 1];
+    if (v > m) m = v;
+  }
+  *value = m;
   return 0;
 }
 
@@ -121,6 +287,12 @@ int check_planes(int plane0, int count, size_t width, size_t height, const char*
   return 0;
 }
 
+bool want_shm()
+{
+  const char* e = std::getenv("F3D_COMM_BACKEND");
+  return e && std::strcmp(e, "shm") == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,6 +300,12 @@ extern "C" {
 int f3d_comm_unique_id(void* id128)
 {
   if (!id128) return f3d::fail("f3d_comm_unique_id: null argument");
+  if (want_shm()) {  // "f3dshm:" + a session name unique to this launch
+    std::memset(id128, 0, 128);
+    std::snprintf(static_cast<char*>(id128), 128, "f3dshm:%d_%llx", static_cast<int>(getpid()),
+                  static_cast<unsigned long long>(std::chrono::steady_clock::now().time_since_epoch().count()));
+    return 0;
+  }
   if (load_rccl()) return 1;
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
   ncclUniqueId id;
@@ -140,7 +318,13 @@ int f3d_comm_init(const void* id128, int rank, int n_ranks)
 {
   F3D_REQUIRE_READY("f3d_comm_init");
   if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return f3d::fail("f3d_comm_init: bad arguments");
-  if (R.comm) return f3d::fail("f3d_comm_init: communicator already initialised");
+  if (R.comm || M.active) return f3d::fail("f3d_comm_init: communicator already initialised");
+  if (std::memcmp(id128, "f3dshm:", 7) == 0) {
+    if (shm_init(static_cast<const char*>(id128), rank, n_ranks)) return 1;
+    R.rank = rank;
+    R.n_ranks = n_ranks;
+    return 0;
+  }
   if (load_rccl()) return 1;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
@@ -153,6 +337,7 @@ int f3d_comm_init(const void* id128, int rank, int n_ranks)
 
 int f3d_comm_destroy(void)
 {
+  shm_destroy();
   if (R.comm) {
     (void)hipStreamSynchronize(f3d::stream());
     (void)R.CommDestroy(R.comm);
@@ -264,6 +449,9 @@ int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size
                       const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers)
 {
   F3D_REQUIRE_READY("f3d_comm_sendrecv");
+  if (M.active)
+    return shm_sendrecv(f3d_ptr<const float>(send_buf), send_offset, send_count, f3d_ptr<float>(recv_buf), recv_offset, recv_count,
+                        peers, n_peers);
   if (!R.comm) return f3d::fail("f3d_comm_sendrecv: f3d_comm_init() has not been called");
   F3D_NCCL(R.GroupStart());
   for (int i = 0; i < n_peers; ++i) {
@@ -284,6 +472,7 @@ int f3d_comm_allreduce_max_f32(float* value)
 {
   F3D_REQUIRE_READY("f3d_comm_allreduce_max_f32");
   if (!value) return f3d::fail("f3d_comm_allreduce_max_f32: null argument");
+  if (M.active) return M.n_ranks == 1 ? 0 : shm_allreduce_max(value);
   if (!R.comm || R.n_ranks == 1) return 0;
   F3D_HIP(hipMemcpyAsync(R.d_scalar, value, sizeof(float), hipMemcpyHostToDevice, f3d::stream()));
   F3D_NCCL(R.AllReduce(R.d_scalar, R.d_scalar, 1, ncclFloat, ncclMax, R.comm, f3d::stream()));

@@ -1,0 +1,57 @@
+"""The one-process-per-rank slab driver, for real: N processes, each with its own HIP context, drive OpticalFlowSlab with
+local_ranks = {rank} exactly as bench.py --gpus N does; only the transport differs (shared-memory mailboxes instead of
+RCCL, because RCCL refuses two ranks on one device and the box has one GPU).  The union of the slabs must equal the
+single-GPU flow bit for bit."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+from conftest import same
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_ranks(n, dims, tmp_path, **kw):
+    session = uuid.uuid4().hex[:12]
+    procs, outs = [], []
+    for r in range(n):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        cmd = [sys.executable, os.path.join(HERE, "slab_proc_worker.py"), str(r), str(n), session, *map(str, dims), out]
+        cmd += [f"{k}={v}" for k, v in kw.items()]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-2000:]}"
+    parts = [np.load(o) for o in outs]
+    return [sum(p[c] for p in parts) for c in "uvw"]   # slabs are disjoint, the other planes are zero
+
+
+@pytest.mark.parametrize("n_ranks,dims,kw", [
+    (2, (48, 40, 44), dict(warp_levels_count=14, outer_iterations_count=4)),
+    (3, (70, 33, 26), dict(warp_levels_count=9, outer_iterations_count=3, inner_iterations_count=3, median_radius=3)),
+    (4, (40, 36, 40), dict()),   # full defaults: thin slabs, ranks that own nothing on coarse levels, multi-hop halos
+])
+def test_processes_equal_single_gpu(f3d, tmp_path, n_ranks, dims, kw):
+    W, H, D = dims
+    f0, f1 = f3d.synth_pair(W, H, D)
+    flow = f3d.OpticalFlow()
+    flow.initialize(W, H, D)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(n_ranks, dims, tmp_path, **kw)
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} processes: component {c} differs, max {np.abs(g - e).max():.3e}"
