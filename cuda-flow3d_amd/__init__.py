@@ -102,6 +102,8 @@ def hip():
         "f3d_pack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_unpack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
+        "f3d_comm_sendrecv_begin": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
+        "f3d_comm_sendrecv_end": [],
         "f3d_comm_allreduce_max_f32": [_fp],
     }
     for name, args in sig.items():
@@ -143,6 +145,7 @@ def host():
         "f3d_slabflow_upload": [C.c_void_p, _fp, _fp],
         "f3d_slabflow_compute_resident": [C.c_void_p, pp, _fp],
         "f3d_slabflow_download": [C.c_void_p, _fp, _fp, _fp],
+        "f3d_slabflow_overlapped_iterations": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_destroy": [C.c_void_p],
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
@@ -510,6 +513,11 @@ class SlabOpticalFlow:
         u, v, ww = (np.zeros((d, h, w), np.float32) for _ in range(3))
         check(host().f3d_slabflow_download(self._h, u.ctypes.data_as(_fp), v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)))
         return u, v, ww
+
+    def overlapped_iterations(self):
+        n = _sz()
+        check(host().f3d_slabflow_overlapped_iterations(self._h, C.byref(n)))
+        return n.value
 
     def destroy(self):
         if self._h:

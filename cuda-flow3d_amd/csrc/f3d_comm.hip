@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 #include <thread>
 
 #include "f3d_internal.h"
@@ -38,7 +39,19 @@ struct Rccl {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
   float* d_scalar = nullptr;
+  // split exchange (f3d_comm_sendrecv_begin / _end): the transfer runs on its own stream beside the kernels
+  hipStream_t side = nullptr;
+  hipEvent_t packed = nullptr, arrived = nullptr;
+  bool open = false;
 } R;
+
+// the shared-memory backend has no second engine: _begin records the request, _end performs it
+struct Pending {
+  std::vector<size_t> send_offset, send_count, recv_offset, recv_count;
+  std::vector<int> peers;
+  const float* send_buf = nullptr;
+  float* recv_buf = nullptr;
+} Q;
 
 int load_rccl()
 {
@@ -338,6 +351,15 @@ int f3d_comm_init(const void* id128, int rank, int n_ranks)
 int f3d_comm_destroy(void)
 {
   shm_destroy();
+  R.open = false;
+  if (R.side) {
+    (void)hipStreamSynchronize(R.side);
+    (void)hipEventDestroy(R.packed);
+    (void)hipEventDestroy(R.arrived);
+    (void)hipStreamDestroy(R.side);
+    R.side = nullptr;
+    R.packed = R.arrived = nullptr;
+  }
   if (R.comm) {
     (void)hipStreamSynchronize(f3d::stream());
     (void)R.CommDestroy(R.comm);
@@ -465,6 +487,61 @@ int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size
       F3D_NCCL(R.Recv(f3d_ptr<float>(recv_buf) + recv_offset[i], recv_count[i], ncclFloat, peers[i], R.comm, f3d::stream()));
   }
   F3D_NCCL(R.GroupEnd());
+  return 0;
+}
+
+int f3d_comm_sendrecv_begin(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
+                            const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers)
+{
+  F3D_REQUIRE_READY("f3d_comm_sendrecv_begin");
+  if (R.open) return f3d::fail("f3d_comm_sendrecv_begin: the previous exchange has not been ended");
+  if (M.active) {
+    Q.send_offset.assign(send_offset, send_offset + n_peers);
+    Q.send_count.assign(send_count, send_count + n_peers);
+    Q.recv_offset.assign(recv_offset, recv_offset + n_peers);
+    Q.recv_count.assign(recv_count, recv_count + n_peers);
+    Q.peers.assign(peers, peers + n_peers);
+    Q.send_buf = f3d_ptr<const float>(send_buf);
+    Q.recv_buf = f3d_ptr<float>(recv_buf);
+    // the staging buffer must be complete now: kernels issued after this call may overwrite what was packed from
+    F3D_HIP(hipStreamSynchronize(f3d::stream()));
+    R.open = true;
+    return 0;
+  }
+  if (!R.comm) return f3d::fail("f3d_comm_sendrecv_begin: f3d_comm_init() has not been called");
+  if (!R.side) {
+    F3D_HIP(hipStreamCreateWithFlags(&R.side, hipStreamNonBlocking));
+    F3D_HIP(hipEventCreateWithFlags(&R.packed, hipEventDisableTiming));
+    F3D_HIP(hipEventCreateWithFlags(&R.arrived, hipEventDisableTiming));
+  }
+  F3D_HIP(hipEventRecord(R.packed, f3d::stream()));
+  F3D_HIP(hipStreamWaitEvent(R.side, R.packed, 0));
+  F3D_NCCL(R.GroupStart());
+  for (int i = 0; i < n_peers; ++i) {
+    if (peers[i] < 0 || peers[i] >= R.n_ranks) {
+      (void)R.GroupEnd();
+      return f3d::fail("f3d_comm_sendrecv_begin: bad peer %d", peers[i]);
+    }
+    if (send_count[i])
+      F3D_NCCL(R.Send(f3d_ptr<const float>(send_buf) + send_offset[i], send_count[i], ncclFloat, peers[i], R.comm, R.side));
+    if (recv_count[i])
+      F3D_NCCL(R.Recv(f3d_ptr<float>(recv_buf) + recv_offset[i], recv_count[i], ncclFloat, peers[i], R.comm, R.side));
+  }
+  F3D_NCCL(R.GroupEnd());
+  F3D_HIP(hipEventRecord(R.arrived, R.side));
+  R.open = true;
+  return 0;
+}
+
+int f3d_comm_sendrecv_end(void)
+{
+  F3D_REQUIRE_READY("f3d_comm_sendrecv_end");
+  if (!R.open) return f3d::fail("f3d_comm_sendrecv_end: no exchange is open");
+  R.open = false;
+  if (M.active)
+    return shm_sendrecv(Q.send_buf, Q.send_offset.data(), Q.send_count.data(), Q.recv_buf, Q.recv_offset.data(), Q.recv_count.data(),
+                        Q.peers.data(), static_cast<int>(Q.peers.size()));
+  F3D_HIP(hipStreamWaitEvent(f3d::stream(), R.arrived, 0));
   return 0;
 }
 

@@ -337,6 +337,13 @@ int f3d_slabflow_compute(f3d_slabflow flow, const float* frame_0, const float* f
   return f3d_slabflow_download(flow, u, v, w);
 }
 
+int f3d_slabflow_overlapped_iterations(f3d_slabflow flow, size_t* count)
+{
+  if (!flow || !count) return 1;
+  *count = flow->driver->OverlappedIterations();
+  return 0;
+}
+
 int f3d_slabflow_destroy(f3d_slabflow flow)
 {
   delete flow;

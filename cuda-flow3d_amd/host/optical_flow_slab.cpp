@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 #include "common_utils.h"
@@ -11,6 +12,9 @@
 OpticalFlowSlab::OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int halo_capacity)
     : OpticalFlowBase("Optical Flow z-slab Multi GPU"), n_ranks_(n_ranks), local_ranks_(std::move(local_ranks)), halo_(halo_capacity)
 {
+  // slabs at least this thick run the overlapped order (0 = never); thinner ones have too little interior to hide anything
+  const char* e = std::getenv("F3D_OVERLAP_MIN_PLANES");
+  overlap_min_planes_ = e ? std::atoi(e) : 32;
 }
 
 OpticalFlowSlab::~OpticalFlowSlab() { Destroy(); }
@@ -97,7 +101,6 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
     failed_ = true;
     return false;
   }
-  const size_t plane = width * height;
   if (locals_.size() > 1) {  // every rank lives here: copy planes between their containers
     for (Local& me : locals_) {
       const int my_base = ZBase(depth, me.rank);
@@ -114,33 +117,41 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
     return true;
   }
   // one rank per process: pack -> grouped send/recv -> unpack
+  return ExchangeBegin(depth, width, height, roles, roles, need_lo, need_hi) && ExchangeEnd(width, height);
+}
+
+bool OpticalFlowSlab::ExchangeBegin(int depth, size_t width, size_t height, const std::vector<Role>& send_roles,
+                                    const std::vector<Role>& recv_roles, int need_lo, int need_hi)
+{
+  const size_t plane = width * height;
   Local& me = locals_[0];
   const int my_base = ZBase(depth, me.rank);
   const std::vector<HaloTransfer> plan = PlanHaloExchange(depth, me.rank, n_ranks_, need_lo, need_hi);
   std::vector<size_t> s_off, s_cnt, r_off, r_cnt;
   std::vector<int> peers;
   // one pack launch, one grouped send/recv, one unpack launch per exchange
-  std::vector<f3d_devptr> pk_field, up_field;
-  std::vector<int> pk_plane, pk_count, up_plane, up_count;
-  std::vector<size_t> pk_off, up_off;
+  std::vector<f3d_devptr> pk_field;
+  std::vector<int> pk_plane, pk_count;
+  std::vector<size_t> pk_off;
+  unpack_ = Unpack();
   size_t s_pos = 0, r_pos = 0;
   for (const HaloTransfer& t : plan) {
     peers.push_back(t.peer);
     s_off.push_back(s_pos);
     r_off.push_back(r_pos);
-    for (Role role : roles) {
+    for (size_t k = 0; k < send_roles.size(); ++k) {
       if (!t.send.empty()) {
-        pk_field.push_back(me.buf[role]);
+        pk_field.push_back(me.buf[send_roles[k]]);
         pk_plane.push_back(t.send.lo - my_base);
         pk_count.push_back(t.send.size());
         pk_off.push_back(s_pos);
         s_pos += static_cast<size_t>(t.send.size()) * plane;
       }
       if (!t.recv.empty()) {
-        up_field.push_back(me.buf[role]);
-        up_plane.push_back(t.recv.lo - my_base);
-        up_count.push_back(t.recv.size());
-        up_off.push_back(r_pos);
+        unpack_.field.push_back(me.buf[recv_roles[k]]);
+        unpack_.plane.push_back(t.recv.lo - my_base);
+        unpack_.count.push_back(t.recv.size());
+        unpack_.offset.push_back(r_pos);
         r_pos += static_cast<size_t>(t.recv.size()) * plane;
       }
     }
@@ -152,18 +163,106 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
     failed_ = true;
     return false;
   }
-  if (peers.empty()) return true;
   constexpr size_t kBatch = 32;  // segments per launch (f3d_pack_segments limit)
   for (size_t i = 0; i < pk_field.size(); i += kBatch) {
     const int n = static_cast<int>(std::min(kBatch, pk_field.size() - i));
     if (!Check(f3d_pack_segments(&pk_field[i], &pk_plane[i], &pk_count[i], &pk_off[i], n, width, height, stage_send_))) return false;
   }
-  if (!Check(f3d_comm_sendrecv(stage_send_, s_off.data(), s_cnt.data(), stage_recv_, r_off.data(), r_cnt.data(), peers.data(),
-                               static_cast<int>(peers.size()))))
-    return false;
-  for (size_t i = 0; i < up_field.size(); i += kBatch) {
-    const int n = static_cast<int>(std::min(kBatch, up_field.size() - i));
-    if (!Check(f3d_unpack_segments(&up_field[i], &up_plane[i], &up_count[i], &up_off[i], n, width, height, stage_recv_))) return false;
+  return Check(f3d_comm_sendrecv_begin(stage_send_, s_off.data(), s_cnt.data(), stage_recv_, r_off.data(), r_cnt.data(), peers.data(),
+                                       static_cast<int>(peers.size())));
+}
+
+bool OpticalFlowSlab::ExchangeEnd(size_t width, size_t height)
+{
+  if (!Check(f3d_comm_sendrecv_end())) return false;
+  constexpr size_t kBatch = 32;
+  for (size_t i = 0; i < unpack_.field.size(); i += kBatch) {
+    const int n = static_cast<int>(std::min(kBatch, unpack_.field.size() - i));
+    if (!Check(f3d_unpack_segments(&unpack_.field[i], &unpack_.plane[i], &unpack_.count[i], &unpack_.offset[i], n, width, height,
+                                   stage_recv_)))
+      return false;
+  }
+  return true;
+}
+
+// One outer iteration (phi/ksi + K sweeps) of a rank that has neighbours, ordered so that the exchange of the new
+// increments runs beside most of the arithmetic.  With own planes [a, b), H = K + 1 planes travelling each way and R_s
+// sweeps still to come after stage s (a stage = a fused pair or a single sweep):
+//   * the LOW ZONE of stage s is [a - R_s, a + H + R_s), the HIGH ZONE [b - H - R_s, b + R_s): the cone of dependence of
+//     the H planes a neighbour needs.  Both zones go through phi/ksi and all stages first; the last stage writes its H
+//     planes into the edge containers (EDU, EDV, EDW), from which they are packed and sent;
+//   * the INTERIOR [a + H + R_s, b - H - R_s) follows while the transfer is in flight.  Stage s of the interior reads
+//     what stage s-1 wrote in the zones and in the interior alike (same containers).  The ping-pong containers never
+//     clash: a zone's stage-s output ends exactly where the interior's stage-(s-1) input begins -- except for the last
+//     stage, whose zone output would overwrite planes the interior's last-but-one stage still reads; hence the edge
+//     containers, copied into place at the end;
+//   * finally the received halos are unpacked.  Every voxel is computed once, by the same kernels on the same inputs as in
+//     the plain order, so the bits do not change (tests/test_gpu_slab_procs.py).
+bool OpticalFlowSlab::SweepsOverlapped(Local& l, int D, size_t W, size_t H, int K, float hx, float hy, float hz,
+                                       float equation_alpha, float equation_smoothness, float equation_data)
+{
+  const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+  const int a = own.lo, b = own.hi, Hs = K + 1;
+  const bool has_lo = a > 0, has_hi = b < D;
+  struct Stage {
+    bool pair;
+    int rest;  // sweeps still to come after this stage
+  };
+  std::vector<Stage> stages;
+  for (int j = 0; j < K;) {
+    const bool pair = FusedSweepsEnabled() && j + 2 <= K;
+    j += pair ? 2 : 1;
+    stages.push_back({pair, K - j});
+  }
+  auto slab = [&](int lo, int hi) {
+    f3d_slab s;
+    s.z_base = a - halo_;
+    s.z_lo = std::max(0, lo);
+    s.z_hi = std::min(D, hi);
+    if (s.z_hi < s.z_lo) s.z_hi = s.z_lo;
+    return s;
+  };
+  enum Zone { LOW, HIGH, INNER };
+  auto zone = [&](Zone z, int grow) {
+    const int lo_edge = a + Hs + grow, hi_edge = b - Hs - grow;
+    if (z == LOW) return slab(a - grow, lo_edge);
+    if (z == HIGH) return slab(hi_edge, b + grow);
+    return slab(has_lo ? lo_edge : a - grow, has_hi ? hi_edge : b + grow);
+  };
+  const Role cur[3] = {DU, DV, DW}, tmp[3] = {TDU, TDV, TDW}, edge[3] = {EDU, EDV, EDW};
+  auto phi = [&](const f3d_slab& win) {
+    return Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy, hz,
+                             equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &win));
+  };
+  auto stage = [&](size_t s, const f3d_slab& win, bool to_edge) {
+    const Role* in = (s % 2 == 0) ? cur : tmp;
+    const Role* out = to_edge ? edge : ((s % 2 == 0) ? tmp : cur);
+    auto* fn = stages[s].pair ? f3d_solve_sweep2 : f3d_solve_sweep;
+    return Check(fn(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]], l.buf[in[2]], l.buf[PHI],
+                    l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]], &win));
+  };
+  const size_t last = stages.size() - 1;
+  const Role* final_out = (last % 2 == 0) ? tmp : cur;
+  for (Zone z : {LOW, HIGH}) {
+    if ((z == LOW && !has_lo) || (z == HIGH && !has_hi)) continue;
+    if (!phi(zone(z, K))) return false;
+    for (size_t s = 0; s <= last; ++s)
+      if (!stage(s, zone(z, stages[s].rest), s == last)) return false;
+  }
+  if (!ExchangeBegin(D, W, H, {edge[0], edge[1], edge[2]}, {final_out[0], final_out[1], final_out[2]}, Hs, Hs)) return false;
+  if (!phi(zone(INNER, K))) return false;
+  for (size_t s = 0; s <= last; ++s)
+    if (!stage(s, zone(INNER, stages[s].rest), false)) return false;
+  const int base = a - halo_;
+  for (int k = 0; k < 3; ++k) {
+    if (has_lo && !Check(f3d_copy_planes(l.buf[final_out[k]], a - base, l.buf[edge[k]], a - base, Hs, W, H))) return false;
+    if (has_hi && !Check(f3d_copy_planes(l.buf[final_out[k]], b - Hs - base, l.buf[edge[k]], b - Hs - base, Hs, W, H))) return false;
+  }
+  if (!ExchangeEnd(W, H)) return false;
+  if (final_out == tmp) {
+    std::swap(l.buf[DU], l.buf[TDU]);
+    std::swap(l.buf[DV], l.buf[TDV]);
+    std::swap(l.buf[DW], l.buf[TDW]);
   }
   return true;
 }
@@ -230,6 +329,7 @@ bool OpticalFlowSlab::ComputeResident(OperationParameters& params)
 
 bool OpticalFlowSlab::Pyramid(OperationParameters& params)
 {
+  overlapped_iterations_ = 0;
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
   GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
@@ -376,7 +476,17 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     for (Local& l : locals_)
       for (Role r : {DU, DV, DW})
         if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, W * sizeof(float), crows))) return false;
+    // Overlapped order: one rank per process, a slab thick enough that zones and interior are distinct, and an exchange
+    // to hide (not after the last outer iteration)
+    const PlaneRange own_here = OwnedPlanes(D, locals_[0].rank, n_ranks_);
+    const bool can_overlap = locals_.size() == 1 && n_ranks_ > 1 && overlap_min_planes_ > 0 &&
+                             own_here.size() >= std::max(overlap_min_planes_, 4 * K + 4) && (own_here.lo > 0 || own_here.hi < D);
     for (size_t i = 0; i < outer_iterations_count; ++i) {
+      if (can_overlap && i + 1 < outer_iterations_count) {
+        if (!SweepsOverlapped(locals_[0], D, W, H, K, hx, hy, hz, equation_alpha, equation_smoothness, equation_data)) return false;
+        ++overlapped_iterations_;
+        continue;
+      }
       for (Local& l : locals_) {
         const f3d_slab pw = Window(D, l.rank, K, K);
         if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy,

@@ -40,12 +40,14 @@ class OpticalFlowSlab : public OpticalFlowBase {
   void DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w);
   float LastDeviceSeconds() const { return last_device_seconds_; }
   bool failed() const { return failed_; }
+  // outer iterations of the last solve that ran in the overlapped order (exchange beside the interior)
+  size_t OverlappedIterations() const { return overlapped_iterations_; }
   DataSize4 FullSize() const { return full_size_; }
 
   bool silent = true;
 
  private:
-  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, kRoles };
+  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, EDU, EDV, EDW, kRoles };
   struct Local {
     int rank;
     DevicePtr buf[kRoles];
@@ -56,6 +58,14 @@ class OpticalFlowSlab : public OpticalFlowBase {
   f3d_slab Window(int depth, int rank, int grow_lo, int grow_hi) const;
   // make `need` planes below/above every slab valid for the given roles (level of `depth`, sub-box width x height)
   bool Exchange(int depth, size_t width, size_t height, const std::vector<Role>& roles, int need_lo, int need_hi);
+  // The same exchange in two halves for the one-rank-per-process case: Begin packs the planes the neighbours need out of
+  // `send_roles` and starts the transfer beside the kernels issued afterwards; End waits for it and unpacks into `recv_roles`.
+  bool ExchangeBegin(int depth, size_t width, size_t height, const std::vector<Role>& send_roles,
+                     const std::vector<Role>& recv_roles, int need_lo, int need_hi);
+  bool ExchangeEnd(size_t width, size_t height);
+  // one outer iteration's sweeps with the halo exchange hidden behind the interior of the slab (see the .cpp)
+  bool SweepsOverlapped(Local& l, int D, size_t W, size_t H, int K, float hx, float hy, float hz, float equation_alpha,
+                        float equation_smoothness, float equation_data);
   bool Check(int status);
 
   int n_ranks_;
@@ -66,6 +76,13 @@ class OpticalFlowSlab : public OpticalFlowBase {
   std::vector<Local> locals_;
   DevicePtr stage_send_ = 0, stage_recv_ = 0;
   size_t stage_floats_ = 0;
+  struct Unpack {  // what ExchangeEnd has to put where
+    std::vector<f3d_devptr> field;
+    std::vector<int> plane, count;
+    std::vector<size_t> offset;
+  } unpack_;
+  int overlap_min_planes_ = 0;
+  size_t overlapped_iterations_ = 0;
   bool failed_ = false;
   float last_device_seconds_ = 0.f;
   CudaOperationConvolution3D taps_;  // only for ComputeGaussianKernel (host arithmetic)

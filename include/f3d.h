@@ -185,6 +185,12 @@ int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plan
  * to peers[i] and receive recv_count[i] floats into recv_buf + recv_offset[i] from peers[i] (zero counts skipped). */
 int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
                       const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers);
+/* The same exchange split in two: _begin starts it behind everything issued on the library stream so far (on a side
+ * stream, so kernels issued afterwards run beside it); _end makes the library stream wait for the received data.  The
+ * send buffer must not be rewritten, nor the receive buffer read, in between.  One exchange may be open at a time. */
+int f3d_comm_sendrecv_begin(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
+                            const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers);
+int f3d_comm_sendrecv_end(void);
 /* max over all ranks of *value (host in/out) */
 int f3d_comm_allreduce_max_f32(float* value);
 /* max |field| over the slab's planes, on the device (feeds the warp halo depth) */

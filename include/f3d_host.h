@@ -92,6 +92,8 @@ int f3d_slabflow_compute(f3d_slabflow flow, const float* frame_0, const float* f
 int f3d_slabflow_upload(f3d_slabflow flow, const float* frame_0, const float* frame_1);
 int f3d_slabflow_compute_resident(f3d_slabflow flow, const f3d_flow_params* params, float* device_seconds);
 int f3d_slabflow_download(f3d_slabflow flow, float* u, float* v, float* w);
+/* outer iterations of the last solve whose halo exchange ran beside the interior of the slab (diagnostics) */
+int f3d_slabflow_overlapped_iterations(f3d_slabflow flow, size_t* count);
 int f3d_slabflow_destroy(f3d_slabflow flow);
 
 /* the decomposition plan (pure host arithmetic, usable without a device) */

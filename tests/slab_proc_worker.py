@@ -23,6 +23,7 @@ f0, f1 = f3d.synth_pair(W, H, D)
 flow = f3d.SlabOpticalFlow(n, [rank])
 flow.initialize(W, H, D)
 u, v, w = flow.compute(f0, f1, **kw)      # every rank fills the planes it owns, the rest stays zero
+overlapped = flow.overlapped_iterations()
 flow.destroy()
 f3d.comm_destroy()
-np.savez(out, u=u, v=v, w=w)
+np.savez(out, u=u, v=v, w=w, overlapped=overlapped)

@@ -67,7 +67,8 @@ def test_single_rank_rccl_init_and_allreduce(f3d):
     f3d.comm_destroy()
 
 
-def test_exchange_legs_pack_rccl_self_unpack(f3d):
+@pytest.mark.parametrize("split", [False, True])
+def test_exchange_legs_pack_rccl_self_unpack(f3d, split):
     """The three legs of one halo exchange as the slab driver issues them (optical_flow_slab.cpp, Exchange): ONE pack
     launch over several (field, plane range) segments, a grouped ncclSend/ncclRecv -- here to the rank itself, which is
     all one GPU offers -- and ONE unpack launch; the planes must arrive bit for bit where the segment table says."""
@@ -75,6 +76,7 @@ def test_exchange_legs_pack_rccl_self_unpack(f3d):
     W, H, D = 70, 13, 9
     rng = np.random.default_rng(7)
     vols = [rng.standard_normal((D, H, W)).astype(np.float32) for _ in range(3)]
+    sent = [v.copy() for v in vols]
     box = f3d.Containers(W, H, D)
     src = [box.alloc() for _ in range(3)]
     dst = [box.alloc(fill=0xFF) for _ in range(3)]
@@ -100,8 +102,15 @@ def test_exchange_legs_pack_rccl_self_unpack(f3d):
         f3d.check(hip.f3d_pack_segments(dp(*[src[s[0]] for s in segs]), ci(*[s[1] for s in segs]), ci(*[s[2] for s in segs]),
                                         sz(*offs), n, W, H, stage_s.value))
         one = C.c_size_t * 1
-        f3d.check(hip.f3d_comm_sendrecv(stage_s.value, one(0), one(total), stage_r.value, one(0), one(total),
-                                        (C.c_int * 1)(0), 1))
+        if split:   # the transfer on RCCL's side stream, a kernel of the library stream beside it, then the join
+            f3d.check(hip.f3d_comm_sendrecv_begin(stage_s.value, one(0), one(total), stage_r.value, one(0), one(total),
+                                                  (C.c_int * 1)(0), 1))
+            f3d.check(hip.f3d_add(src[0], src[1], W, H, D, None))
+            f3d.check(hip.f3d_comm_sendrecv_end())
+            vols[0] = vols[0] + vols[1]            # the add ran after the pack: the packed planes are the old ones
+        else:
+            f3d.check(hip.f3d_comm_sendrecv(stage_s.value, one(0), one(total), stage_r.value, one(0), one(total),
+                                            (C.c_int * 1)(0), 1))
         f3d.check(hip.f3d_unpack_segments(dp(*[dst[s[0]] for s in segs]), ci(*shift), ci(*[s[2] for s in segs]),
                                           sz(*offs), n, W, H, stage_r.value))
         f3d.sync()
@@ -110,7 +119,7 @@ def test_exchange_legs_pack_rccl_self_unpack(f3d):
     got = [box.download(p, (W, H, D)) for p in dst]
     exp = [np.full((D, H, W), np.nan, np.float32) for _ in range(3)]
     for (f, p0, cnt), d0 in zip(segs, shift):
-        exp[f][d0:d0 + cnt] = vols[f][p0:p0 + cnt]
+        exp[f][d0:d0 + cnt] = sent[f][p0:p0 + cnt]
     for g, e in zip(got, exp):
         filled = ~np.isnan(e)
         assert np.array_equal(g[filled], e[filled])

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(n, dims, tmp_path, **kw):
+def run_ranks(n, dims, tmp_path, env=None, **kw):
     session = uuid.uuid4().hex[:12]
     procs, outs = [], []
     for r in range(n):
@@ -24,7 +24,7 @@ def run_ranks(n, dims, tmp_path, **kw):
         outs.append(out)
         cmd = [sys.executable, os.path.join(HERE, "slab_proc_worker.py"), str(r), str(n), session, *map(str, dims), out]
         cmd += [f"{k}={v}" for k, v in kw.items()]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env={**os.environ, **(env or {})}))
     logs = []
     for p in procs:
         try:
@@ -37,6 +37,7 @@ def run_ranks(n, dims, tmp_path, **kw):
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-2000:]}"
     parts = [np.load(o) for o in outs]
+    run_ranks.overlapped = [int(p["overlapped"]) for p in parts]
     return [sum(p[c] for p in parts) for c in "uvw"]   # slabs are disjoint, the other planes are zero
 
 
@@ -53,5 +54,25 @@ def test_processes_equal_single_gpu(f3d, tmp_path, n_ranks, dims, kw):
     exp = flow.compute(f0, f1, silent=True, **kw)
     flow.destroy()
     got = run_ranks(n_ranks, dims, tmp_path, **kw)
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} processes: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+@pytest.mark.parametrize("n_ranks,dims,min_planes", [(2, (40, 36, 64), "24"), (3, (33, 30, 84), "24"), (2, (40, 36, 64), "0")])
+def test_overlapped_exchange_order(f3d, tmp_path, n_ranks, dims, min_planes):
+    """Slabs of 28-32 planes: the finest levels run the overlapped order (zones first, transfer beside the interior,
+    optical_flow_slab.cpp SweepsOverlapped), the coarse ones the plain order; "0" switches the overlap off.  Same bits."""
+    W, H, D = dims
+    kw = dict(warp_levels_count=6, outer_iterations_count=5)
+    f0, f1 = f3d.synth_pair(W, H, D)
+    flow = f3d.OpticalFlow()
+    flow.initialize(W, H, D)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(n_ranks, dims, tmp_path, env={"F3D_OVERLAP_MIN_PLANES": min_planes}, **kw)
+    if min_planes == "0":
+        assert run_ranks.overlapped == [0] * n_ranks
+    else:   # up to 6 levels x 4 of the 5 outer iterations; the coarsest levels of the 3-rank case fall below 24 planes
+        assert all(8 <= c <= 24 for c in run_ranks.overlapped), run_ranks.overlapped
     for g, e, c in zip(got, exp, "uvw"):
         assert same(g, e), f"{n_ranks} processes: component {c} differs, max {np.abs(g - e).max():.3e}"
