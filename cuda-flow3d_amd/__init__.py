@@ -102,6 +102,7 @@ def hip():
         "f3d_pack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_unpack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
+        "f3d_flow_stats": [_dp, _dp, _dp, _sz, _sz, _sz, _slabp, _fp, _fp, C.POINTER(C.c_double)],
         "f3d_comm_sendrecv_begin": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
         "f3d_comm_sendrecv_end": [],
         "f3d_comm_allreduce_max_f32": [_fp],
@@ -329,8 +330,13 @@ _FLOAT_KEYS = {"equation_alpha", "equation_smoothness", "equation_data", "hx", "
 _SIZE4_KEYS = {"data_size", "resample_size", "container_size"}
 
 
+class Stat3(C.Structure):
+    """src/data_types/data_structs.h:29-33"""
+    _fields_ = [("min", C.c_float), ("max", C.c_float), ("avg", C.c_float)]
+
+
 class Operation:
-    """One of the six operators, driven exactly like the reference drives them: Initialize({"container_size"}),
+    """One of the operators (add, convolution, median, registration, resample, solve, stat), driven exactly like the reference drives them: Initialize({"container_size"}),
     Execute(bag of pointers to caller variables).  After execute() the (possibly swapped) pointer values are
     available in .values (the solver swaps dev_flow_d* / dev_temp_d* through the bag)."""
 
@@ -365,6 +371,8 @@ class Operation:
                 store[k] = C.c_float(v)
             elif k in _SIZE4_KEYS:
                 store[k] = Size4(v[0], v[1], v[2], 0) if not isinstance(v, Size4) else v
+            elif k == "stat":
+                store[k] = v            # a Stat3 the operator fills in
             else:
                 raise TypeError(f"unknown parameter key {k!r}")
         n = len(store)

@@ -134,6 +134,42 @@ __global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ f, F3
   if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));  // non-negative floats order like uints
 }
 
+// ---- flow statistics: min / max / sum of |(u, v, w)| over a slab -------------------------------------------------------
+// cuda_operation_stat_p.cpp:85-104 of the reference does this on the host after a download; here the flow stays on the
+// device.  Magnitudes are non-negative, so their bit patterns order like unsigned integers (atomicMin / atomicMax);
+// the sum is accumulated in double (the reference adds floats in scan order, which no parallel reduction reproduces).
+struct FlowStats {
+  unsigned min_bits, max_bits;
+  double sum;
+};
+__global__ __launch_bounds__(256) void k_flow_stats(const float* __restrict__ u, const float* __restrict__ v,
+                                                    const float* __restrict__ w, F3dGeo g, FlowStats* out)
+{
+  const int z = g.z_lo + blockIdx.z;
+  float lo = __uint_as_float(0x7f7fffffu), hi = 0.f;
+  double sum = 0.0;
+  for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
+    const size_t r = f3d_row(g, y, z);
+    for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
+      const float a = u[r + x], b = v[r + x], c = w[r + x];
+      const float m = sqrtf(a * a + b * b + c * c);
+      lo = fminf(lo, m);
+      hi = fmaxf(hi, m);
+      sum += static_cast<double>(m);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, off));
+    hi = fmaxf(hi, __shfl_down(hi, off));
+    sum += __shfl_down(sum, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out->min_bits, __float_as_uint(lo));
+    atomicMax(&out->max_bits, __float_as_uint(hi));
+    atomicAdd(&out->sum, sum);
+  }
+}
+
 bool same_buffer(f3d_devptr a, f3d_devptr b, const char* who)
 {
   if (a == b) {
@@ -296,6 +332,32 @@ int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, con
   F3D_HIP(hipMemcpyAsync(&bits, d_result, sizeof(unsigned), hipMemcpyDeviceToHost, f3d::stream()));
   F3D_HIP(hipStreamSynchronize(f3d::stream()));
   std::memcpy(result, &bits, sizeof(float));
+  return 0;
+}
+
+int f3d_flow_stats(f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w, size_t width, size_t height, size_t depth,
+                   const f3d_slab* slab, float* min_magnitude, float* max_magnitude, double* sum_magnitude)
+{
+  F3D_REQUIRE_READY("f3d_flow_stats");
+  if (!min_magnitude || !max_magnitude || !sum_magnitude) return f3d::fail("f3d_flow_stats: null argument");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_flow_stats")) return 1;
+  static FlowStats* d_stats = nullptr;
+  if (!d_stats) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(FlowStats)));
+  const FlowStats init = {0x7f7fffffu, 0u, 0.0};  // FLT_MAX, 0, 0
+  F3D_HIP(hipMemcpyAsync(d_stats, &init, sizeof(init), hipMemcpyHostToDevice, f3d::stream()));
+  if (g.z_hi > g.z_lo) {
+    const int gy = g.H < 64 ? g.H : 64;
+    hipLaunchKernelGGL(k_flow_stats, dim3(1, gy, g.z_hi - g.z_lo), dim3(256, 1, 1), 0, f3d::stream(), f3d_ptr<const float>(flow_u),
+                       f3d_ptr<const float>(flow_v), f3d_ptr<const float>(flow_w), g, d_stats);
+    F3D_HIP(hipGetLastError());
+  }
+  FlowStats h;
+  F3D_HIP(hipMemcpyAsync(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost, f3d::stream()));
+  F3D_HIP(hipStreamSynchronize(f3d::stream()));
+  std::memcpy(min_magnitude, &h.min_bits, sizeof(float));
+  std::memcpy(max_magnitude, &h.max_bits, sizeof(float));
+  *sum_magnitude = h.sum;
   return 0;
 }
 

@@ -148,6 +148,7 @@ int f3d_op_create(f3d_op* op, const char* name)
   else if (n == "registration") impl = new CudaOperationRegistration;
   else if (n == "resample") impl = new CudaOperationResample;
   else if (n == "solve") impl = new CudaOperationSolve;
+  else if (n == "stat") impl = new CudaOperationStat;
   if (!impl) return 1;
   *op = new f3d_op_s;
   (*op)->op = impl;

@@ -60,6 +60,30 @@ void CudaOperationAdd::Execute(OperationParameters& params)
   CheckDeviceError(f3d_add(operand_0, operand_1, data_size.width, data_size.height, data_size.depth, slab_));
 }
 
+// ---- flow statistics (cuda_operation_stat_p.cpp:44-107, on device data) ------------------------------------------
+
+void CudaOperationStat::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DevicePtr dev_flow_u, dev_flow_v, dev_flow_w;
+  DataSize4 data_size;
+  Stat3* p_stat;
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_u, "dev_flow_u");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_v, "dev_flow_v");
+  GET_PARAM_OR_RETURN(params, DevicePtr, dev_flow_w, "dev_flow_w");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_PTR_OR_RETURN(params, Stat3, p_stat, "stat");
+  if (!silent) std::printf("Compute statistics...\n");
+  double sum = 0.0;
+  if (CheckDeviceError(f3d_flow_stats(dev_flow_u, dev_flow_v, dev_flow_w, data_size.width, data_size.height, data_size.depth, slab_,
+                                      &p_stat->min, &p_stat->max, &sum)))
+    return;
+  const size_t planes = slab_ ? static_cast<size_t>(slab_->z_hi - slab_->z_lo) : data_size.depth;
+  const double count = static_cast<double>(data_size.width) * static_cast<double>(data_size.height) * static_cast<double>(planes);
+  p_stat->avg = count > 0 ? static_cast<float>(sum / count) : 0.f;
+  if (!silent) std::printf("Min: %8.4f Max: %8.4f Avg: %8.4f\n", p_stat->min, p_stat->max, p_stat->avg);
+}
+
 // ---- Gaussian (cuda_operation_convolution.cpp:85-114, 134-184) -----------------------------------------------
 
 void CudaOperationConvolution3D::ComputeGaussianKernel(float sigma, size_t precision, float pixel_size)

@@ -42,6 +42,16 @@ class CudaOperationAdd : public CudaOperationBase {
   void Execute(OperationParameters& params) override;
 };
 
+// min / max / average flow magnitude        keys: dev_flow_u, dev_flow_v, dev_flow_w, data_size, stat (Stat3*)
+// (the reference's CudaOperationStatP, cuda_operation_stat_p.cpp:44-107, works on downloaded host volumes)
+class CudaOperationStat : public CudaOperationBase {
+ public:
+  CudaOperationStat() : CudaOperationBase("CUDA Stat") {}
+  bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
+  void Execute(OperationParameters& params) override;
+  bool silent = true;
+};
+
 // separable Gaussian, rows -> columns -> slices   keys: dev_input, dev_output, dev_temp, data_size, gaussian_sigma
 class CudaOperationConvolution3D : public CudaOperationBase {
  public:

@@ -196,6 +196,13 @@ int f3d_comm_allreduce_max_f32(float* value);
 /* max |field| over the slab's planes, on the device (feeds the warp halo depth) */
 int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result);
 
+/* Flow statistics on the device: min, max and SUM of sqrt(u^2 + v^2 + w^2) over the slab's planes (host out; the
+ * caller divides by the voxel count, or adds the sums of several slabs first).  Device counterpart of the host loop
+ * in src/cuda_operations/partial_data/cuda_operation_stat_p.cpp:85-104; min and max are exact, the sum is accumulated in
+ * double (the reference adds floats in scan order). */
+int f3d_flow_stats(f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w, size_t width, size_t height, size_t depth,
+                   const f3d_slab* slab, float* min_magnitude, float* max_magnitude, double* sum_magnitude);
+
 #ifdef __cplusplus
 }
 #endif

@@ -318,6 +318,32 @@ void orc_add(float* a, const float* b, int W, int H, int D, const orc_geom* g)
       }
 }
 
+/* cuda_operation_stat_p.cpp:85-104 (serial on purpose: the reference's float sum depends on the scan order) */
+void orc_flow_stats(const float* u, const float* v, const float* w, int W, int H, int D, const orc_geom* g,
+                    float* min_mag, float* max_mag, float* avg_float, double* sum_double)
+{
+  (void)D;
+  float mn = 3.402823466e+38f, mx = 1.175494351e-38f, avg = 0.f;   /* numeric_limits<float>::max() / ::min() */
+  double sum = 0.0;
+  size_t count = 0;
+  for (int z = g->z_lo; z < g->z_hi; z++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        size_t c = IDX(g, x, y, z);
+        float magnitude = sqrtf(u[c] * u[c] + v[c] * v[c] + w[c] * w[c]);
+        mn = fminf(mn, magnitude);
+        mx = fmaxf(mx, magnitude);
+        avg += magnitude;
+        sum += (double)magnitude;
+        count++;
+      }
+  if (count) avg /= (float)count;
+  *min_mag = mn;
+  *max_mag = mx;
+  *avg_float = avg;
+  *sum_double = sum;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* A.5  src/kernels/median_3d.cu:34-45 (stable insertion sort), :282-297 (window gather, element r^3/2) */
 static void insertion_sort(float* window, int size)

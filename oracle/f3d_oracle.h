@@ -82,6 +82,10 @@ void orc_solve_sweep(const float* f0, const float* f1, const float* u, const flo
                      float* tdu, float* tdv, float* tdw, const orc_geom* g);
 
 void orc_add(float* a, const float* b, int W, int H, int D, const orc_geom* g);
+/* src/cuda_operations/partial_data/cuda_operation_stat_p.cpp:85-104: min, max, and the float sum in scan order (avg = sum
+ * / count as the reference computes it) plus the same sum in double */
+void orc_flow_stats(const float* u, const float* v, const float* w, int W, int H, int D, const orc_geom* g,
+                    float* min_mag, float* max_mag, float* avg_float, double* sum_double);
 
 /* A.5 median, window diameter r in {3,5,7} */
 void orc_median(const float* in, float* out, int W, int H, int D, int r, const orc_geom* g);

@@ -75,6 +75,9 @@ def lib():
         L.orc_phi_ksi.argtypes = [fp] * 8 + [C.c_int] * 3 + [C.c_float] * 5 + [fp, fp, gp]
         L.orc_solve_sweep.restype = None
         L.orc_solve_sweep.argtypes = [fp] * 10 + [C.c_int] * 3 + [C.c_float] * 4 + [fp] * 3 + [gp]
+        L.orc_flow_stats.restype = None
+        L.orc_flow_stats.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, gp, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.orc_add.restype = None
         L.orc_add.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, gp]
         L.orc_median.restype = None
@@ -213,6 +216,14 @@ def solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, alpha, g=None, o
 def add(a, b, dims, g=None):
     W, H, D = dims
     lib().orc_add(_p(a), _p(b), W, H, D, g or geom(a, z_hi=D))
+
+
+def flow_stats(u, v, w, dims, g=None):
+    """(min, max, avg as the reference's float scan computes it, sum in double) of the flow magnitude"""
+    W, H, D = dims
+    mn, mx, avg, s = C.c_float(), C.c_float(), C.c_float(), C.c_double()
+    lib().orc_flow_stats(_p(u), _p(v), _p(w), W, H, D, g or geom(u, z_hi=D), C.byref(mn), C.byref(mx), C.byref(avg), C.byref(s))
+    return mn.value, mx.value, avg.value, s.value
 
 
 def median(inp, dims, r, g=None):

@@ -347,3 +347,38 @@ def test_memset2d_sub_box(f3d, value):
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
     finally:
         box.free()
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:4])
+def test_flow_stats(f3d, oracle, dims, cdims):
+    """f3d_flow_stats / the "stat" operator: min and max of |(u,v,w)| equal the reference's host loop bit for bit; the
+    average is the double-precision sum rounded once (the reference's scan-order float sum is only approximated)."""
+    rng = np.random.default_rng(5)
+    W, H, D = dims
+    u, v, w = (box_in_container(rng, dims, cdims, -4, 4) for _ in range(3))
+    mn_o, mx_o, avg_o, sum_o = oracle.flow_stats(u, v, w, dims)
+    dev = Dev(f3d, cdims)
+    try:
+        pu, pv, pw = dev.put(u), dev.put(v), dev.put(w)
+        mn, mx, s = C.c_float(), C.c_float(), C.c_double()
+        f3d.check(f3d.hip().f3d_flow_stats(pu, pv, pw, W, H, D, None, C.byref(mn), C.byref(mx), C.byref(s)))
+        assert (mn.value, mx.value) == (mn_o, mx_o)
+        assert abs(s.value - sum_o) <= 1e-12 * sum_o
+        op = f3d.Operation("stat")
+        assert op.name == "CUDA Stat" and op.initialize(dev.cont)
+        st = f3d.Stat3()
+        op.execute(dev_flow_u=pu, dev_flow_v=pv, dev_flow_w=pw, data_size=dims, stat=st)
+        assert (st.min, st.max) == (mn_o, mx_o)
+        # the reference adds up to 343 000 floats in scan order: its own rounding error is ~1e-5 here (and grows with the
+        # volume); the device average is the double sum rounded once
+        assert abs(st.avg - avg_o) <= 2e-4 * avg_o
+        assert abs(st.avg - np.float32(sum_o / (W * H * D))) <= 1e-7 * avg_o
+        # a slab window
+        slab = f3d.Slab(0, 1, D - 1)
+        f3d.check(f3d.hip().f3d_flow_stats(pu, pv, pw, W, H, D, C.byref(slab), C.byref(mn), C.byref(mx), C.byref(s)))
+        g = oracle.geom(u, z_base=0, z_lo=1, z_hi=D - 1)
+        mn2, mx2, _, sum2 = oracle.flow_stats(u, v, w, dims, g=g)
+        assert (mn.value, mx.value) == (mn2, mx2) and abs(s.value - sum2) <= 1e-12 * sum2
+        op.destroy()
+    finally:
+        dev.close()
