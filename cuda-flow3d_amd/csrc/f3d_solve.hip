@@ -755,6 +755,7 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
   const int q_end = z1 < g.D ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
   const int x0 = tx * kLanes;
   const int y0 = ty * TY;
+  const bool tile_at_x_face = __builtin_amdgcn_readfirstlane(static_cast<int>(tx == 0 || x0 + kLanes >= g.W)) != 0;
 
   // row waves
   const int y = y0 - 1 + r;
@@ -962,9 +963,12 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
       xp.u = lane_right_or(hC.u, eu); xp.v = lane_right_or(hC.v, ev); xp.w = lane_right_or(hC.w, ew);
       zm = hM;
       zp = sN;
-      // mirror rule at the faces of the volume: the missing neighbour is the opposite one
-      if (x == 0) xm = xp;
-      if (x == g.W - 1) xp = xm;
+      // mirror rule at the faces of the volume: the missing neighbour is the opposite one.  Only tiles that touch a face
+      // pay for the selects (wave-uniform branches).
+      if (tile_at_x_face) {
+        if (x == 0) xm = xp;
+        if (x == g.W - 1) xp = xm;
+      }
       if (y == 0) ym = yp;
       if (y == g.H - 1) yp = ym;
       if (t == 0) zm = zp;
