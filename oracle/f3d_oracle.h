@@ -9,7 +9,10 @@
  *   - level schedule (orc_max_warp_level / orc_level_geometry): PINNED against the reference's own
  *     src/optical_flow/optical_flow_base.cpp compiled verbatim into oracle/_ref/ (tests/test_oracle_ref.py).
  *   - RAW U8/F32 volume I/O: PINNED against the reference's src/data_types/data3d.cpp in oracle/_ref/.
- *   - kernel numerics (resample, warp, phi/ksi, sweep, median, Gaussian, add): PARITY UNPINNED in this
+ *   - warp (orc_warp) and flow statistics (orc_flow_stats): PINNED against the reference's own host implementations
+ *     (partial_data/cuda_operation_register_p.cpp:96-139, cuda_operation_stat_p.cpp:85-104) compiled in place into
+ *     oracle/_ref/libf3d_ref_ops.so (tests/test_oracle.py).
+ *   - remaining kernel numerics (resample, phi/ksi, sweep, median, Gaussian, add): PARITY UNPINNED in this
  *     repo.  The reference ships no tests, golden vectors or fixtures for them, and its kernels are CUDA
  *     (.cu, need nvcc + the CUDA device runtime, absent here) so they cannot be built without writing
  *     stand-ins.  Each function below cites the reference file:line it restates.
@@ -66,6 +69,8 @@ void orc_resample_axis(const float* in, float* out, int ow, int oh, int od, int 
                        int axis, const orc_geom* g_in, const orc_geom* g_out);
 
 /* A.2 trilinear backward warp */
+/* PINNED: equals the reference's own host implementation (partial_data/cuda_operation_register_p.cpp:96-139, built in place into
+ * oracle/_ref/libf3d_ref_ops.so) bit for bit -- tests/test_oracle.py::test_warp_equals_the_reference_cpu_warp */
 void orc_warp(const float* f0, const float* f1, const float* u, const float* v, const float* w,
               int W, int H, int D, float hx, float hy, float hz, float* out, const orc_geom* g);
 

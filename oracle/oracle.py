@@ -110,8 +110,38 @@ def ref():
             R.ref_read_raw_f32.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, fp]
             R.ref_write_raw.argtypes = [C.c_char_p, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
             R.ref_write_vtk.argtypes = [C.c_char_p, fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t]
+        if hasattr(R, "ref_have_host_ops"):
+            fp = C.POINTER(C.c_float)
+            sz = C.c_size_t
+            R.ref_have_host_ops.restype = C.c_int
+            R.ref_warp.argtypes = [fp, fp, fp, fp, fp, sz, sz, sz, C.c_float, C.c_float, C.c_float, fp]
+            R.ref_flow_stats.argtypes = [fp, fp, fp, sz, sz, sz, fp, fp, fp]
         _REF = R
     return _REF
+
+
+def ref_host_ops():
+    """True when the reference's host-only operators (CPU warp, flow statistics) were built (oracle/_ref/libf3d_ref_ops.so)."""
+    r = ref()
+    return bool(r is not None and hasattr(r, "ref_have_host_ops") and r.ref_have_host_ops())
+
+
+def ref_warp(f0, f1, u, v, w, h):
+    """The REFERENCE's own CPU warp (cuda_operation_register_p.cpp:96-139) on dense [D, H, W] volumes."""
+    D, H, W = f0.shape
+    out = np.empty_like(f0)
+    ok = ref().ref_warp(_p(f0), _p(f1), _p(u), _p(v), _p(w), W, H, D, h[0], h[1], h[2], _p(out))
+    assert ok
+    return out
+
+
+def ref_flow_stats(u, v, w):
+    """(min, max, avg) exactly as the reference's CudaOperationStatP computes them (cuda_operation_stat_p.cpp:85-104)."""
+    D, H, W = u.shape
+    mn, mx, avg = C.c_float(), C.c_float(), C.c_float()
+    ok = ref().ref_flow_stats(_p(u), _p(v), _p(w), W, H, D, C.byref(mn), C.byref(mx), C.byref(avg))
+    assert ok
+    return mn.value, mx.value, avg.value
 
 
 def _p(a):

@@ -9,10 +9,16 @@
  *                                               the image carries that header under triton/backends/nvidia)
  * The reference's kernels (src/kernels/*.cu) and operator hosts call into nvcc/the CUDA driver and are
  * NOT buildable here; nothing in this file stands in for them.
+ * Two operators whose Execute() is plain host C++ live in a second library (ref_ops_bridge.cpp ->
+ * oracle/_ref/libf3d_ref_ops.so).  Their translation units reference three CUDA driver symbols that are never reached;
+ * the library is therefore opened HERE with lazy binding (Python's ctypes binds eagerly and could not load it).
  */
+#include <dlfcn.h>
+
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "src/optical_flow/optical_flow_base.h"
 #include "src/data_types/operation_parameters.h"
@@ -93,5 +99,43 @@ int ref_write_vtk(const char* path, const float* u, const float* v, const float*
   return Data3D::WriteFlowToFileVTK(path, a, b, c);
 }
 #endif
+
+/* ---- the host-only operators of libf3d_ref_ops.so, opened lazily ---- */
+static void* ops_lib(void)
+{
+  static void* handle = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&ops_lib), &info) && info.dli_fname) {
+      std::string path(info.dli_fname);
+      const size_t slash = path.rfind('/');
+      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libf3d_ref_ops.so";
+      handle = dlopen(path.c_str(), RTLD_LAZY | RTLD_LOCAL);
+    }
+  }
+  return handle;
+}
+
+int ref_have_host_ops(void) { return ops_lib() != nullptr; }
+
+int ref_warp(const float* f0, const float* f1, const float* u, const float* v, const float* w, size_t W, size_t H, size_t D, float hx,
+             float hy, float hz, float* out)
+{
+  typedef int (*fn_t)(const float*, const float*, const float*, const float*, const float*, size_t, size_t, size_t, float, float,
+                      float, float*);
+  void* lib = ops_lib();
+  fn_t fn = lib ? reinterpret_cast<fn_t>(dlsym(lib, "refops_warp")) : nullptr;
+  return fn ? fn(f0, f1, u, v, w, W, H, D, hx, hy, hz, out) : 0;
+}
+
+int ref_flow_stats(const float* u, const float* v, const float* w, size_t W, size_t H, size_t D, float* mn, float* mx, float* avg)
+{
+  typedef int (*fn_t)(const float*, const float*, const float*, size_t, size_t, size_t, float*, float*, float*);
+  void* lib = ops_lib();
+  fn_t fn = lib ? reinterpret_cast<fn_t>(dlsym(lib, "refops_flow_stats")) : nullptr;
+  return fn ? fn(u, v, w, W, H, D, mn, mx, avg) : 0;
+}
 
 }  // extern "C"

@@ -130,3 +130,43 @@ def test_kernels_on_a_z_window_equal_the_whole_volume(oracle):
     g5 = oracle.Geom(cdims[1], cdims[0], 2, 4, 9)
     part = oracle.median(np.ascontiguousarray(arrs[2][2:11]), dims, 5, g=g5)
     assert bit_same(part[2:7, :H, :W], med[4:9, :H, :W])
+
+
+# ---- the oracle's warp and flow statistics against the REFERENCE's own host implementations --------------------------
+# (cuda_operation_register_p.cpp:96-139 and cuda_operation_stat_p.cpp:85-104, compiled in place into oracle/_ref; on the
+# GPU box the prebuilt library travels with the snapshot, elsewhere these tests skip)
+
+def _need_ref_ops(oracle):
+    if not oracle.ref_host_ops():
+        pytest.skip("oracle/_ref/libf3d_ref_ops.so not built (no /root/reference here)")
+
+
+@pytest.mark.parametrize("dims,h", [((37, 21, 9), (1.0, 1.0, 1.0)), ((16, 9, 7), (7.1, 1.6, 1.25)), ((5, 4, 4), (1.3, 0.9, 2.0)),
+                                     ((50, 33, 23), (1.05, 1.1, 0.97))])
+def test_warp_equals_the_reference_cpu_warp(oracle, dims, h):
+    """A.2 pinned: same bits as the reference's plain-C++ warp, including targets outside the volume (~45 % here), exact
+    integer landings and NaN flow."""
+    _need_ref_ops(oracle)
+    W, H, D = dims
+    rng = np.random.default_rng(hash(dims) % 2**32)
+    f0 = rng.uniform(0, 255, (D, H, W)).astype(np.float32)
+    f1 = rng.uniform(0, 255, (D, H, W)).astype(np.float32)
+    u, v, w = (rng.uniform(-6, 6, (D, H, W)).astype(np.float32) for _ in range(3))
+    u[::3, ::2, ::5] = np.round(u[::3, ::2, ::5])          # exact integer landings (h = 1 case)
+    v[1::4, 1::3, 2::7] = np.nan
+    w[0, 0, :2] = np.inf
+    exp = oracle.ref_warp(f0, f1, u, v, w, h)
+    got = oracle.warp(f0, f1, u, v, w, dims, h)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    outside = np.count_nonzero(got == f0) / got.size
+    assert 0.2 < outside < 0.99      # both branches of the bounds test are exercised
+
+
+def test_flow_stats_equal_the_reference(oracle):
+    _need_ref_ops(oracle)
+    rng = np.random.default_rng(4)
+    for dims in [(37, 21, 9), (64, 8, 5), (70, 70, 70)]:
+        W, H, D = dims
+        u, v, w = (rng.uniform(-4, 4, (D, H, W)).astype(np.float32) for _ in range(3))
+        mn, mx, avg, _ = oracle.flow_stats(u, v, w, dims)
+        assert (mn, mx, avg) == oracle.ref_flow_stats(u, v, w)
