@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "f3d_internal.h"
@@ -131,6 +132,8 @@ void prof_end(int kernel)
 
 }  // namespace f3d
 
+std::map<void*, void*> g_alloc_base;  // staggered allocations: user pointer -> hipMalloc pointer
+
 // rows x words dwords of a pitched array set to one 32-bit pattern (grid.y strides over the rows)
 __global__ __launch_bounds__(256) void k_fill_rows(unsigned* __restrict__ p, size_t pitch_words, unsigned word, unsigned words,
                                                    unsigned rows)
@@ -219,9 +222,21 @@ int f3d_alloc_pitched(f3d_devptr* ptr, size_t* pitch, size_t width_bytes, size_t
   if (!ptr || !pitch || width_bytes == 0 || rows == 0) return f3d::fail("f3d_alloc_pitched: bad argument");
   const size_t align = 256;  // whole 256-B wave rows; also keeps every row 16-B aligned for dwordx4 access
   size_t p = (width_bytes + align - 1) / align * align;
+  // Successive allocations are staggered by 17 x 256 B (modulo 64 KiB; F3D_ALLOC_SKEW = other byte count, 0 = off).
+  // Equally sized containers otherwise start at the same offset of every power-of-two stride of the memory system, and the
+  // one-sweep kernel, which streams 13 of them in lockstep, runs 10 % slower at 512^3 (1.70 -> 1.54 ms; any non-zero
+  // stagger gives the same gain; phi/ksi and the fused pair do not care).
+  static const size_t skew_unit = [] {
+    const char* e = std::getenv("F3D_ALLOC_SKEW");
+    return e ? static_cast<size_t>(std::atol(e)) / 256 * 256 : static_cast<size_t>(17 * 256);
+  }();
+  static size_t serial = 0;
+  const size_t skew = skew_unit ? (serial++ * skew_unit) % 65536 : 0;
   void* d = nullptr;
-  F3D_HIP(hipMalloc(&d, p * rows + align));
-  *ptr = static_cast<f3d_devptr>(reinterpret_cast<uintptr_t>(d));
+  F3D_HIP(hipMalloc(&d, p * rows + align + (skew_unit ? 65536 : 0)));
+  char* user = static_cast<char*>(d) + skew;
+  if (skew_unit) g_alloc_base[user] = d;
+  *ptr = static_cast<f3d_devptr>(reinterpret_cast<uintptr_t>(user));
   *pitch = p;
   return 0;
 }
@@ -229,7 +244,13 @@ int f3d_alloc_pitched(f3d_devptr* ptr, size_t* pitch, size_t width_bytes, size_t
 int f3d_free(f3d_devptr ptr)
 {
   F3D_REQUIRE_READY("f3d_free");
-  F3D_HIP(hipFree(f3d_ptr<void>(ptr)));
+  void* user = f3d_ptr<void>(ptr);
+  auto it = g_alloc_base.find(user);
+  if (it != g_alloc_base.end()) {
+    user = it->second;
+    g_alloc_base.erase(it);
+  }
+  F3D_HIP(hipFree(user));
   return 0;
 }
 
