@@ -46,6 +46,7 @@ struct SolveArgs {
   float hx, hy, hz;
   float p0, p1;  // sweep: alpha, unused; phi_ksi: eps_smooth, eps_data
   unsigned long long* probe = nullptr;  // timing experiments (k_sweep7 with ABL bit 3): [wave][phase] cycle sums
+  int plain_division = 0;               // timing experiments (F3D_UDIV=0): every division the ordinary IEEE sequence
 };
 
 enum { F0 = 0, F1 = 1, U = 2, V = 3, Wf = 4, DU = 5, DV = 6, DW = 7, PHI = 8 };
@@ -56,35 +57,135 @@ struct Hood {
   float c[NA], xm[NA], xp[NA], ym[NA], yp[NA], zm[NA], zp[NA];
 };
 
-// A.3: src/kernels/solve_3d.cu:177-260
-__device__ __forceinline__ void phi_ksi_voxel(const Hood<8>& n, float hx, float hy, float hz, float eps_s,
-                                              float eps_d, float& phi, float& ksi)
+// ---- exact division by a wave-uniform divisor ----------------------------------------------------------------------------
+// The derivatives of A.3 / A.4 divide per-voxel numerators by 2h or 4h.  IEEE binary32 division is an 11-instruction
+// sequence with a quarter-rate reciprocal (19.5 ns per wave and SIMD, tools/lab/valu_rate); phi/ksi does twelve of them.
+// For a divisor d shared by the wave, q = (float)((double)x * R), R = RN64(1 / (double)d), is the SAME float:
+//   * x * R differs from x / d by at most 2^-52 relatively (two roundings to binary64);
+//   * a quotient of two binary32 numbers is never a rounding boundary of binary32 (a midpoint m has an odd 25-bit
+//     significand; x = m * d would need more than 24 significant bits), and it stays at least 2^-49 * |q| away from
+//     every boundary (x - m * d is a non-zero multiple of 2^(min exponent), |x| * 2^-49 at least);
+//   so no boundary lies between the exact quotient and the computed double, and both round to the same binary32.
+// The argument needs a normal result: a quotient in the subnormal range CAN be a tie.  Numerators with 0 < |x| < 2^-100
+// (and divisors outside 2^-20 .. 2^20) therefore send the whole wave through the ordinary division; +-0, Inf and NaN are
+// fine.  Checked on 2 x 10^8 random and adversarial (near-midpoint) numerators against binary32 division: no difference.
+// Cost 7.5 ns instead of 19.5 ns, plus two integer instructions per numerator for the guard.
+struct UDiv {
+  double r;  // RN64(1 / d)
+  float d;
+};
+__device__ __forceinline__ UDiv make_udiv(float d)
 {
-  const float dux = (n.xp[U] - n.xm[U] + n.xp[DU] - n.xm[DU]) / (2.f * hx);
-  const float duy = (n.yp[U] - n.ym[U] + n.yp[DU] - n.ym[DU]) / (2.f * hy);
-  const float duz = (n.zp[U] - n.zm[U] + n.zp[DU] - n.zm[DU]) / (2.f * hz);
-  const float dvx = (n.xp[V] - n.xm[V] + n.xp[DV] - n.xm[DV]) / (2.f * hx);
-  const float dvy = (n.yp[V] - n.ym[V] + n.yp[DV] - n.ym[DV]) / (2.f * hy);
-  const float dvz = (n.zp[V] - n.zm[V] + n.zp[DV] - n.zm[DV]) / (2.f * hz);
-  const float dwx = (n.xp[Wf] - n.xm[Wf] + n.xp[DW] - n.xm[DW]) / (2.f * hx);
-  const float dwy = (n.yp[Wf] - n.ym[Wf] + n.yp[DW] - n.ym[DW]) / (2.f * hy);
-  const float dwz = (n.zp[Wf] - n.zm[Wf] + n.zp[DW] - n.zm[DW]) / (2.f * hz);
+  UDiv u;
+  u.d = d;
+  const double r = 1.0 / static_cast<double>(d);
+  // the divisor is wave-uniform: keep the reciprocal in scalar registers
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__double_as_longlong(r)));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__double_as_longlong(r) >> 32));
+  u.r = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+  return u;
+}
+__device__ __forceinline__ bool udiv_divisor_ok(float d) { return d >= 0x1p-20f && d <= 0x1p20f; }
+__device__ __forceinline__ float udiv(float x, const UDiv& u) { return static_cast<float>(static_cast<double>(x) * u.r); }
+// key(x) = (bits << 1) - 1 as unsigned: +-0 -> 0xffffffff, tiny non-zero -> small, anything >= 2^-100 -> >= kUdivSafe
+constexpr unsigned kUdivSafe = (0x0d800000u << 1) - 1u;
+__device__ __forceinline__ unsigned udiv_key(float x) { return (__float_as_uint(x) << 1) - 1u; }
+template <int N>
+__device__ __forceinline__ bool udiv_all_safe(const float (&num)[N])
+{
+  unsigned k = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < N; ++i) k = min(k, udiv_key(num[i]));
+  return __builtin_amdgcn_ballot_w64(k < kUdivSafe) == 0;  // wave-uniform
+}
+
+// fx, fy, fz of A.3 / A.4 from their numerators
+struct FDivs {
+  UDiv x4, y4, z4;
+  bool ok;
+};
+__device__ __forceinline__ FDivs make_f_divs(float hx, float hy, float hz)
+{
+  FDivs s;
+  s.x4 = make_udiv(4.f * hx); s.y4 = make_udiv(4.f * hy); s.z4 = make_udiv(4.f * hz);
+  s.ok = udiv_divisor_ok(s.x4.d) && udiv_divisor_ok(s.y4.d) && udiv_divisor_ok(s.z4.d);
+  return s;
+}
+__device__ __forceinline__ void f_derivatives(float (&q)[3], const FDivs& dv)
+{
+  if (dv.ok && udiv_all_safe(q)) {
+    q[0] = udiv(q[0], dv.x4);
+    q[1] = udiv(q[1], dv.y4);
+    q[2] = udiv(q[2], dv.z4);
+  } else {
+    q[0] = q[0] / dv.x4.d;
+    q[1] = q[1] / dv.y4.d;
+    q[2] = q[2] / dv.z4.d;
+  }
+}
+
+// the six uniform divisors of the solver kernels
+struct SolveDivs {
+  UDiv x2, y2, z2, x4, y4, z4;
+  bool ok;
+};
+__device__ __forceinline__ SolveDivs make_solve_divs(float hx, float hy, float hz)
+{
+  SolveDivs s;
+  s.x2 = make_udiv(2.f * hx); s.y2 = make_udiv(2.f * hy); s.z2 = make_udiv(2.f * hz);
+  s.x4 = make_udiv(4.f * hx); s.y4 = make_udiv(4.f * hy); s.z4 = make_udiv(4.f * hz);
+  s.ok = udiv_divisor_ok(s.x2.d) && udiv_divisor_ok(s.y2.d) && udiv_divisor_ok(s.z2.d) && udiv_divisor_ok(s.x4.d) &&
+         udiv_divisor_ok(s.y4.d) && udiv_divisor_ok(s.z4.d);
+  return s;
+}
+
+// A.3: src/kernels/solve_3d.cu:177-260
+__device__ __forceinline__ void phi_ksi_voxel(const Hood<8>& n, const SolveDivs& dv, float eps_s, float eps_d, float& phi,
+                                              float& ksi)
+{
+  // numerators in the order x, y, z of u, v, w, then of f (the reference's left-to-right sums)
+  float q[12] = {n.xp[U] - n.xm[U] + n.xp[DU] - n.xm[DU],     n.yp[U] - n.ym[U] + n.yp[DU] - n.ym[DU],
+                 n.zp[U] - n.zm[U] + n.zp[DU] - n.zm[DU],     n.xp[V] - n.xm[V] + n.xp[DV] - n.xm[DV],
+                 n.yp[V] - n.ym[V] + n.yp[DV] - n.ym[DV],     n.zp[V] - n.zm[V] + n.zp[DV] - n.zm[DV],
+                 n.xp[Wf] - n.xm[Wf] + n.xp[DW] - n.xm[DW],   n.yp[Wf] - n.ym[Wf] + n.yp[DW] - n.ym[DW],
+                 n.zp[Wf] - n.zm[Wf] + n.zp[DW] - n.zm[DW],   n.xp[F0] - n.xm[F0] + n.xp[F1] - n.xm[F1],
+                 n.yp[F0] - n.ym[F0] + n.yp[F1] - n.ym[F1],   n.zp[F0] - n.zm[F0] + n.zp[F1] - n.zm[F1]};
+  if (dv.ok && udiv_all_safe(q)) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q[3 * c + 0] = udiv(q[3 * c + 0], dv.x2);
+      q[3 * c + 1] = udiv(q[3 * c + 1], dv.y2);
+      q[3 * c + 2] = udiv(q[3 * c + 2], dv.z2);
+    }
+    q[9] = udiv(q[9], dv.x4);
+    q[10] = udiv(q[10], dv.y4);
+    q[11] = udiv(q[11], dv.z4);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q[3 * c + 0] = q[3 * c + 0] / dv.x2.d;
+      q[3 * c + 1] = q[3 * c + 1] / dv.y2.d;
+      q[3 * c + 2] = q[3 * c + 2] / dv.z2.d;
+    }
+    q[9] = q[9] / dv.x4.d;
+    q[10] = q[10] / dv.y4.d;
+    q[11] = q[11] / dv.z4.d;
+  }
+  const float dux = q[0], duy = q[1], duz = q[2], dvx = q[3], dvy = q[4], dvz = q[5], dwx = q[6], dwy = q[7], dwz = q[8];
 
   phi = 1.f / (2.f * sqrtf(dux * dux + duy * duy + duz * duz + dvx * dvx + dvy * dvy + dvz * dvz + dwx * dwx +
                            dwy * dwy + dwz * dwz + eps_s * eps_s));
 
-  const float fx = (n.xp[F0] - n.xm[F0] + n.xp[F1] - n.xm[F1]) / (4.f * hx);
-  const float fy = (n.yp[F0] - n.ym[F0] + n.yp[F1] - n.ym[F1]) / (4.f * hy);
-  const float fz = (n.zp[F0] - n.zm[F0] + n.zp[F1] - n.zm[F1]) / (4.f * hz);
+  const float fx = q[9], fy = q[10], fz = q[11];
   const float ft = n.c[F1] - n.c[F0];
 
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
   const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
   const float J14 = fx * ft, J24 = fy * ft, J34 = fz * ft, J44 = ft * ft;
 
-  const float du = n.c[DU], dv = n.c[DV], dw = n.c[DW];
-  float s = (J11 * du + J12 * dv + J13 * dw + J14) * du + (J12 * du + J22 * dv + J23 * dw + J24) * dv +
-            (J13 * du + J23 * dv + J33 * dw + J34) * dw + (J14 * du + J24 * dv + J34 * dw + J44);
+  const float du = n.c[DU], dv_c = n.c[DV], dw = n.c[DW];
+  float s = (J11 * du + J12 * dv_c + J13 * dw + J14) * du + (J12 * du + J22 * dv_c + J23 * dw + J24) * dv_c +
+            (J13 * du + J23 * dv_c + J33 * dw + J34) * dw + (J14 * du + J24 * dv_c + J34 * dw + J44);
   s = static_cast<float>(s > 0) * s;
   ksi = 1.f / (2.f * sqrtf(s + eps_d * eps_d));
 }
@@ -133,6 +234,8 @@ __device__ __forceinline__ void sweep_voxel_s(const Face6& xm, const Face6& xp, 
                                               float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym, bool has_zp,
                                               bool has_zm, float& r_du, float& r_dv, float& r_dw)
 {
+  // plain IEEE divisions here: k_sweep6 is bound by memory, not by the vector unit (the uniform-divisor form pays in
+  // k_phiksi6 and k_sweep7)
   const float fx = (xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1]) / (4.f * hx);
   const float fy = (yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1]) / (4.f * hy);
   const float fz = (zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]) / (4.f * hz);
@@ -474,6 +577,8 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
   __shared__ float img[2][NA][kTY3 + 2][kLanes];
   __shared__ float hrow[kRing][2][NA][kLanes];
   __shared__ float hcol[kRing][kTY3][kLanes];
+  SolveDivs divs = make_solve_divs(a.hx, a.hy, a.hz);
+  divs.ok = divs.ok && !a.plain_division;
 
   int tile = static_cast<int>(blockIdx.x);
   if (xcd_remap) {
@@ -574,7 +679,7 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
       n.xp[i] = lane_right_or(C.v[i], xcol[i]);
     }
     float phi, ksi;
-    phi_ksi_voxel(n, a.hx, a.hy, a.hz, a.p0, a.p1, phi, ksi);
+    phi_ksi_voxel(n, divs, a.p0, a.p1, phi, ksi);
     asm volatile("" ::"v"(phi), "v"(ksi));
     __builtin_amdgcn_sched_barrier(0);
     if (FULL) {
@@ -657,12 +762,13 @@ struct S3 {
 __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, const Face6& ym, const Face6& yp,
                                              const Face6& zm, const Face6& zp, const float (&c)[kNL], float Uc, float Vc,
                                              float Wc, float dVc, float dWc, float ksi, float hx, float hy, float hz,
-                                             float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym, bool has_zp,
-                                             bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k)
+                                             const FDivs& fd, float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym,
+                                             bool has_zp, bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k)
 {
-  const float fx = (xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1]) / (4.f * hx);
-  const float fy = (yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1]) / (4.f * hy);
-  const float fz = (zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]) / (4.f * hz);
+  float fq[3] = {xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1], yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1],
+                 zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]};
+  f_derivatives(fq, fd);
+  const float fx = fq[0], fy = fq[1], fz = fq[2];
   const float ft = c[LF1] - c[LF0];
 
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
@@ -734,6 +840,8 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
   __shared__ float hrow[kR7][2][9][kLanes];       // raw halo rows of the edge waves, by LDS-DMA
   __shared__ float hcol[kR7][NR][kLanes];         // raw x-halo of a row: [side*32 + near*16 + array], near = adjacent column
   __shared__ float hc1[2][3][2][32];              // S after sweep 1 in the two halo columns: [component][side][core row]
+  FDivs fdivs = make_f_divs(a.hx, a.hy, a.hz);
+  fdivs.ok = fdivs.ok && !a.plain_division;
 
   int tile = static_cast<int>(blockIdx.x);
   if (xcd_remap) {
@@ -927,7 +1035,7 @@ __global__ __launch_bounds__(kLanes*(TY + 3)) void k_sweep7(SolveArgs a, F3dGeo 
         kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
       } else
       sweep_stage1(xm, xp, ym, yp, plane_face(M), plane_face(P), cf.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                   a.p0, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
+                   fdivs, a.p0, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
     }
     const S3 sN = {C.u + r_du, C.v + r_dv, C.w + r_dw};  // what a neighbour reads after sweep 1: U + dU'
     if (do1) {
@@ -1194,6 +1302,8 @@ int f3d_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_d
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 1, "f3d_phi_ksi")) return 1;
   SolveArgs a;
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
   const f3d_devptr in[8] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw};
   for (int i = 0; i < 8; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
   a.in[8] = a.in[9] = nullptr;
@@ -1222,6 +1332,8 @@ int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 1, "f3d_solve_sweep")) return 1;
   SolveArgs a;
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
   const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
   for (int i = 0; i < 10; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
   a.out[0] = f3d_ptr<float>(temp_du);
@@ -1249,6 +1361,8 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 2, "f3d_solve_sweep2")) return 1;
   SolveArgs a;
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
   const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
   for (int i = 0; i < 10; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
   a.out[0] = f3d_ptr<float>(temp_du);

@@ -382,3 +382,34 @@ def test_flow_stats(f3d, oracle, dims, cdims):
         op.destroy()
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("scale", [1e-33, 1e-38, 3e-42])
+def test_phi_ksi_and_fused_sweeps_tiny_numerators(f3d, oracle, scale):
+    """Derivative numerators below 2^-100 (down to subnormal data): the exact-division shortcut by the uniform divisors 2h
+    and 4h (f3d_solve.hip, UDiv) must hand such waves to the ordinary IEEE sequence -- quotients in the subnormal range
+    can be ties.  Same bits as the oracle, which only ever divides the ordinary way."""
+    dims, cdims, h = (70, 21, 9), (128, 24, 9), (7.1, 1.6, 1.25)
+    W, H, D = dims
+    rng = np.random.default_rng(12)
+    arrs = [a * np.float32(scale) for a in solver_inputs(rng, dims, cdims)]
+    arrs[2:5] = solver_inputs(rng, dims, cdims)[2:5]   # u, v, w stay O(1): their differences are normal, du's are tiny
+    arrs[2][:D, :H, :W] = np.float32(0.75)              # ... and constant, so (u+ - u-) + (du+ - du-) is tiny as well
+    arrs[3][:D, :H, :W] = np.float32(-1.5)
+    arrs[4][:D, :H, :W] = np.float32(0.25)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, 7.5)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.out(), dev.out()
+        f3d.check(f3d.hip().f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
+        assert bit_same(dev.get(phi)[:D, :H, :W], phi_o[:D, :H, :W])
+        assert bit_same(dev.get(ksi)[:D, :H, :W], ksi_o[:D, :H, :W])
+        outs = [dev.out() for _ in range(3)]
+        f3d.check(f3d.hip().f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, 7.5, *outs, None))
+        for g, e in zip(outs, s2):
+            assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W])
+    finally:
+        dev.close()

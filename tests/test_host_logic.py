@@ -179,3 +179,24 @@ def test_uninitialised_operator_reports_and_returns(f3d, capfd):
         o.destroy()
     with pytest.raises(f3d.F3dError):
         f3d.Operation("fft")
+
+
+def test_uniform_divisor_identity():
+    """The arithmetic fact the solver kernels' UDiv shortcut rests on (f3d_solve.hip): for binary32 x and d,
+    (float)((double)x * RN64(1 / (double)d)) == x / d whenever the quotient is in the normal range.  Random significands over
+    200 binades and numerators placed next to every kind of rounding boundary of the quotient."""
+    rng = np.random.default_rng(0)
+    bad = 0
+    for trial in range(60):
+        d = np.float32(rng.uniform(1, 64)) if trial % 3 else np.float32(rng.choice([2, 4, 3, 6, 14.2, 6.4, 2.0006, 63.99999]))
+        r = np.float64(1.0) / np.float64(d)
+        m = rng.integers(1 << 23, 1 << 24, size=100000).astype(np.float64)
+        e = rng.integers(-123, 77, size=100000)
+        x = (m * np.exp2(e.astype(np.float64))).astype(np.float32) * rng.choice([-1, 1], size=100000).astype(np.float32)
+        mid = ((rng.integers(1 << 24, 1 << 25, size=100000) | 1).astype(np.float64)) * np.exp2(rng.integers(-60, 60, size=100000) - 24.0)
+        near = (mid * np.float64(d)).astype(np.float32)           # numerators whose quotient sits next to a midpoint
+        for xs in (x, near, np.nextafter(near, np.float32(np.inf)), np.nextafter(near, np.float32(-np.inf))):
+            q_ref = (xs / d).astype(np.float32)
+            q_fast = (xs.astype(np.float64) * r).astype(np.float32)
+            bad += int(np.count_nonzero(q_ref.view(np.uint32) != q_fast.view(np.uint32)))
+    assert bad == 0

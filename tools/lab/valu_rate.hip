@@ -11,6 +11,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed)
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x * 1e-3f; pa[i] = float2v{a[i], a[i] + 1.f}; }
   const float b = seed * 0.999f, c = seed * 1e-3f;
+  const double rd = 1.0 / static_cast<double>(seed * 3.3f);
+  bool tiny = false;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -18,11 +20,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed)
       if (MODE == 1) pa[i] = pa[i] * b + c;         // pk_mul + pk_add: 2 instr, 4 flops
       if (MODE == 2) a[i] = c / (a[i] + b);         // IEEE divide
       if (MODE == 3) a[i] = sqrtf(a[i] + b);        // IEEE sqrt
+      if (MODE == 4) {                              // exact division by a uniform divisor through double: cvt, mul_f64, cvt
+        const float x = a[i] + b;
+        a[i] = static_cast<float>(static_cast<double>(x) * rd);
+      }
+      if (MODE == 5) {                              // ... plus the guard for tiny non-zero numerators (3 integer ops)
+        const float x = a[i] + b;
+        const unsigned u = __float_as_uint(x) & 0x7fffffffu;
+        tiny |= (u - 1u) < 0x0d800000u - 1u;
+        a[i] = static_cast<float>(static_cast<double>(x) * rd);
+      }
     }
   }
   float s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += a[i] + pa[i].x + pa[i].y;
+  if (tiny) s += 1.f;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -56,6 +69,8 @@ int main()
     run<1>("pk mul+add", 2, w);
     run<2>("div(+add)", 1, w);
     run<3>("sqrt(+add)", 1, w);
+    run<4>("udiv f64(+add)", 1, w);
+    run<5>("udiv f64+guard", 1, w);
   }
   return 0;
 }
