@@ -413,3 +413,37 @@ def test_phi_ksi_and_fused_sweeps_tiny_numerators(f3d, oracle, scale):
             assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W])
     finally:
         dev.close()
+
+
+TINY_CASES = [((2, 2, 2), (64, 4, 4)), ((3, 2, 2), (3, 2, 2)), ((65, 2, 3), (128, 2, 3)), ((2, 10, 2), (2, 10, 2)),
+              ((64, 9, 2), (64, 9, 2)), ((129, 19, 3), (192, 20, 3))]
+
+
+@pytest.mark.parametrize("dims,cdims", TINY_CASES)
+def test_solver_kernels_at_minimum_sizes(f3d, oracle, dims, cdims):
+    """Every dimension down to 2 (the smallest the mirror rule m(-1) = 1, m(n) = n - 2 allows): phi/ksi, one sweep and the
+    fused pair; single planes, single rows, one column past a tile."""
+    rng = np.random.default_rng(21)
+    W, H, D = dims
+    h = (1.7, 0.8, 1.1)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, 7.5)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.out(), dev.out()
+        f3d.check(f3d.hip().f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
+        assert bit_same(dev.get(phi)[:D, :H, :W], phi_o[:D, :H, :W])
+        assert bit_same(dev.get(ksi)[:D, :H, :W], ksi_o[:D, :H, :W])
+        o1 = [dev.out() for _ in range(3)]
+        o2 = [dev.out() for _ in range(3)]
+        f3d.check(f3d.hip().f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *o1, None))
+        f3d.check(f3d.hip().f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, 7.5, *o2, None))
+        for g, e in zip(o1, s1):
+            assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W])
+        for g, e in zip(o2, s2):
+            assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W])
+    finally:
+        dev.close()
