@@ -2,13 +2,17 @@
 //
 // Mirrors what src/main.cpp:53-239 of the reference does (load a pair of RAW volumes, run OpticalFlowE with
 // the nine-key parameter bag, write flow-u/v/w as RAW float32), with the compile-time constants turned into
-// flags:  flow3d --dims W H D --frames f0.raw f1.raw [--f32] [--out prefix] [--levels N] [--scale s]
+// flags:  flow3d --dims W H D --frames f0.raw f1.raw [f2.raw ...] [--f32] [--out prefix] [--levels N] [--scale s]
 //                [--outer N] [--inner N] [--alpha a] [--eps-smooth e] [--eps-data e] [--median r] [--sigma s]
-//                [--synthetic] [--vtk] [--silent]
+//                [--synthetic] [--vtk] [--stats] [--silent]
+// More than two frames make a sequence: the driver, its containers and operators are set up once (the reference does
+// Initialize / Destroy per pair, src/main.cpp:150,184) and the flow of every consecutive pair is written as
+// <prefix>_<k>_flow-{u,v,w}-W-H-D.raw.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "hip_utils.h"
 #include "optical_flow.h"
@@ -16,16 +20,17 @@
 
 static void Usage()
 {
-  std::printf("usage: flow3d --dims W H D (--frames f0.raw f1.raw [--f32] | --synthetic) [--out prefix]\n"
+  std::printf("usage: flow3d --dims W H D (--frames f0.raw f1.raw [f2.raw ...] [--f32] | --synthetic) [--out prefix]\n"
               "              [--levels N] [--scale s] [--outer N] [--inner N] [--alpha a] [--eps-smooth e]\n"
-              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--silent]\n");
+              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent]\n");
 }
 
 int main(int argc, char** argv)
 {
   size_t width = 0, height = 0, depth = 0;
-  std::string file_0, file_1, prefix = "flow3d";
-  bool f32_input = false, synthetic = false, write_vtk = false, silent_mode = false;
+  std::vector<std::string> files;
+  std::string prefix = "flow3d";
+  bool f32_input = false, synthetic = false, write_vtk = false, silent_mode = false, print_stats = false;
 
   // defaults of src/main.cpp:77-85
   size_t warp_levels_count = 40;
@@ -47,7 +52,11 @@ int main(int argc, char** argv)
       }
     };
     if (a == "--dims") { need(3); width = std::strtoull(argv[++i], nullptr, 10); height = std::strtoull(argv[++i], nullptr, 10); depth = std::strtoull(argv[++i], nullptr, 10); }
-    else if (a == "--frames") { need(2); file_0 = argv[++i]; file_1 = argv[++i]; }
+    else if (a == "--frames") {
+      need(2);
+      while (i + 1 < argc && std::strncmp(argv[i + 1], "--", 2) != 0) files.push_back(argv[++i]);
+    }
+    else if (a == "--stats") print_stats = true;
     else if (a == "--out") { need(1); prefix = argv[++i]; }
     else if (a == "--levels") { need(1); warp_levels_count = std::strtoull(argv[++i], nullptr, 10); }
     else if (a == "--scale") { need(1); warp_scale_factor = std::strtof(argv[++i], nullptr); }
@@ -64,7 +73,7 @@ int main(int argc, char** argv)
     else if (a == "--silent") silent_mode = true;
     else { Usage(); return 64; }
   }
-  if (width == 0 || height == 0 || depth == 0 || (!synthetic && file_0.empty())) {
+  if (width == 0 || height == 0 || depth == 0 || (!synthetic && files.size() < 2)) {
     Usage();
     return 64;
   }
@@ -75,23 +84,11 @@ int main(int argc, char** argv)
 
   if (!InitDeviceContextWithFirstAvailableDevice()) return 1;
 
-  Data3D frame_0, frame_1;
-  if (synthetic) {
-    if (!frame_0.Allocate(width, height, depth) || !frame_1.Allocate(width, height, depth)) return 2;
-    f3d_synth::TranslatedGaussianPair(width, height, depth, frame_0.DataPtr(), frame_1.DataPtr());
-  } else {
-    const bool ok = f32_input ? (frame_0.ReadRAWFromFileF32(file_0.c_str(), width, height, depth) &&
-                                 frame_1.ReadRAWFromFileF32(file_1.c_str(), width, height, depth))
-                              : (frame_0.ReadRAWFromFileU8(file_0.c_str(), width, height, depth) &&
-                                 frame_1.ReadRAWFromFileU8(file_1.c_str(), width, height, depth));
-    if (!ok) return 2;
-  }
-
   DataSize4 data_size = {width, height, depth, 0};
   OpticalFlowE optical_flow_e;
   if (!optical_flow_e.Initialize(data_size)) return 3;
+  if (!optical_flow_e.AllocateResidentFrames()) return 3;
 
-  Data3D flow_u(width, height, depth), flow_v(width, height, depth), flow_w(width, height, depth);
   OperationParameters params;
   params.PushValuePtr("warp_levels_count", &warp_levels_count);
   params.PushValuePtr("warp_scale_factor", &warp_scale_factor);
@@ -102,17 +99,44 @@ int main(int argc, char** argv)
   params.PushValuePtr("equation_data", &equation_data);
   params.PushValuePtr("median_radius", &median_radius);
   params.PushValuePtr("gaussian_sigma", &gaussian_sigma);
-
   std::printf("Mode: Full GPU mode \n");
   optical_flow_e.silent = silent_mode;
-  optical_flow_e.ComputeFlow(frame_0, frame_1, flow_u, flow_v, flow_w, params);
 
+  auto load = [&](Data3D& frame, const std::string& path) {
+    return f32_input ? frame.ReadRAWFromFileF32(path.c_str(), width, height, depth)
+                     : frame.ReadRAWFromFileU8(path.c_str(), width, height, depth);
+  };
+  Data3D frame_0, frame_1;
+  Data3D flow_u(width, height, depth), flow_v(width, height, depth), flow_w(width, height, depth);
+  const size_t pairs = synthetic ? 1 : files.size() - 1;
+  if (synthetic) {
+    if (!frame_0.Allocate(width, height, depth) || !frame_1.Allocate(width, height, depth)) return 2;
+    f3d_synth::TranslatedGaussianPair(width, height, depth, frame_0.DataPtr(), frame_1.DataPtr());
+  } else if (!load(frame_0, files[0])) {
+    return 2;
+  }
   const std::string suffix =
       "-" + std::to_string(width) + "-" + std::to_string(height) + "-" + std::to_string(depth) + ".raw";
-  flow_u.WriteRAWToFileF32((prefix + "_flow-u" + suffix).c_str());
-  flow_v.WriteRAWToFileF32((prefix + "_flow-v" + suffix).c_str());
-  flow_w.WriteRAWToFileF32((prefix + "_flow-w" + suffix).c_str());
-  if (write_vtk) Data3D::WriteFlowToFileVTK((prefix + "_flow.vtk").c_str(), flow_u, flow_v, flow_w);
+  for (size_t k = 0; k < pairs; ++k) {
+    if (!synthetic && !load(frame_1, files[k + 1])) return 2;
+    optical_flow_e.UploadResidentFrames(frame_0, frame_1);
+    optical_flow_e.ComputeFlowResident(params);
+    if (print_stats) {
+      Stat3 stat = {0.f, 0.f, 0.f};
+      if (optical_flow_e.ResultStatistics(stat))
+        std::printf("Flow magnitude  min: %8.4f  max: %8.4f  avg: %8.4f\n", stat.min, stat.max, stat.avg);
+    }
+    optical_flow_e.DownloadFlow(flow_u, flow_v, flow_w);
+    const std::string tag = pairs > 1 ? prefix + "_" + std::to_string(k) : prefix;
+    flow_u.WriteRAWToFileF32((tag + "_flow-u" + suffix).c_str());
+    flow_v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
+    flow_w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
+    if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), flow_u, flow_v, flow_w);
+    if (pairs > 1) {
+      std::printf("pair %zu of %zu: %.3f s on the device\n", k + 1, pairs, optical_flow_e.LastDeviceSeconds());
+      frame_0.Swap(frame_1);   // the second frame of this pair is the first of the next
+    }
+  }
 
   optical_flow_e.Destroy();
   f3d_shutdown();

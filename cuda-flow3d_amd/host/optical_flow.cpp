@@ -239,6 +239,24 @@ void OpticalFlowE::DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w)
   CopyData3DFromDevice(result_flow_[2], flow_w, dev_container_size_.height, dev_container_size_.pitch);
 }
 
+bool OpticalFlowE::ResultStatistics(Stat3& stat)
+{
+  if (!IsInitialized() || !result_flow_[0]) return false;
+  OperationParameters init;
+  init.PushValuePtr("container_size", &dev_container_size_);
+  if (!cuop_stat_.Initialize(&init)) return false;
+  DataSize4 data_size = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
+  OperationParameters bag;
+  bag.PushValuePtr("dev_flow_u", &result_flow_[0]);
+  bag.PushValuePtr("dev_flow_v", &result_flow_[1]);
+  bag.PushValuePtr("dev_flow_w", &result_flow_[2]);
+  bag.PushValuePtr("data_size", &data_size);
+  bag.PushValuePtr("stat", &stat);
+  cuop_stat_.silent = true;
+  cuop_stat_.Execute(bag);
+  return true;
+}
+
 bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, DevicePtr raw_1, bool raw_is_pooled)
 {
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;

@@ -62,6 +62,9 @@ class OpticalFlowE : public OpticalFlowBase {
   const DataSize4& ContainerSize() const { return dev_container_size_; }
   void ComputeFlowResident(OperationParameters& params);
   void DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w);
+  // min / max / average magnitude of the flow ComputeFlowResident() left on the device (CudaOperationStat); false when there
+  // is none
+  bool ResultStatistics(Stat3& stat);
   float LastDeviceSeconds() const { return last_device_seconds_; }
 
  private:
@@ -86,6 +89,7 @@ class OpticalFlowE : public OpticalFlowBase {
   CudaOperationRegistration cuop_register_;
   CudaOperationResample cuop_resample_;
   CudaOperationSolve cuop_solve_;
+  CudaOperationStat cuop_stat_;  // not in the list below: the reference's single-GPU driver has six operators
   std::vector<CudaOperationBase*> cuda_operations_;
 };
 

@@ -168,3 +168,39 @@ def test_missing_key_is_reported_not_fatal(f3d, capfd):
     cont.free()
     flush_c_stdio()
     assert "Missing parameter 'operand_1'" in capfd.readouterr().out
+
+
+def test_cli_frame_sequence_and_stats(f3d, tmp_path):
+    """bin/flow3d on three frames: one Initialize, the flow of every consecutive pair written, --stats printing what
+    the device statistics operator returns; each pair equals a fresh OpticalFlow.compute of the same two frames."""
+    import re
+    import subprocess
+    W, H, D = 48, 40, 24
+    f0, f1 = f3d.synth_pair(W, H, D)
+    frames = [np.round(np.clip(f0, 0, 255)), np.round(np.clip(f1, 0, 255)), np.round(np.clip(0.5 * (f0 + f1), 0, 255))]
+    paths = []
+    for k, fr in enumerate(frames):
+        p = tmp_path / f"frame{k}.raw"
+        fr.astype(np.uint8).tofile(p)
+        paths.append(str(p))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow3d_amd", "bin", "flow3d")
+    prefix = str(tmp_path / "seq")
+    kw = dict(warp_levels_count=5, outer_iterations_count=3)
+    run = subprocess.run([exe, "--dims", str(W), str(H), str(D), "--frames", *paths, "--out", prefix, "--levels", "5", "--outer", "3",
+                          "--stats", "--silent"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    stats = re.findall(r"Flow magnitude\s+min:\s*([\d.]+)\s+max:\s*([\d.]+)\s+avg:\s*([\d.]+)", run.stdout)
+    assert len(stats) == 2, run.stdout
+    for k in range(2):
+        a = frames[k].astype(np.uint8).astype(np.float32)
+        b = frames[k + 1].astype(np.uint8).astype(np.float32)
+        flow = f3d.OpticalFlow()
+        flow.initialize(W, H, D)
+        exp = flow.compute(a, b, silent=True, **kw)
+        flow.destroy()
+        got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}.raw", np.float32).reshape(D, H, W) for c in "uvw"]
+        for g, e in zip(got, exp):
+            assert same(g, e)
+        mag = np.sqrt(exp[0] * exp[0] + exp[1] * exp[1] + exp[2] * exp[2])
+        mn, mx, avg = (float(v) for v in stats[k])
+        assert abs(mn - mag.min()) < 1e-3 and abs(mx - mag.max()) < 1e-3 and abs(avg - mag.mean()) < 1e-3
