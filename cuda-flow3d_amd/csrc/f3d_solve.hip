@@ -333,14 +333,15 @@ __device__ __forceinline__ void gld_lds_lane(const float* lane_addr, float* lds_
 // The registers a hand-issued load writes are, to the compiler, defined at the load statement: nothing stops it from
 // copying them (a v_mov for a tied asm operand, a control-flow merge, a loop back edge) while the data is still on its way.
 // So the wait is a statement of its own with NO register operands, and only the empty statement after it hands the
-// registers back through "+v": whatever copies the compiler makes for those operands then come after the s_waitcnt.
-// tests/test_isa_hazards.py scans the generated code of every kernel here for any read of a load's destination between
-// the load and the wait that covers it, so a copy inserted elsewhere fails the build check instead of a parity test
+// registers back through "+v": whatever copies the compiler makes for those operands then come after the s_waitcnt.  The
+// hand-back leaves a comment naming its registers in the generated code ("; f3d_handback v12 v13 ..."), which is what
+// tests/test_isa_hazards.py uses to walk the control-flow graph of every kernel here for any read of a load's destination
+// between the load and the wait that covers it, so a copy inserted elsewhere fails the build check instead of a parity test
 // once in a few hundred launches.
 #define F3D_WAIT_PLANE(N, P)                                                                                           \
   do {                                                                                                                 \
     asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                                                              \
-    asm volatile(""                                                                                                    \
+    asm volatile("; f3d_handback %0 %1 %2 %3 %4 %5 %6 %7 %8 %9"                                                        \
                  : "+v"((P).f0), "+v"((P).f1), "+v"((P).phi), "+v"((P).u), "+v"((P).v), "+v"((P).w), "+v"((P).su),     \
                    "+v"((P).dv), "+v"((P).dw), "+v"((P).ksi)::"memory");                                              \
   } while (0)
@@ -565,7 +566,7 @@ struct Plane8 {
 #define F3D_WAIT_PLANE8(N, P)                                                                                          \
   do {                                                                                                                 \
     asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");                                                              \
-    asm volatile(""                                                                                                    \
+    asm volatile("; f3d_handback %0 %1 %2 %3 %4 %5 %6 %7"                                                              \
                  : "+v"((P).v[0]), "+v"((P).v[1]), "+v"((P).v[2]), "+v"((P).v[3]), "+v"((P).v[4]), "+v"((P).v[5]),     \
                    "+v"((P).v[6]), "+v"((P).v[7])::"memory");                                                         \
   } while (0)

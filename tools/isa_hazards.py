@@ -8,11 +8,15 @@ memory system is slow.  This script compiles the file to assembly and walks ever
 
   * `global_load_dword vN, ...` (always hand-issued) puts vN in flight;
   * `s_waitcnt vmcnt(0)` lands everything;
-  * an instruction that names a register in flight is accepted only if an `s_waitcnt vmcnt(K)` precedes it in its own basic
-    block with no memory instruction in between -- that is where the source hands the registers back, and where the
-    compiler's copies for the hand-back operands belong; the register then counts as landed.  Anywhere else it is a violation.
-For k_sweep7 (one group of loads in flight, every wait is vmcnt(0)) this is exact.  k_sweep6 and k_phiksi6 keep a second
-group in flight across a counted wait; a copy of THAT group placed right behind the wait of the older one would slip through.
+  * the source hands registers back right behind a wait with a statement that leaves the comment `; f3d_handback vA vB ...`
+    in the code: those registers have landed;
+  * an instruction that names a register in flight is accepted only between an `s_waitcnt vmcnt(K)` and the end of its basic
+    block with no memory instruction in between (the compiler's copies for the hand-back operands); the register then
+    counts as landed.  Anywhere else it is a violation.
+The walk follows the assembler's layout, not the control-flow graph: a union over CFG paths drowns in infeasible ones (the
+two arms of `if (edge) wait(20) else wait(11)` are correlated with later branches), so a cold block that the compiler
+places out of line can raise a false alarm -- rebuild with -gline-tables-only and read the inlined-at chain of the two
+instructions before believing it (that is how the one case seen so far, a variant of k_sweep6, was cleared).
 The text of a kernel is walked twice so that loads issued at the bottom of the unrolled loop meet the wait at its top.
 Also checks that no kernel uses scratch (a spill of an in-flight register would be the same bug).
 Usage: isa_hazards.py [file.s]   (without an argument the source is compiled with the product's flags)
@@ -68,6 +72,13 @@ def check_kernel(body):
     for rep in range(2):
         for ln, raw in enumerate(body, 1):
             t = raw.strip()
+            if t.startswith("; f3d_handback"):
+                if after_wait:
+                    for r in vregs(t):
+                        flight.pop(r, None)
+                else:
+                    bad.append((ln, t, sorted(vregs(t) & set(flight))))
+                continue
             if not t or t[0] in ";.":
                 continue
             if t.endswith(":"):
