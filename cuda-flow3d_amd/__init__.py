@@ -74,7 +74,10 @@ def hip():
         "f3d_memset2d": [_dp, _sz, C.c_int, _sz, _sz],
         "f3d_copy3d_h2d": [_dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz],
         "f3d_copy3d_d2h": [_fp, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
-        "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)],
+        "f3d_copy_planes_h2d": [_dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz, _sz, _sz],
+        "f3d_copy_planes_d2h": [_fp, _sz, _sz, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
+        "f3d_host_register": [C.c_void_p, _sz], "f3d_host_unregister": [C.c_void_p],
+        "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)], "f3d_get_container": [C.POINTER(Size4)],
         "f3d_event_create": [C.POINTER(C.c_void_p)], "f3d_event_record": [C.c_void_p],
         "f3d_event_sync": [C.c_void_p], "f3d_event_elapsed_ms": [_fp, C.c_void_p, C.c_void_p],
         "f3d_event_destroy": [C.c_void_p], "f3d_stream_sync": [],
@@ -151,6 +154,12 @@ def host():
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
         "f3d_plan_resample_source": [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2,
+        "f3d_volume_wrap": [C.POINTER(C.c_void_p), _fp, _sz, _sz, _sz], "f3d_volume_destroy": [C.c_void_p],
+        "f3d_op_solve_p_last": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)],
+        "f3d_plan_solve_piecemeal": [_sz, _sz, _sz, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
+        "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
+        "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
+        "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -162,6 +171,12 @@ def host():
     L.f3d_op_name.restype = C.c_char_p
     L.f3d_max_warp_level.argtypes = [_sz, _sz, _sz, C.c_float]
     L.f3d_max_warp_level.restype = _sz
+    L.f3d_volume_object.argtypes = [C.c_void_p]
+    L.f3d_volume_object.restype = C.c_void_p
+    L.f3d_volume_data.argtypes = [C.c_void_p]
+    L.f3d_volume_data.restype = C.c_void_p
+    L.f3d_piecemeal_budget_bytes.argtypes = []
+    L.f3d_piecemeal_budget_bytes.restype = _sz
     _host = L
     return L
 
@@ -335,6 +350,45 @@ class Stat3(C.Structure):
     _fields_ = [("min", C.c_float), ("max", C.c_float), ("avg", C.c_float)]
 
 
+class HostVolume:
+    """Dense host volume [z, y, x] float32 handed to the piecemeal operators as a Data3D* (f3d_volume_wrap).  Like the
+    reference's Data3D::Swap, registration_p / solve_p exchange STORAGE between the volumes of one call, so .array looks
+    the current storage up among all wrapped arrays."""
+    _storage = {}
+
+    def __init__(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        if a.ndim != 3:
+            raise ValueError("volume must be [z, y, x]")
+        self._h = C.c_void_p()
+        d, h, w = a.shape
+        check(host().f3d_volume_wrap(C.byref(self._h), a.ctypes.data_as(_fp), w, h, d), "f3d_volume_wrap")
+        HostVolume._storage[a.ctypes.data] = a
+        self._first = a.ctypes.data
+
+    @property
+    def object(self):
+        return host().f3d_volume_object(self._h)
+
+    @property
+    def array(self):
+        return HostVolume._storage[host().f3d_volume_data(self._h)]
+
+    def destroy(self):
+        if self._h:
+            host().f3d_volume_destroy(self._h)
+            self._h = C.c_void_p()
+            HostVolume._storage.pop(self._first, None)
+
+
+def plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass=0):
+    """(chunk, outer_per_pass, halo, max_planes) the piecemeal solver would use for a level (host arithmetic)."""
+    out = [C.c_int() for _ in range(4)]
+    check(host().f3d_plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations,
+                                          forced_outer_per_pass, *[C.byref(o) for o in out]))
+    return tuple(o.value for o in out)
+
+
 class Operation:
     """One of the operators (add, convolution, median, registration, resample, solve, stat), driven exactly like the reference drives them: Initialize({"container_size"}),
     Execute(bag of pointers to caller variables).  After execute() the (possibly swapped) pointer values are
@@ -362,8 +416,11 @@ class Operation:
 
     def execute(self, **params):
         store = {}
+        volumes = {}
         for k, v in params.items():
-            if k in _PTR_KEYS:
+            if isinstance(v, HostVolume):
+                volumes[k] = v          # Data3D* keys of the piecemeal operators: the bag holds the object itself
+            elif k in _PTR_KEYS:
                 store[k] = _dp(v)
             elif k in _SIZE_T_KEYS:
                 store[k] = _sz(v)
@@ -371,16 +428,25 @@ class Operation:
                 store[k] = C.c_float(v)
             elif k in _SIZE4_KEYS:
                 store[k] = Size4(v[0], v[1], v[2], 0) if not isinstance(v, Size4) else v
+            elif k == "max_mag":
+                store[k] = _sz(v)
             elif k == "stat":
                 store[k] = v            # a Stat3 the operator fills in
             else:
                 raise TypeError(f"unknown parameter key {k!r}")
-        n = len(store)
-        keys = (C.c_char_p * n)(*[k.encode() for k in store])
-        ptrs = (C.c_void_p * n)(*[C.cast(C.byref(v), C.c_void_p) for v in store.values()])
+        n = len(store) + len(volumes)
+        keys = (C.c_char_p * n)(*[k.encode() for k in list(store) + list(volumes)])
+        ptrs = (C.c_void_p * n)(*([C.cast(C.byref(v), C.c_void_p) for v in store.values()] +
+                                  [C.c_void_p(v.object) for v in volumes.values()]))
         check(host().f3d_op_execute(self._h, keys, ptrs, n), "f3d_op_execute")
         self.values = {k: (v.value if hasattr(v, "value") else v) for k, v in store.items()}
         return self.values
+
+    def solve_p_last(self):
+        """(chunk, outer_per_pass, halo, passes) of the last solve_p execute"""
+        c, n, h, p = C.c_int(), C.c_int(), C.c_int(), _sz()
+        check(host().f3d_op_solve_p_last(self._h, C.byref(c), C.byref(n), C.byref(h), C.byref(p)), "f3d_op_solve_p_last")
+        return c.value, n.value, h.value, p.value
 
     def destroy(self):
         if self._h:
@@ -437,6 +503,47 @@ class OpticalFlow:
     def destroy(self):
         if self._h:
             host().f3d_flow_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class PiecemealOpticalFlow:
+    """OpticalFlowP: every volume stays in host memory, z-chunks stream through the device (no pre-blur, no median, like
+    the reference's piecemeal driver).  F3D_P_BUDGET_MB bounds the device memory it uses."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(host().f3d_pflow_create(C.byref(self._h)), "f3d_pflow_create")
+        self.device_seconds = 0.0
+
+    def initialize(self, width, height, depth):
+        if host().f3d_pflow_initialize(self._h, width, height, depth) != 0:
+            raise F3dError("OpticalFlowP::Initialize failed: " + (hip().f3d_last_error() or b"").decode())
+        self.dims = (width, height, depth)
+        return True
+
+    def compute(self, frame_0, frame_1, silent=True, **kw):
+        f0, p0 = _f32(frame_0)
+        f1, p1 = _f32(frame_1)
+        w, h, d = self.dims
+        if f0.shape != (d, h, w) or f1.shape != (d, h, w):
+            raise ValueError(f"frames must be [z,y,x] = {(d, h, w)}")
+        u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
+        prm = make_params(**kw)
+        secs = C.c_float()
+        check(host().f3d_pflow_compute(self._h, p0, p1, w, h, d, C.byref(prm), int(silent), u.ctypes.data_as(_fp),
+                                       v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp), C.byref(secs)), "f3d_pflow_compute")
+        self.device_seconds = secs.value
+        return u, v, ww
+
+    def stats(self):
+        """(solver residencies, levels that did not fit the budget) of the last compute"""
+        a, b = _sz(), _sz()
+        check(host().f3d_pflow_stats(self._h, C.byref(a), C.byref(b)), "f3d_pflow_stats")
+        return a.value, b.value
+
+    def destroy(self):
+        if self._h:
+            host().f3d_pflow_destroy(self._h)
             self._h = C.c_void_p()
 
 

@@ -311,6 +311,62 @@ int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_de
   return 0;
 }
 
+// Plane-range copies between a host volume with its own row / plane strides (a level's sub-box inside a full-size dense
+// volume) and a pitched container.  Asynchronous on the library stream: with page-locked host memory (f3d_host_register)
+// the call returns at once and the caller orders reuse of the host planes with f3d_stream_sync().
+int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
+                        size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth)
+{
+  F3D_REQUIRE_READY("f3d_copy_planes_h2d");
+  if (depth == 0) return 0;
+  if (!src || height > dev_height || width * sizeof(float) > dev_pitch || width > src_row_floats || height > src_rows)
+    return f3d::fail("f3d_copy_planes_h2d: %zux%zu does not fit the container or the host volume", width, height);
+  char* d = f3d_ptr<char>(dst) + dev_plane0 * dev_height * dev_pitch;
+  const size_t wb = width * sizeof(float), sb = src_row_floats * sizeof(float);
+  if (height == dev_height && height == src_rows) {
+    F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, sb, wb, height * depth, hipMemcpyHostToDevice, S.stream));
+  } else {
+    for (size_t z = 0; z < depth; ++z)
+      F3D_HIP(hipMemcpy2DAsync(d + z * dev_height * dev_pitch, dev_pitch, src + z * src_rows * src_row_floats, sb, wb, height,
+                               hipMemcpyHostToDevice, S.stream));
+  }
+  return 0;
+}
+
+int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height, size_t depth,
+                        f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0)
+{
+  F3D_REQUIRE_READY("f3d_copy_planes_d2h");
+  if (depth == 0) return 0;
+  if (!dst || height > dev_height || width * sizeof(float) > dev_pitch || width > dst_row_floats || height > dst_rows)
+    return f3d::fail("f3d_copy_planes_d2h: %zux%zu does not fit the container or the host volume", width, height);
+  const char* s = f3d_ptr<const char>(src) + dev_plane0 * dev_height * dev_pitch;
+  const size_t wb = width * sizeof(float), db = dst_row_floats * sizeof(float);
+  if (height == dev_height && height == dst_rows) {
+    F3D_HIP(hipMemcpy2DAsync(dst, db, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, S.stream));
+  } else {
+    for (size_t z = 0; z < depth; ++z)
+      F3D_HIP(hipMemcpy2DAsync(dst + z * dst_rows * dst_row_floats, db, s + z * dev_height * dev_pitch, dev_pitch, wb, height,
+                               hipMemcpyDeviceToHost, S.stream));
+  }
+  return 0;
+}
+
+int f3d_host_register(void* ptr, size_t bytes)
+{
+  F3D_REQUIRE_READY("f3d_host_register");
+  if (!ptr || bytes == 0) return f3d::fail("f3d_host_register: empty range");
+  F3D_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return 0;
+}
+
+int f3d_host_unregister(void* ptr)
+{
+  F3D_REQUIRE_READY("f3d_host_unregister");
+  F3D_HIP(hipHostUnregister(ptr));
+  return 0;
+}
+
 int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes)
 {
   F3D_REQUIRE_READY("f3d_copy_d2d");
@@ -324,6 +380,13 @@ int f3d_set_container(const f3d_size4* c)
       c->pitch % sizeof(float) != 0)
     return f3d::fail("f3d_set_container: invalid container size");
   S.container = *c;
+  return 0;
+}
+
+int f3d_get_container(f3d_size4* c)
+{
+  if (!c) return f3d::fail("f3d_get_container: null output");
+  *c = S.container;
   return 0;
 }
 

@@ -6,7 +6,9 @@
 #include "f3d_host.h"
 #include "hip_utils.h"
 #include "operations.h"
+#include "operations_p.h"
 #include "optical_flow.h"
+#include "optical_flow_p.h"
 #include "optical_flow_slab.h"
 #include "synth.h"
 
@@ -18,6 +20,15 @@ struct f3d_flow_s {
 struct f3d_slabflow_s {
   OpticalFlowSlab* driver = nullptr;
   ~f3d_slabflow_s() { delete driver; }
+};
+
+struct f3d_pflow_s {
+  OpticalFlowP driver;
+};
+
+struct f3d_volume_s {
+  Data3D view;
+  f3d_volume_s(float* data, size_t w, size_t h, size_t d) : view(data, w, h, d) {}
 };
 
 struct f3d_op_s {
@@ -149,6 +160,11 @@ int f3d_op_create(f3d_op* op, const char* name)
   else if (n == "resample") impl = new CudaOperationResample;
   else if (n == "solve") impl = new CudaOperationSolve;
   else if (n == "stat") impl = new CudaOperationStat;
+  else if (n == "add_p") impl = new CudaOperationAddP;
+  else if (n == "resample_p") impl = new CudaOperationResampleP;
+  else if (n == "registration_p") impl = new CudaOperationRegistrationP;
+  else if (n == "solve_p") impl = new CudaOperationSolveP;
+  else if (n == "stat_p") impl = new CudaOperationStatP;
   if (!impl) return 1;
   *op = new f3d_op_s;
   (*op)->op = impl;
@@ -173,6 +189,8 @@ int f3d_op_execute(f3d_op op, const char* const* keys, void* const* value_ptrs, 
   OperationParameters bag;
   for (size_t i = 0; i < count; ++i) bag.PushValuePtr(keys[i], value_ptrs[i]);
   if (auto* solve = dynamic_cast<CudaOperationSolve*>(op->op)) solve->silent = true;
+  if (auto* solve_p = dynamic_cast<CudaOperationSolveP*>(op->op)) solve_p->silent = true;
+  if (auto* stat_p = dynamic_cast<CudaOperationStatP*>(op->op)) stat_p->silent = true;
   op->op->Execute(bag);
   return 0;
 }
@@ -188,6 +206,96 @@ int f3d_op_destroy(f3d_op op)
 {
   if (op) op->op->Destroy();
   delete op;
+  return 0;
+}
+
+int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes)
+{
+  auto* solve_p = op ? dynamic_cast<CudaOperationSolveP*>(op->op) : nullptr;
+  if (!solve_p) return 1;
+  if (chunk) *chunk = solve_p->LastPlan().chunk;
+  if (outer_per_pass) *outer_per_pass = solve_p->LastPlan().outer_per_pass;
+  if (halo) *halo = solve_p->LastPlan().halo;
+  if (passes) *passes = solve_p->LastPasses();
+  return 0;
+}
+
+int f3d_volume_wrap(f3d_volume* vol, float* data, size_t width, size_t height, size_t depth)
+{
+  if (!vol || !data || width == 0 || height == 0 || depth == 0) return 1;
+  *vol = new (std::nothrow) f3d_volume_s(data, width, height, depth);
+  return *vol ? 0 : 1;
+}
+
+void* f3d_volume_object(f3d_volume vol) { return vol ? &vol->view : nullptr; }
+
+float* f3d_volume_data(f3d_volume vol) { return vol ? vol->view.DataPtr() : nullptr; }
+
+int f3d_volume_destroy(f3d_volume vol)
+{
+  delete vol;
+  return 0;
+}
+
+int f3d_pflow_create(f3d_pflow* flow)
+{
+  if (!flow) return 1;
+  *flow = new (std::nothrow) f3d_pflow_s;
+  return *flow ? 0 : 1;
+}
+
+int f3d_pflow_initialize(f3d_pflow flow, size_t width, size_t height, size_t depth)
+{
+  if (!flow) return 1;
+  if (f3d_init(-1) != 0) {
+    std::fprintf(stderr, "f3d_pflow_initialize: %s\n", f3d_last_error());
+    return 1;
+  }
+  DataSize4 size = {width, height, depth, 0};
+  return flow->driver.Initialize(size) ? 0 : 1;
+}
+
+int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1, size_t width, size_t height, size_t depth,
+                      const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds)
+{
+  if (!flow || !frame_0 || !frame_1 || !params || !u || !v || !w) return 1;
+  Data3D f0(const_cast<float*>(frame_0), width, height, depth), f1(const_cast<float*>(frame_1), width, height, depth);
+  Data3D fu(u, width, height, depth), fv(v, width, height, depth), fw(w, width, height, depth);
+  f3d_flow_params p = *params;
+  OperationParameters bag;
+  FillBag(bag, p);
+  flow->driver.silent = silent != 0;
+  flow->driver.ComputeFlow(f0, f1, fu, fv, fw, bag);
+  if (device_seconds) *device_seconds = flow->driver.LastDeviceSeconds();
+  // the driver hands every caller volume its own storage back; anything else would lose the result
+  return (f0.DataPtr() == frame_0 && f1.DataPtr() == frame_1 && fu.DataPtr() == u && fv.DataPtr() == v && fw.DataPtr() == w) ? 0 : 1;
+}
+
+int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels)
+{
+  if (!flow) return 1;
+  if (solve_passes) *solve_passes = flow->driver.LastSolvePasses();
+  if (streamed_levels) *streamed_levels = flow->driver.LastStreamedLevels();
+  return 0;
+}
+
+int f3d_pflow_destroy(f3d_pflow flow)
+{
+  delete flow;
+  return 0;
+}
+
+size_t f3d_piecemeal_budget_bytes(void) { return PiecemealBudgetBytes(); }
+
+int f3d_plan_solve_piecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations, int outer_iterations,
+                             int forced_outer_per_pass, int* chunk, int* outer_per_pass, int* halo, int* max_planes)
+{
+  const SolvePiecemealPlan plan =
+      PlanSolvePiecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass);
+  if (chunk) *chunk = plan.chunk;
+  if (outer_per_pass) *outer_per_pass = plan.outer_per_pass;
+  if (halo) *halo = plan.halo;
+  if (max_planes) *max_planes = plan.max_planes;
   return 0;
 }
 

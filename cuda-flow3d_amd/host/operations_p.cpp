@@ -1,0 +1,571 @@
+// Piecemeal operators: z-chunks of host volumes streamed through one device arena (see operations_p.h).  Parameter keys
+// and the print-and-return error convention follow src/cuda_operations/partial_data/cuda_operation_*_p.cpp; the chunking
+// itself is new.  All copies and launches of one Execute are queued on the library stream in order; Execute returns after
+// the stream has drained, so the host volumes are complete.
+#include "operations_p.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <utility>
+#include <vector>
+
+#include "common_utils.h"
+#include "hip_utils.h"
+#include "slab_plan.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+constexpr size_t kFieldSkew = 17 * kAlign;  // same stagger as f3d_alloc_pitched: fields must not share every stride
+
+size_t RoundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// One device block shared by all piecemeal operators; grows to the largest request and is reused across calls.
+struct Arena {
+  DevicePtr base = 0;
+  size_t bytes = 0;
+} g_arena;
+
+DevicePtr ArenaReserve(size_t bytes)
+{
+  if (bytes <= g_arena.bytes) return g_arena.base;
+  PiecemealReleaseArena();
+  size_t pitch = 0;
+  DevicePtr p = 0;
+  if (CheckDeviceError(f3d_alloc_pitched(&p, &pitch, bytes, 1))) return 0;
+  g_arena.base = p;
+  g_arena.bytes = bytes;
+  return p;
+}
+
+// Compact container of one level: rows of `pitch` bytes, `H` rows per plane.
+struct ChunkBox {
+  size_t W = 0, H = 0, pitch = 0, plane = 0;
+  ChunkBox(size_t w, size_t h) : W(w), H(h), pitch(RoundUp(w * sizeof(float), kAlign)), plane(pitch * h) {}
+  size_t FieldBytes(size_t planes) const { return RoundUp(planes * plane, kAlign) + kFieldSkew; }
+  // planes that `buffers` buffers may hold in total
+  size_t TotalPlanes(size_t budget, size_t buffers) const
+  {
+    const size_t overhead = buffers * (kFieldSkew + kAlign);
+    return budget > overhead ? (budget - overhead) / plane : 0;
+  }
+};
+
+// Carves buffers out of the arena, one after the other.
+class Carver {
+ public:
+  explicit Carver(const ChunkBox& box) : box_(box) {}
+  void Add(size_t planes) { sizes_.push_back(planes); }
+  bool Commit()
+  {
+    size_t total = 0;
+    for (size_t p : sizes_) total += box_.FieldBytes(p);
+    const DevicePtr base = ArenaReserve(total);
+    if (!base) return false;
+    size_t at = 0;
+    for (size_t p : sizes_) {
+      ptrs_.push_back(base + at);
+      at += box_.FieldBytes(p);
+    }
+    return true;
+  }
+  DevicePtr operator[](size_t i) const { return ptrs_[i]; }
+
+ private:
+  const ChunkBox& box_;
+  std::vector<size_t> sizes_;
+  std::vector<DevicePtr> ptrs_;
+};
+
+// Switches the device library to a chunk geometry and puts the caller's container back afterwards, so resident
+// operators initialised earlier keep working.
+class ContainerScope {
+ public:
+  ContainerScope(const ChunkBox& box, size_t planes)
+  {
+    had_ = f3d_get_container(&old_) == 0 && old_.pitch != 0;
+    f3d_size4 c = {box.W, box.H, planes, box.pitch};
+    ok_ = !CheckDeviceError(f3d_set_container(&c));
+  }
+  ~ContainerScope()
+  {
+    if (had_) f3d_set_container(&old_);
+  }
+  bool ok() const { return ok_; }
+
+ private:
+  f3d_size4 old_ = {0, 0, 0, 0};
+  bool had_ = false, ok_ = false;
+};
+
+bool Fits(const Data3D& v, const DataSize4& s) { return s.width <= v.Width() && s.height <= v.Height() && s.depth <= v.Depth(); }
+
+float* PlanePtr(Data3D& v, int z) { return v.DataPtr() + static_cast<size_t>(z) * v.Width() * v.Height(); }
+
+bool Upload(DevicePtr dst, const ChunkBox& b, int dev_plane0, Data3D& v, size_t w, size_t h, int z0, int count)
+{
+  return !CheckDeviceError(f3d_copy_planes_h2d(dst, b.pitch, b.H, dev_plane0, PlanePtr(v, z0), v.Width(), v.Height(), w, h, count));
+}
+
+bool Download(Data3D& v, size_t w, size_t h, int z0, int count, DevicePtr src, const ChunkBox& b, int dev_plane0)
+{
+  return !CheckDeviceError(f3d_copy_planes_d2h(PlanePtr(v, z0), v.Width(), v.Height(), w, h, count, src, b.pitch, b.H, dev_plane0));
+}
+
+// pointer under which container plane (z - new_base) is the plane the buffer holds for z at (z - old_base)
+DevicePtr Rebase(DevicePtr p, const ChunkBox& b, int old_base, int new_base)
+{
+  const int64_t shift = (static_cast<int64_t>(new_base) - old_base) * static_cast<int64_t>(b.plane);
+  return static_cast<DevicePtr>(static_cast<int64_t>(p) + shift);
+}
+
+void LowMemory(const char* name)
+{
+  std::printf("Operation '%s': Error. Low GPU memory. Data cannot be partitioned properly.\n", name);
+}
+
+}  // namespace
+
+size_t PiecemealBudgetBytes()
+{
+  if (const char* e = std::getenv("F3D_P_BUDGET_MB")) {
+    const double mb = std::atof(e);
+    if (mb > 0) return static_cast<size_t>(mb * 1024.0 * 1024.0);
+  }
+  size_t free_b = 0, total_b = 0;
+  if (CheckDeviceError(f3d_mem_info(&free_b, &total_b))) return 0;
+  return static_cast<size_t>(0.85 * static_cast<double>(free_b + g_arena.bytes));
+}
+
+void PiecemealReleaseArena()
+{
+  if (g_arena.base) {
+    f3d_stream_sync();
+    CheckDeviceError(f3d_free(g_arena.base));
+  }
+  g_arena.base = 0;
+  g_arena.bytes = 0;
+}
+
+SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
+                                      int outer_iterations, int forced_outer_per_pass)
+{
+  SolvePiecemealPlan plan;
+  const ChunkBox box(width, height);
+  const size_t total = box.TotalPlanes(budget_bytes, 13);
+  plan.max_planes = static_cast<int>(std::min<size_t>(total / 13, static_cast<size_t>(std::numeric_limits<int>::max())));
+  if (depth <= 0 || outer_iterations <= 0) return plan;
+  if (plan.max_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
+    plan.chunk = depth;
+    plan.outer_per_pass = outer_iterations;
+    plan.halo = 0;
+    return plan;
+  }
+  const int step = inner_iterations + 1;
+  // Cost per owned plane of one full solve, in arbitrary time units: link bytes at ~50 GB/s (eight fields up with their
+  // halos, three down, per pass) against device bytes at ~5 TB/s (300 B per voxel and outer iteration on windows that
+  // average chunk + halo planes).
+  double best = 0.0;
+  for (int n = 1; n <= outer_iterations; ++n) {
+    if (forced_outer_per_pass > 0 && n != std::min(forced_outer_per_pass, outer_iterations)) continue;
+    const int halo = n * step;
+    const int chunk = plan.max_planes - 2 * halo;
+    if (chunk < 1) break;
+    const double passes = std::ceil(static_cast<double>(outer_iterations) / n);
+    const double wide = static_cast<double>(chunk + 2 * halo) / chunk, mid = static_cast<double>(chunk + halo) / chunk;
+    const double link = passes * (8.0 * wide + 3.0) * 4.0 / 50e9;
+    const double device = outer_iterations * 300.0 * mid / 5e12;
+    const double cost = link + device;
+    if (plan.chunk == 0 || cost < best) {
+      best = cost;
+      plan.chunk = chunk;
+      plan.outer_per_pass = n;
+      plan.halo = halo;
+    }
+  }
+  return plan;
+}
+
+bool CudaOperationPiecemealBase::Initialize(const OperationParameters*)
+{
+  size_t free_b = 0, total_b = 0;
+  initialized_ = !CheckDeviceError(f3d_mem_info(&free_b, &total_b));  // needs a live device context, nothing else
+  return initialized_;
+}
+
+// ---- add (cuda_operation_add_p.cpp:52-214) ----------------------------------------------------------------------
+
+void CudaOperationAddP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_operand_0, *p_operand_1;
+  DataSize4 data_size;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_operand_0, "operand_0");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_operand_1, "operand_1");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  if (!Fits(*p_operand_0, data_size) || !Fits(*p_operand_1, data_size)) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return;
+  }
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  if (W == 0 || H == 0 || D == 0) return;
+  const ChunkBox box(W, H);
+  const int chunk = static_cast<int>(std::min<size_t>(box.TotalPlanes(PiecemealBudgetBytes(), 2) / 2, D));
+  if (chunk < 1) return LowMemory(GetName());
+  Carver buf(box);
+  buf.Add(chunk);
+  buf.Add(chunk);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, chunk);
+  if (!scope.ok()) return;
+  for (int z0 = 0; z0 < D; z0 += chunk) {
+    const int z1 = std::min(D, z0 + chunk);
+    const f3d_slab slab = {z0, z0, z1};
+    if (!Upload(buf[0], box, 0, *p_operand_0, W, H, z0, z1 - z0) || !Upload(buf[1], box, 0, *p_operand_1, W, H, z0, z1 - z0)) return;
+    if (CheckDeviceError(f3d_add(buf[0], buf[1], W, H, D, &slab))) return;
+    if (!Download(*p_operand_0, W, H, z0, z1 - z0, buf[0], box, 0)) return;
+  }
+  CheckDeviceError(f3d_stream_sync());
+}
+
+// ---- statistics (cuda_operation_stat_p.cpp:44-107) ----------------------------------------------------------------
+
+void CudaOperationStatP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_flow_u, *p_flow_v, *p_flow_w;
+  DataSize4 data_size;
+  Stat3* p_stat;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_u, "flow_u");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_v, "flow_v");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_w, "flow_w");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_PTR_OR_RETURN(params, Stat3, p_stat, "stat");
+  if (!silent) std::printf("Compute statistics...\n");
+  Data3D* vols[3] = {p_flow_u, p_flow_v, p_flow_w};
+  for (Data3D* v : vols)
+    if (!Fits(*v, data_size)) {
+      std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+      return;
+    }
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  if (W == 0 || H == 0 || D == 0) return;
+  const ChunkBox box(W, H);
+  const int chunk = static_cast<int>(std::min<size_t>(box.TotalPlanes(PiecemealBudgetBytes(), 3) / 3, D));
+  if (chunk < 1) return LowMemory(GetName());
+  Carver buf(box);
+  for (int i = 0; i < 3; ++i) buf.Add(chunk);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, chunk);
+  if (!scope.ok()) return;
+  float mn = std::numeric_limits<float>::max(), mx = 0.f;
+  double sum = 0.0;
+  for (int z0 = 0; z0 < D; z0 += chunk) {
+    const int z1 = std::min(D, z0 + chunk);
+    const f3d_slab slab = {z0, z0, z1};
+    for (int i = 0; i < 3; ++i)
+      if (!Upload(buf[i], box, 0, *vols[i], W, H, z0, z1 - z0)) return;
+    float cmn = 0.f, cmx = 0.f;
+    double csum = 0.0;
+    if (CheckDeviceError(f3d_flow_stats(buf[0], buf[1], buf[2], W, H, D, &slab, &cmn, &cmx, &csum))) return;
+    mn = std::fmin(mn, cmn);
+    mx = std::fmax(mx, cmx);
+    sum += csum;
+  }
+  p_stat->min = mn;
+  p_stat->max = mx;
+  p_stat->avg = static_cast<float>(sum / (static_cast<double>(W) * static_cast<double>(H) * static_cast<double>(D)));
+  if (!silent) std::printf("Min: %8.4f Max: %8.4f Avg: %8.4f\n", p_stat->min, p_stat->max, p_stat->avg);
+}
+
+// ---- resample (cuda_operation_resample_p.cpp:63-116: X input->output, then Y and Z in place) -----------------------
+
+void CudaOperationResampleP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  DataSize4 data_size, resample_size;
+  Data3D *input_ptr, *output_ptr;
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, DataSize4, resample_size, "resample_size");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, input_ptr, "input");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, output_ptr, "output");
+  Data3D& input = *input_ptr;
+  Data3D& output = *output_ptr;
+  // the reference's three checks (cuda_operation_resample_p.cpp:79-98)
+  const bool downsample_check = output.Width() >= input.Width() && output.Height() >= input.Height() && output.Depth() >= input.Depth();
+  if (!Fits(input, data_size) || !Fits(output, resample_size) || !downsample_check) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return;
+  }
+  const size_t Wi = data_size.width, Hi = data_size.height, Wo = resample_size.width, Ho = resample_size.height;
+  const int Di = static_cast<int>(data_size.depth), Do = static_cast<int>(resample_size.depth);
+  if (Wi == 0 || Hi == 0 || Di == 0 || Wo == 0 || Ho == 0 || Do == 0) return;
+
+  // Buffers per chunk of `c` output planes that read `s` source planes: source, x pass, x+y pass (s planes each), result
+  // (c planes), all in one container geometry that holds both boxes.
+  const ChunkBox box(std::max(Wi, Wo), std::max(Hi, Ho));
+  const size_t total = box.TotalPlanes(PiecemealBudgetBytes(), 4);
+  auto source_of = [&](int z0, int z1) { return ResampleSourcePlanes(Di, Do, PlaneRange{z0, z1}); };
+  auto fits = [&](int c) {
+    size_t worst = 0;
+    for (int z0 = 0; z0 < Do; z0 += c) worst = std::max<size_t>(worst, source_of(z0, std::min(Do, z0 + c)).size());
+    return 3 * worst + static_cast<size_t>(c) <= total;
+  };
+  int chunk = Do;
+  if (!fits(chunk)) {  // largest chunk that fits, by bisection (the source span grows with the chunk)
+    int lo = 0, hi = Do;
+    while (hi - lo > 1) {
+      const int mid = lo + (hi - lo) / 2;
+      (fits(mid) ? lo : hi) = mid;
+    }
+    chunk = lo;
+  }
+  if (chunk < 1) return LowMemory(GetName());
+  size_t span = 0;
+  for (int z0 = 0; z0 < Do; z0 += chunk) span = std::max<size_t>(span, source_of(z0, std::min(Do, z0 + chunk)).size());
+  Carver buf(box);
+  for (int i = 0; i < 3; ++i) buf.Add(span);
+  buf.Add(chunk);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, std::max<size_t>(span, chunk));
+  if (!scope.ok()) return;
+
+  // In place (input == output) a chunk's result lands on host planes [z0, z1) of the volume it is read from.  Going up
+  // in z is safe when the depth shrinks or stays (later chunks read planes >= floor(z1 * delta) >= z1), going down when
+  // it grows (earlier chunks read planes < ceil(z0 * delta) <= z0).
+  const int n_chunks = (Do + chunk - 1) / chunk;
+  const bool descending = Do > Di;
+  for (int k = 0; k < n_chunks; ++k) {
+    const int z0 = (descending ? n_chunks - 1 - k : k) * chunk, z1 = std::min(Do, z0 + chunk);
+    const PlaneRange src = source_of(z0, z1);
+    const f3d_slab in_slab = {src.lo, src.lo, src.hi}, out_slab = {z0, z0, z1};
+    if (!Upload(buf[0], box, 0, input, Wi, Hi, src.lo, src.size())) return;
+    if (CheckDeviceError(f3d_resample_x(buf[0], buf[1], Wo, Hi, Di, Wi, &in_slab))) return;
+    if (CheckDeviceError(f3d_resample_y(buf[1], buf[2], Wo, Ho, Di, Hi, &in_slab))) return;
+    if (CheckDeviceError(f3d_resample_z(buf[2], buf[3], Wo, Ho, Do, Di, &in_slab, &out_slab))) return;
+    if (!Download(output, Wo, Ho, z0, z1 - z0, buf[3], box, 0)) return;
+  }
+  CheckDeviceError(f3d_stream_sync());
+}
+
+// ---- registration (cuda_operation_register_p.cpp:54-139: the reference warps on the CPU) ---------------------------
+
+void CudaOperationRegistrationP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_frame_0, *p_frame_1, *p_flow_u, *p_flow_v, *p_flow_w, *p_temp;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_frame_0, "frame_0");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_frame_1, "frame_1");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_u, "flow_u");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_v, "flow_v");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_w, "flow_w");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_temp, "temp");
+  float hx, hy, hz;
+  DataSize4 data_size;
+  size_t max_mag;
+  GET_PARAM_OR_RETURN(params, float, hx, "hx");
+  GET_PARAM_OR_RETURN(params, float, hy, "hy");
+  GET_PARAM_OR_RETURN(params, float, hz, "hz");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, size_t, max_mag, "max_mag");
+  (void)max_mag;  // the halo comes from the flow itself, chunk by chunk
+  Data3D* in[4] = {p_frame_0, p_flow_u, p_flow_v, p_flow_w};
+  for (Data3D* v : {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w, p_temp})
+    if (!Fits(*v, data_size)) {
+      std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+      return;
+    }
+  if (p_frame_1 == p_temp) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  if (W == 0 || H == 0 || D == 0) return;
+
+  // frame_0, u, v, w and the result hold `chunk` planes; frame_1 gets the rest for chunk + 2 * reach planes
+  const ChunkBox box(W, H);
+  const size_t total = box.TotalPlanes(PiecemealBudgetBytes(), 6);
+  int chunk, f1_cap;
+  if (total >= 6 * static_cast<size_t>(D)) {
+    chunk = f1_cap = D;
+  } else {
+    chunk = static_cast<int>(std::min<size_t>(total / 8, D));
+    f1_cap = chunk < 1 ? 0 : static_cast<int>(std::min<size_t>(total - 5 * static_cast<size_t>(chunk), D));
+  }
+  if (chunk < 1 || f1_cap < 1) return LowMemory(GetName());
+  Carver buf(box);
+  for (int i = 0; i < 5; ++i) buf.Add(chunk);
+  buf.Add(f1_cap);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, std::max(chunk, f1_cap));
+  if (!scope.ok()) return;
+  const DevicePtr dev_out = buf[4], dev_f1 = buf[5];
+
+  for (int z0 = 0; z0 < D; z0 += chunk) {
+    const int z1 = std::min(D, z0 + chunk);
+    for (int i = 0; i < 4; ++i)
+      if (!Upload(buf[i], box, 0, *in[i], W, H, z0, z1 - z0)) return;
+    const f3d_slab own = {z0, z0, z1};
+    float max_w = 0.f;
+    if (CheckDeviceError(f3d_abs_max(buf[3], W, H, D, &own, &max_w))) return;
+    // frame_1 planes a voxel of plane z can read: z - reach .. z + reach (registration_3d.cu:46-80)
+    const float planes = std::ceil(max_w / hz);
+    const int reach = (planes == planes && planes < static_cast<float>(D)) ? static_cast<int>(planes) + 1 : D;
+    int sub = z1 - z0;
+    if (std::min(D, z1 + reach) - std::max(0, z0 - reach) > f1_cap) sub = f1_cap - 2 * reach;
+    if (sub < 1) {
+      std::printf("Operation '%s': Error. Low GPU memory: a flow of %.1f planes in z needs %d planes of frame_1, %d fit.\n", GetName(),
+                  max_w / hz, 2 * reach + 1, f1_cap);
+      return;
+    }
+    for (int s0 = z0; s0 < z1; s0 += sub) {
+      const int s1 = std::min(z1, s0 + sub);
+      const int lo = std::max(0, s0 - reach), hi = std::min(D, s1 + reach);
+      if (!Upload(dev_f1, box, 0, *p_frame_1, W, H, lo, hi - lo)) return;
+      // one z_base (frame_1's) for every operand: the chunk buffers are addressed as if they started at plane `lo`
+      const f3d_slab win = {lo, s0, s1};
+      if (CheckDeviceError(f3d_warp(Rebase(buf[0], box, z0, lo), dev_f1, Rebase(buf[1], box, z0, lo), Rebase(buf[2], box, z0, lo),
+                                    Rebase(buf[3], box, z0, lo), W, H, D, hx, hy, hz, Rebase(dev_out, box, z0, lo), &win)))
+        return;
+    }
+    if (!Download(*p_temp, W, H, z0, z1 - z0, dev_out, box, 0)) return;
+  }
+  if (CheckDeviceError(f3d_stream_sync())) return;
+  p_frame_1->Swap(*p_temp);
+}
+
+// ---- solve (cuda_operation_solve_p.cpp:60-207) --------------------------------------------------------------------
+
+void CudaOperationSolveP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_frame_0, *p_frame_1, *p_flow_u, *p_flow_v, *p_flow_w, *p_flow_du, *p_flow_dv, *p_flow_dw, *p_temp_du, *p_temp_dv, *p_temp_dw;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_frame_0, "frame_0");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_frame_1, "frame_1");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_u, "flow_u");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_v, "flow_v");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_w, "flow_w");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_du, "flow_du");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_dv, "flow_dv");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_flow_dw, "flow_dw");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_temp_du, "temp_du");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_temp_dv, "temp_dv");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_temp_dw, "temp_dw");
+  size_t outer_iterations_count, inner_iterations_count;
+  float equation_alpha, equation_smoothness, equation_data, hx, hy, hz;
+  DataSize4 data_size;
+  GET_PARAM_OR_RETURN(params, size_t, outer_iterations_count, "outer_iterations_count");
+  GET_PARAM_OR_RETURN(params, size_t, inner_iterations_count, "inner_iterations_count");
+  GET_PARAM_OR_RETURN(params, float, equation_alpha, "equation_alpha");
+  GET_PARAM_OR_RETURN(params, float, equation_smoothness, "equation_smoothness");
+  GET_PARAM_OR_RETURN(params, float, equation_data, "equation_data");
+  GET_PARAM_OR_RETURN(params, float, hx, "hx");
+  GET_PARAM_OR_RETURN(params, float, hy, "hy");
+  GET_PARAM_OR_RETURN(params, float, hz, "hz");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+
+  Data3D* fixed[5] = {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w};
+  Data3D* inc[3] = {p_flow_du, p_flow_dv, p_flow_dw};
+  Data3D* next[3] = {p_temp_du, p_temp_dv, p_temp_dw};
+  for (Data3D* v : {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w, p_flow_du, p_flow_dv, p_flow_dw, p_temp_du, p_temp_dv, p_temp_dw})
+    if (!Fits(*v, data_size)) {
+      std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+      return;
+    }
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  const int K = static_cast<int>(inner_iterations_count), outer = static_cast<int>(outer_iterations_count);
+  last_plan_ = SolvePiecemealPlan();
+  last_passes_ = 0;
+  if (W == 0 || H == 0 || D == 0) return;
+
+  // The increments start at zero (cuda_operation_solve_p.cpp:152-154); with no sweep to run that is also the result.
+  if (outer == 0 || K == 0) {
+    for (Data3D* v : inc) v->ZeroData();
+    return;
+  }
+
+  int forced = 0;
+  if (const char* e = std::getenv("F3D_P_OUTER_PER_PASS")) forced = std::atoi(e);
+  const SolvePiecemealPlan plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced);
+  last_plan_ = plan;
+  if (plan.chunk < 1) return LowMemory(GetName());
+  const int chunk = plan.chunk, halo = plan.halo, planes = std::min(D, chunk + 2 * halo);
+
+  enum { F0, F1, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, kFields };
+  const ChunkBox box(W, H);
+  Carver carve(box);
+  for (int i = 0; i < kFields; ++i) carve.Add(planes);
+  if (!carve.Commit()) return;
+  ContainerScope scope(box, planes);
+  if (!scope.ok()) return;
+  DevicePtr buf[kFields];
+  for (int i = 0; i < kFields; ++i) buf[i] = carve[i];
+
+  if (!silent) {
+    std::printf("%d x %d planes, %d outer iterations per pass\n", (D + chunk - 1) / chunk, chunk, plan.outer_per_pass);
+    Utils::PrintProgressBar(0.f);
+  }
+  const size_t rows = static_cast<size_t>(planes) * H;
+  const bool fused = FusedSweepsEnabled();
+  for (int i0 = 0; i0 < outer; i0 += plan.outer_per_pass) {
+    const int n = std::min(plan.outer_per_pass, outer - i0);
+    const int reach = halo ? n * (K + 1) : 0;  // planes of input this pass reads beyond the chunk
+    for (int z0 = 0; z0 < D; z0 += chunk) {
+      const int z1 = std::min(D, z0 + chunk);
+      const int base = halo ? z0 - halo : 0;  // global plane held by container plane 0
+      const int lo = std::max(0, z0 - reach), hi = std::min(D, z1 + reach);
+      auto window = [&](int grow) { return f3d_slab{base, std::max(0, z0 - grow), std::min(D, z1 + grow)}; };
+      for (int i = 0; i < 5; ++i)
+        if (!Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo)) return;
+      for (int i = 0; i < 3; ++i) {
+        if (i0 == 0) {
+          if (CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
+        } else if (!Upload(buf[DU + i], box, lo - base, *inc[i], W, H, lo, hi - lo)) {
+          return;
+        }
+      }
+      // Outer iteration j of this pass leaves the increments valid on the chunk widened by g = (n-1-j)(K+1) planes:
+      // phi/ksi on g + K, sweep s on g + K-1-s; a fused pair runs on the window of its second sweep.
+      for (int j = 0; j < n; ++j) {
+        const int g = halo ? (n - 1 - j) * (K + 1) : 0;
+        const f3d_slab pw = window(g + K);
+        if (CheckDeviceError(f3d_phi_ksi(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], W, H, D, hx, hy, hz,
+                                         equation_smoothness, equation_data, buf[PHI], buf[KSI], &pw)))
+          return;
+        for (int s = 0; s < K;) {
+          const bool pair = fused && s + 2 <= K;
+          const f3d_slab sw = window(g + K - 1 - s - (pair ? 1 : 0));
+          const int status =
+              pair ? f3d_solve_sweep2(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], buf[PHI], buf[KSI], W, H, D,
+                                      hx, hy, hz, equation_alpha, buf[TDU], buf[TDV], buf[TDW], &sw)
+                   : f3d_solve_sweep(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], buf[PHI], buf[KSI], W, H, D,
+                                     hx, hy, hz, equation_alpha, buf[TDU], buf[TDV], buf[TDW], &sw);
+          if (CheckDeviceError(status)) return;
+          std::swap(buf[DU], buf[TDU]);
+          std::swap(buf[DV], buf[TDV]);
+          std::swap(buf[DW], buf[TDW]);
+          s += pair ? 2 : 1;
+        }
+      }
+      for (int i = 0; i < 3; ++i)
+        if (!Download(*next[i], W, H, z0, z1 - z0, buf[DU + i], box, z0 - base)) return;
+    }
+    if (CheckDeviceError(f3d_stream_sync())) return;
+    for (int i = 0; i < 3; ++i) inc[i]->Swap(*next[i]);
+    ++last_passes_;
+    if (!silent) {
+      const float complete = static_cast<float>(i0 + n) / static_cast<float>(outer);
+      Utils::PrintProgressBar(complete);
+      std::printf(" % 3.0f%%", complete * 100);
+    }
+  }
+  if (!silent) std::printf("\n");
+}

@@ -1,0 +1,99 @@
+// "Piecemeal" operators: the host-volume flavour of the operator layer (class names, name strings and parameter keys of
+// src/cuda_operations/partial_data/cuda_operation_{add,resample,register,solve,stat}_p.{h,cpp}).  Every parameter that is
+// a device pointer in operations.h is a Data3D* here: full-size dense host volumes whose corner sub-box holds the current
+// pyramid level, streamed through the GPU in z-chunks sized to the free device memory, so a volume larger than HBM can be
+// processed.
+//
+// What is new relative to the reference (which uploads ten fields and downloads three for EVERY sweep,
+// cuda_operation_solve_p.cpp:188-207, 586-745, and warps on the CPU, cuda_operation_register_p.cpp:96-139):
+//   * the solver keeps a chunk on the device for whole outer iterations: phi/ksi and the K inner sweeps run on windows
+//     that shrink by one plane per sweep inside a halo of n (K + 1) planes, n outer iterations per residency, so the
+//     PCIe traffic per outer iteration is 11 / n field transfers instead of 13 K + 10; phi and ksi never leave the device;
+//   * the warp runs on the device with a per-chunk halo taken from max |w| of the chunk;
+//   * chunks live in one reusable device arena, in a compact container of the level's own size.
+// The kernels are the resident path's, launched on slab windows, so every result is bit-identical to the corresponding
+// "entire data" operator.
+#ifndef F3D_HOST_OPERATIONS_P_H_
+#define F3D_HOST_OPERATIONS_P_H_
+
+#include "operations.h"
+
+// Device memory the piecemeal operators may use for chunks: F3D_P_BUDGET_MB when set (tests force small chunks with it),
+// else 85 % of the free device memory plus what the shared chunk arena already holds.
+size_t PiecemealBudgetBytes();
+// Give the arena's device memory back (the driver's Destroy does).
+void PiecemealReleaseArena();
+
+// How the solver cuts a level: `chunk` owned planes per residency, `outer_per_pass` outer iterations computed before the
+// increments go back to the host, `halo` = outer_per_pass * (K + 1) planes uploaded on either side (0 when the level fits).
+struct SolvePiecemealPlan {
+  int chunk = 0;
+  int outer_per_pass = 0;
+  int halo = 0;
+  int max_planes = 0;  // planes of one field the budget allows
+};
+// Pure host arithmetic (CPU-testable).  forced_outer_per_pass > 0 pins n (F3D_P_OUTER_PER_PASS); chunk == 0 means the
+// budget cannot hold even one plane with its halo.
+SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
+                                      int outer_iterations, int forced_outer_per_pass);
+
+class CudaOperationPiecemealBase : public CudaOperationBase {
+ public:
+  // the reference's piecemeal operators take no container at Initialize (cuda_operation_solve_p.cpp:34-58)
+  bool Initialize(const OperationParameters* params = nullptr) override;
+
+ protected:
+  explicit CudaOperationPiecemealBase(const char* name) : CudaOperationBase(name) {}
+};
+
+// operand_0 += operand_1                      keys: operand_0, operand_1 (Data3D*), data_size
+class CudaOperationAddP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationAddP() : CudaOperationPiecemealBase("CUDA Add Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+};
+
+// area resample of the data_size sub-box of `input` into the resample_size sub-box of `output`; input == output is allowed
+// (the driver resamples the flow in place)    keys: input, output (Data3D*), data_size, resample_size
+class CudaOperationResampleP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationResampleP() : CudaOperationPiecemealBase("CUDA Resample Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+};
+
+// backward trilinear warp of frame_1; the result is written to `temp` and the two volumes are swapped, like the reference
+// keys: frame_0, frame_1, flow_u, flow_v, flow_w, temp (Data3D*), hx, hy, hz, data_size, max_mag (size_t, a hint only)
+class CudaOperationRegistrationP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationRegistrationP() : CudaOperationPiecemealBase("CUDA Registration") {}
+  void Execute(OperationParameters& params) override;
+};
+
+// lagged-nonlinearity solver on host volumes.  keys: frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw,
+// temp_du, temp_dv, temp_dw (Data3D*), outer_iterations_count, inner_iterations_count, equation_alpha,
+// equation_smoothness, equation_data, hx, hy, hz, data_size.  "phi" and "ksi" are accepted and ignored: the
+// nonlinearities stay on the device.  The name string keeps the reference's spelling.
+class CudaOperationSolveP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationSolveP() : CudaOperationPiecemealBase("CUDA Sove Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+
+  bool silent = false;
+  // what the last Execute did (tests and the driver's log)
+  const SolvePiecemealPlan& LastPlan() const { return last_plan_; }
+  size_t LastPasses() const { return last_passes_; }
+
+ private:
+  SolvePiecemealPlan last_plan_;
+  size_t last_passes_ = 0;
+};
+
+// min / max / average flow magnitude            keys: flow_u, flow_v, flow_w (Data3D*), data_size, stat (Stat3*)
+class CudaOperationStatP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationStatP() : CudaOperationPiecemealBase("CUDA Stat Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+  bool silent = false;
+};
+
+#endif

@@ -1,0 +1,249 @@
+// OpticalFlowP: the coarse-to-fine loop of src/optical_flow/optical_flow_p.cpp:57-318 on host volumes -- per level
+// {resample both frames from the originals, resample the flow in place, warp frame 1, solve, add} -- with the piecemeal
+// operators doing the device work chunk by chunk.
+#include "optical_flow_p.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common_utils.h"
+#include "hip_utils.h"
+
+OpticalFlowP::OpticalFlowP() : OpticalFlowBase("Optical Flow Single GPU Piecemeal Processing")
+{
+  // initialisation order of the reference's forward_list (optical_flow_p.cpp:29-33)
+  cuda_operations_ = {&cuop_add_p_, &cuop_stat_p_, &cuop_solve_p_, &cuop_resample_p_, &cuop_register_p_};
+}
+
+OpticalFlowP::~OpticalFlowP()
+{
+  if (initialized_) Destroy();
+}
+
+bool OpticalFlowP::Initialize(const DataSize4& data_size)
+{
+  initialized_ = true;
+  data_size_ = data_size;
+  std::printf("Initialization of cuda operations...\n");
+  for (CudaOperationBase* cuop : cuda_operations_) {
+    std::printf("%-18s: ", cuop->GetName());
+    if (cuop->Initialize()) {
+      std::printf("OK\n");
+    } else {
+      Destroy();
+      initialized_ = false;
+    }
+  }
+  return initialized_;
+}
+
+void OpticalFlowP::Destroy()
+{
+  for (CudaOperationBase* cuop : cuda_operations_) cuop->Destroy();
+  PiecemealReleaseArena();
+  initialized_ = false;
+}
+
+void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
+                               OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
+  float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
+  GET_PARAM_OR_RETURN(params, size_t, warp_levels_count, "warp_levels_count");
+  GET_PARAM_OR_RETURN(params, float, warp_scale_factor, "warp_scale_factor");
+  GET_PARAM_OR_RETURN(params, size_t, outer_iterations_count, "outer_iterations_count");
+  GET_PARAM_OR_RETURN(params, size_t, inner_iterations_count, "inner_iterations_count");
+  GET_PARAM_OR_RETURN(params, float, equation_alpha, "equation_alpha");
+  GET_PARAM_OR_RETURN(params, float, equation_smoothness, "equation_smoothness");
+  GET_PARAM_OR_RETURN(params, float, equation_data, "equation_data");
+  GET_PARAM_OR_RETURN(params, size_t, median_radius, "median_radius");   // read like the reference, not used by this driver
+  GET_PARAM_OR_RETURN(params, float, gaussian_sigma, "gaussian_sigma");  // likewise
+  (void)median_radius;
+  (void)gaussian_sigma;
+
+  float hx, hy, hz;
+  DataSize4 original_data_size = {frame_0.Width(), frame_0.Height(), frame_0.Depth(), 0};
+  DataSize4 current_data_size = {0, 0, 0, 0};
+  DataSize4 prev_data_size = {0, 0, 0, 0};
+  Stat3 flow_stat = {0.f, 0.f, 0.f};
+  for (Data3D* v : {&frame_1, &flow_u, &flow_v, &flow_w})
+    if (v->Width() != original_data_size.width || v->Height() != original_data_size.height || v->Depth() != original_data_size.depth) {
+      std::printf("'%s': Error. Frames and flow volumes must have the same size.\n", GetName());
+      return;
+    }
+
+  const size_t max_warp_level = GetMaxWarpLevel(original_data_size.width, original_data_size.height, original_data_size.depth, warp_scale_factor);
+  int current_warp_level = static_cast<int>(std::min(warp_levels_count, max_warp_level)) - 1;
+
+  // Host scratch: eight volumes of the original size (the reference keeps ten: phi and ksi stay on the device here).
+  const size_t W0 = original_data_size.width, H0 = original_data_size.height, D0 = original_data_size.depth;
+  if (!silent) {
+    std::printf("Allocating additional memory on the host...\n");
+    std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * (W0 * H0 * D0 * sizeof(float)) / (1024.f * 1024.f));
+  }
+  Data3D frame_0_res, frame_1_res_br, flow_du, flow_dv, flow_dw, temp_0, temp_1, temp_2;
+  Data3D* own[8] = {&frame_0_res, &frame_1_res_br, &flow_du, &flow_dv, &flow_dw, &temp_0, &temp_1, &temp_2};
+  for (Data3D* v : own)
+    if (!v->Allocate(W0, H0, D0)) return;
+
+  // Page-lock everything the copies touch.  Data3D::Swap exchanges storage between volumes of this set only, so the
+  // pointers registered here are the ones to release at the end.
+  std::vector<void*> pinned;
+  const char* pin_env = std::getenv("F3D_P_PIN");
+  if (pin_host_memory && !(pin_env && pin_env[0] == '0')) {
+    const size_t bytes = W0 * H0 * D0 * sizeof(float);
+    Data3D* all[13] = {&frame_0, &frame_1, &flow_u, &flow_v, &flow_w, own[0], own[1], own[2], own[3], own[4], own[5], own[6], own[7]};
+    for (Data3D* v : all) {
+      if (f3d_host_register(v->DataPtr(), bytes) == 0) {
+        pinned.push_back(v->DataPtr());
+      } else if (!silent) {
+        std::printf("'%s': host memory could not be page-locked (%s); copies will be staged.\n", GetName(), f3d_last_error());
+        break;
+      }
+    }
+  }
+
+  Data3D* p_frame_0 = &frame_0;
+  Data3D* p_frame_1 = &frame_1;
+  Data3D* p_frame_0_res = &frame_0_res;
+  Data3D* p_frame_1_res_br = &frame_1_res_br;
+
+  f3d_event ev_start = nullptr, ev_stop = nullptr;
+  CheckDeviceError(f3d_event_create(&ev_start));
+  CheckDeviceError(f3d_event_create(&ev_stop));
+  CheckDeviceError(f3d_event_record(ev_start));
+  if (!silent) std::printf("\nStarting optical flow computation...\n");
+  solve_passes_ = 0;
+  streamed_levels_ = 0;
+  cuop_stat_p_.silent = silent;
+  OperationParameters op;
+
+  while (current_warp_level >= 0) {
+    const PyramidLevel lv = GetLevel(original_data_size, warp_scale_factor, current_warp_level);
+    current_data_size = lv.size;
+    hx = lv.hx;
+    hy = lv.hy;
+    hz = lv.hz;
+    if (!silent)
+      std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", current_warp_level, current_data_size.width, current_data_size.height,
+                  current_data_size.depth);
+
+    /* Data resampling */
+    if (current_warp_level == 0) {
+      std::swap(p_frame_0, p_frame_0_res);
+      std::swap(p_frame_1, p_frame_1_res_br);
+    } else {
+      op.Clear();
+      op.PushValuePtr("input", p_frame_0);
+      op.PushValuePtr("output", p_frame_0_res);
+      op.PushValuePtr("data_size", &original_data_size);
+      op.PushValuePtr("resample_size", &current_data_size);
+      cuop_resample_p_.Execute(op);
+
+      op.Clear();
+      op.PushValuePtr("input", p_frame_1);
+      op.PushValuePtr("output", p_frame_1_res_br);
+      op.PushValuePtr("data_size", &original_data_size);
+      op.PushValuePtr("resample_size", &current_data_size);
+      cuop_resample_p_.Execute(op);
+    }
+
+    /* Flow field resampling (in place) */
+    if (prev_data_size.width == 0) {
+      flow_u.ZeroData();
+      flow_v.ZeroData();
+      flow_w.ZeroData();
+    } else {
+      for (Data3D* flow : {&flow_u, &flow_v, &flow_w}) {
+        op.Clear();
+        op.PushValuePtr("input", flow);
+        op.PushValuePtr("output", flow);
+        op.PushValuePtr("data_size", &prev_data_size);
+        op.PushValuePtr("resample_size", &current_data_size);
+        cuop_resample_p_.Execute(op);
+      }
+    }
+
+    /* Backward registration: *p_frame_1_res_br and temp_0 trade storage, the warped frame ends up in the former */
+    {
+      size_t max_magnitude = static_cast<size_t>(std::ceil(flow_stat.max / warp_scale_factor));
+      op.Clear();
+      op.PushValuePtr("frame_0", p_frame_0_res);
+      op.PushValuePtr("frame_1", p_frame_1_res_br);
+      op.PushValuePtr("flow_u", &flow_u);
+      op.PushValuePtr("flow_v", &flow_v);
+      op.PushValuePtr("flow_w", &flow_w);
+      op.PushValuePtr("temp", &temp_0);
+      op.PushValuePtr("hx", &hx);
+      op.PushValuePtr("hy", &hy);
+      op.PushValuePtr("hz", &hz);
+      op.PushValuePtr("data_size", &current_data_size);
+      op.PushValuePtr("max_mag", &max_magnitude);
+      cuop_register_p_.Execute(op);
+    }
+
+    /* Difference problem solver */
+    {
+      op.Clear();
+      op.PushValuePtr("frame_0", p_frame_0_res);
+      op.PushValuePtr("frame_1", p_frame_1_res_br);
+      op.PushValuePtr("flow_u", &flow_u);
+      op.PushValuePtr("flow_v", &flow_v);
+      op.PushValuePtr("flow_w", &flow_w);
+      op.PushValuePtr("flow_du", &flow_du);
+      op.PushValuePtr("flow_dv", &flow_dv);
+      op.PushValuePtr("flow_dw", &flow_dw);
+      op.PushValuePtr("temp_du", &temp_1);
+      op.PushValuePtr("temp_dv", &temp_2);
+      // at level 0 temp_0 holds the caller's unwarped frame 1 (see below), so the third scratch is the free resample buffer
+      Data3D* third = current_warp_level == 0 ? p_frame_1 : &temp_0;
+      op.PushValuePtr("temp_dw", third);
+      op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
+      op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
+      op.PushValuePtr("equation_alpha", &equation_alpha);
+      op.PushValuePtr("equation_smoothness", &equation_smoothness);
+      op.PushValuePtr("equation_data", &equation_data);
+      op.PushValuePtr("data_size", &current_data_size);
+      op.PushValuePtr("hx", &hx);
+      op.PushValuePtr("hy", &hy);
+      op.PushValuePtr("hz", &hz);
+      cuop_solve_p_.silent = silent;
+      cuop_solve_p_.Execute(op);
+      solve_passes_ += cuop_solve_p_.LastPasses();
+      if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
+    }
+
+    /* Add the solved flow increment to the global flow */
+    {
+      Data3D* flows[3] = {&flow_u, &flow_v, &flow_w};
+      Data3D* incs[3] = {&flow_du, &flow_dv, &flow_dw};
+      for (int i = 0; i < 3; ++i) {
+        op.Clear();
+        op.PushValuePtr("operand_0", flows[i]);
+        op.PushValuePtr("operand_1", incs[i]);
+        op.PushValuePtr("data_size", &current_data_size);
+        cuop_add_p_.Execute(op);
+      }
+    }
+
+    // At level 0 the registration swapped the CALLER's frame_1 with temp_0; give the caller its storage (and its data,
+    // which the warp only read) back.  The reference leaves the warped frame in the caller's volume.
+    if (current_warp_level == 0) frame_1.Swap(temp_0);
+
+    prev_data_size = current_data_size;
+    --current_warp_level;
+  }
+
+  float elapsed_time = 0.f;
+  CheckDeviceError(f3d_event_record(ev_stop));
+  CheckDeviceError(f3d_event_sync(ev_stop));
+  CheckDeviceError(f3d_event_elapsed_ms(&elapsed_time, ev_start, ev_stop));
+  last_device_seconds_ = elapsed_time / 1000.f;
+  if (!silent) std::printf("Total GPU computation time: % 4.4fs\n", elapsed_time / 1000.);
+  f3d_event_destroy(ev_start);
+  f3d_event_destroy(ev_stop);
+  for (void* p : pinned) f3d_host_unregister(p);
+}

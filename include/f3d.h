@@ -76,10 +76,25 @@ int f3d_copy3d_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t d
                    const float* src, size_t width, size_t height, size_t depth);
 int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth,
                    f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
+/* The piecemeal operators' chunk copies (cuMemcpy3D with srcZ / dstZ and host strides,
+ * src/cuda_operations/partial_data/cuda_operation_solve_p.cpp:217-243, 278-296): `depth` planes of a width x height
+ * region between a host volume whose rows are *_row_floats apart and whose planes are *_rows rows apart (the pointer
+ * already addresses the first plane) and container planes dev_plane0...  Asynchronous on the library stream; order
+ * reuse of the host memory with f3d_stream_sync(). */
+int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
+                        size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth);
+int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height, size_t depth,
+                        f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
+/* Page-lock caller memory so the copies above run at full link rate and asynchronously (the reference's
+ * ALLOCATE_PINNED_MEMORY switch, src/data_types/data3d.cpp:30,57-61, applied to memory the caller already owns). */
+int f3d_host_register(void* ptr, size_t bytes);
+int f3d_host_unregister(void* ptr);
 /* cuMemcpyDtoD: src/cuda_operations/entire_data/cuda_operation_median.cpp:96-98 */
 int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes);
 /* cuModuleGetGlobal("container_size") + cuMemcpyHtoD in every op's Initialize, e.g. cuda_operation_solve.cpp:59-61 */
 int f3d_set_container(const f3d_size4* container);
+/* the geometry last set (operators that switch it for a chunk put it back afterwards) */
+int f3d_get_container(f3d_size4* container);
 
 /* cuEventCreate/Record/Synchronize/ElapsedTime/Destroy: optical_flow_e.cpp:163-169,579-587 */
 int f3d_event_create(f3d_event* ev);

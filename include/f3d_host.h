@@ -62,6 +62,34 @@ int f3d_op_set_slab(f3d_op op, const f3d_slab* slab);
 int f3d_op_destroy(f3d_op op);
 
 /* host-only helpers (no device needed) */
+/* ---- piecemeal (out-of-core) path: host volumes streamed through the device in z-chunks --------------------
+ * Operators "add_p", "resample_p", "registration_p", "solve_p", "stat_p" (f3d_op_create) mirror
+ * src/cuda_operations/partial_data/cuda_operation_*_p.cpp: they take no container at initialize (pass NULL) and their
+ * Data3D* keys (operand_0, input, output, frame_0, flow_u, temp, ...) take f3d_volume_object() of a wrapped volume. */
+typedef struct f3d_volume_s* f3d_volume;
+/* non-owning Data3D view of caller memory (src/data_types/data3d.h:22-62) */
+int f3d_volume_wrap(f3d_volume* vol, float* data, size_t width, size_t height, size_t depth);
+void* f3d_volume_object(f3d_volume vol);
+/* the storage the view addresses NOW: registration_p and solve_p swap storage between their volumes like the reference
+ * (Data3D::Swap, cuda_operation_register_p.cpp:138, cuda_operation_solve_p.cpp:167-169) */
+float* f3d_volume_data(f3d_volume vol);
+int f3d_volume_destroy(f3d_volume vol);
+/* what the last solve_p Execute did */
+int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes);
+/* chunk plan of solve_p for a level (pure host arithmetic) and the device budget it would use now */
+int f3d_plan_solve_piecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations, int outer_iterations,
+                             int forced_outer_per_pass, int* chunk, int* outer_per_pass, int* halo, int* max_planes);
+size_t f3d_piecemeal_budget_bytes(void);
+
+/* OpticalFlowP (src/optical_flow/optical_flow_p.h:35-57; ComputeFlow optical_flow_p.cpp:57-318): no pre-blur, no median */
+typedef struct f3d_pflow_s* f3d_pflow;
+int f3d_pflow_create(f3d_pflow* flow);
+int f3d_pflow_initialize(f3d_pflow flow, size_t width, size_t height, size_t depth);
+int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1, size_t width, size_t height, size_t depth,
+                      const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds);
+int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels);
+int f3d_pflow_destroy(f3d_pflow flow);
+
 size_t f3d_max_warp_level(size_t width, size_t height, size_t depth, float scale_factor);
 int f3d_level_geometry(size_t width, size_t height, size_t depth, float scale_factor, int level,
                        f3d_size4* size, float* hx, float* hy, float* hz);

@@ -1,0 +1,247 @@
+"""Out-of-core ("piecemeal") path on the MI355X: the five host-volume operators and the OpticalFlowP driver, with the device
+budget forced small (F3D_P_BUDGET_MB) so that every operator really cuts its level into several z-chunks.  Every result
+must equal the oracle's whole-volume result bit for bit (sign of zero aside): chunking, halos, the in-place resample
+order and the number of outer iterations per residency must not be visible in the output."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import box_in_container, same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _env():
+    keep = {k: os.environ.get(k) for k in ("F3D_P_BUDGET_MB", "F3D_P_OUTER_PER_PASS", "F3D_P_PIN")}
+    yield
+    for k, v in keep.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def budget_for(planes_total, w, h, buffers):
+    """MB that let `buffers` buffers hold `planes_total` planes of a w x h level in total (mirrors ChunkBox::TotalPlanes)."""
+    pitch = (w * 4 + 255) // 256 * 256
+    return (planes_total * pitch * h + buffers * (17 * 256 + 256) + 1024) / (1024.0 * 1024.0)
+
+
+def set_budget(mb):
+    os.environ["F3D_P_BUDGET_MB"] = repr(float(mb))
+
+
+def make_op(f3d, name):
+    f3d.check(f3d.hip().f3d_init(-1), "f3d_init")
+    op = f3d.Operation(name)
+    assert op.initialize(None), name
+    return op
+
+
+def test_operator_names(f3d):
+    names = {"add_p": "CUDA Add Piecemeal", "resample_p": "CUDA Resample Piecemeal", "registration_p": "CUDA Registration",
+             "solve_p": "CUDA Sove Piecemeal", "stat_p": "CUDA Stat Piecemeal"}
+    for key, name in names.items():
+        op = make_op(f3d, key)
+        assert op.name == name
+        op.destroy()
+
+
+def test_add_and_stat_in_chunks(f3d, oracle):
+    rng = np.random.default_rng(3)
+    W, H, D = 45, 22, 31
+    cd = (64, 32, 40)
+    a = box_in_container(rng, (W, H, D), cd, poison=False)
+    b = box_in_container(rng, (W, H, D), cd, poison=False)
+    c = box_in_container(rng, (W, H, D), cd, poison=False)
+    expect = a.copy()
+    expect[:D, :H, :W] += b[:D, :H, :W]
+    set_budget(budget_for(2 * 7, W, H, 2))  # 7 planes per chunk -> 5 chunks
+    va, vb, vc = (f3d.HostVolume(x) for x in (a, b, c))
+    op = make_op(f3d, "add_p")
+    op.execute(operand_0=va, operand_1=vb, data_size=(W, H, D))
+    assert same(va.array, expect)
+    op.destroy()
+
+    set_budget(budget_for(3 * 4, W, H, 3))
+    st = f3d.Stat3()
+    op = make_op(f3d, "stat_p")
+    op.execute(flow_u=va, flow_v=vb, flow_w=vc, data_size=(W, H, D), stat=st)
+    mn, mx, avg, total = oracle.flow_stats(va.array, vb.array, vc.array, (W, H, D))
+    assert st.min == mn and st.max == mx
+    assert abs(st.avg - total / (W * H * D)) <= 1e-6 * abs(avg)
+    op.destroy()
+    for v in (va, vb, vc):
+        v.destroy()
+
+
+@pytest.mark.parametrize("in_dims,out_dims,planes", [
+    ((50, 33, 23), (48, 32, 22), 20),     # one level down, several chunks
+    ((50, 33, 23), (7, 5, 4), 40),        # frames from the original size: long source spans
+    ((19, 14, 11), (20, 15, 12), 12),     # flow upsampling
+    ((30, 20, 16), (30, 20, 16), 10),     # identity sizes
+])
+def test_resample_matches_oracle(f3d, oracle, in_dims, out_dims, planes):
+    rng = np.random.default_rng(5)
+    cd = (64, 40, 32)
+    src = box_in_container(rng, in_dims, cd, lo=-2, hi=2, poison=True)
+    expect = oracle.resample(src, in_dims, out_dims)
+    ow, oh, od = out_dims
+    wc, hc = max(in_dims[0], ow), max(in_dims[1], oh)
+    op = make_op(f3d, "resample_p")
+    # separate output
+    set_budget(budget_for(planes, wc, hc, 4))
+    vin, vout = f3d.HostVolume(src.copy()), f3d.HostVolume(np.full(src.shape, np.nan, np.float32))
+    op.execute(input=vin, output=vout, data_size=in_dims, resample_size=out_dims)
+    assert same(vout.array[:od, :oh, :ow], expect[:od, :oh, :ow])
+    assert same(vin.array[:in_dims[2], :in_dims[1], :in_dims[0]], src[:in_dims[2], :in_dims[1], :in_dims[0]])
+    # in place, like the driver resamples the flow
+    vio = f3d.HostVolume(src.copy())
+    op.execute(input=vio, output=vio, data_size=in_dims, resample_size=out_dims)
+    assert same(vio.array[:od, :oh, :ow], expect[:od, :oh, :ow])
+    op.destroy()
+    for v in (vin, vout, vio):
+        v.destroy()
+
+
+@pytest.mark.parametrize("w_amp,planes", [(0.4, 60), (3.0, 60), (9.0, 120), (40.0, 6 * 26)])
+def test_registration_matches_oracle(f3d, oracle, w_amp, planes):
+    """Flows of up to w_amp planes in z: the chunk halo follows max |w| of each chunk; large flows force sub-chunks."""
+    rng = np.random.default_rng(int(w_amp * 10))
+    W, H, D = 37, 21, 26
+    cd = (48, 24, 32)
+    h = (1.3, 0.9, 1.1)
+    f0 = box_in_container(rng, (W, H, D), cd, 0, 255)
+    f1 = box_in_container(rng, (W, H, D), cd, 0, 255)
+    u = box_in_container(rng, (W, H, D), cd, -6, 6)
+    v = box_in_container(rng, (W, H, D), cd, -6, 6)
+    w = box_in_container(rng, (W, H, D), cd, -w_amp, w_amp)
+    w[3, 4, 5] = np.nan          # NaN flow -> frame_0 (registration_3d.cu:60-64)
+    w[10:14] *= 0.1              # a quiet stretch: its chunks need a thinner halo
+    expect = oracle.warp(f0, f1, u, v, w, (W, H, D), h)
+    set_budget(budget_for(planes, W, H, 6))
+    vols = [f3d.HostVolume(x.copy()) for x in (f0, f1, u, v, w)]
+    temp = f3d.HostVolume(np.full(f0.shape, np.nan, np.float32))
+    op = make_op(f3d, "registration_p")
+    op.execute(frame_0=vols[0], frame_1=vols[1], flow_u=vols[2], flow_v=vols[3], flow_w=vols[4], temp=temp,
+               hx=h[0], hy=h[1], hz=h[2], data_size=(W, H, D), max_mag=0)
+    # the warped frame is now frame_1's storage, the old frame_1 is in temp (Data3D::Swap)
+    assert same(vols[1].array[:D, :H, :W], expect[:D, :H, :W])
+    assert same(temp.array[:D, :H, :W], f1[:D, :H, :W])
+    op.destroy()
+    for x in vols + [temp]:
+        x.destroy()
+
+
+def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, eps_d):
+    du, dv, dw = (np.zeros_like(f0) for _ in range(3))
+    for _ in range(outer):
+        phi, ksi = oracle.phi_ksi(f0, f1, u, v, w, du, dv, dw, dims, h, eps_s, eps_d)
+        for _ in range(inner):
+            du, dv, dw = oracle.solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, alpha)
+    return du, dv, dw
+
+
+@pytest.mark.parametrize("planes,forced,outer,inner", [
+    (1000, 0, 3, 5),   # fits: one residency
+    (22, 1, 3, 5),     # 10-plane chunks, increments go home after every outer iteration
+    (34, 2, 5, 5),     # two outer iterations per residency, last pass shorter
+    (30, 0, 4, 3),     # planner's own choice, odd inner count
+    (26, 3, 3, 2),     # three per residency with pairs only
+])
+def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner):
+    rng = np.random.default_rng(planes)
+    W, H, D = 37, 21, 27
+    cd = (40, 24, 30)
+    dims, h = (W, H, D), (1.25, 1.0, 1.6)
+    f0 = box_in_container(rng, dims, cd, 0, 255)
+    f1 = np.full_like(f0, np.nan)
+    f1[:D, :H, :W] = f0[:D, :H, :W] + rng.uniform(-8, 8, size=(D, H, W)).astype(np.float32)
+    u, v, w = (box_in_container(rng, dims, cd, -2, 2) for _ in range(3))
+    expect = oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, 7.5, 0.001, 0.001)
+    set_budget(budget_for(13 * planes, W, H, 13))
+    os.environ["F3D_P_OUTER_PER_PASS"] = str(forced)
+    names = ["frame_0", "frame_1", "flow_u", "flow_v", "flow_w", "flow_du", "flow_dv", "flow_dw", "temp_du", "temp_dv", "temp_dw"]
+    arrays = [f0, f1, u, v, w] + [np.full(f0.shape, np.nan, np.float32) for _ in range(6)]
+    vols = {n: f3d.HostVolume(a.copy()) for n, a in zip(names, arrays)}
+    op = make_op(f3d, "solve_p")
+    op.execute(outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5, equation_smoothness=0.001,
+               equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **vols)
+    chunk, per_pass, halo, passes = op.solve_p_last()
+    if planes >= D:
+        assert (chunk, per_pass, halo, passes) == (D, outer, 0, 1)
+    else:
+        assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
+        if forced:
+            assert per_pass == forced
+    for n, e in zip(("flow_du", "flow_dv", "flow_dw"), expect):
+        got = vols[n].array[:D, :H, :W]
+        assert same(got, e[:D, :H, :W]), f"{n}: max diff {np.nanmax(np.abs(got - e[:D, :H, :W]))}"
+    # inputs untouched
+    for n, a in zip(names[:5], arrays[:5]):
+        assert same(vols[n].array[:D, :H, :W], a[:D, :H, :W])
+    op.destroy()
+    for x in vols.values():
+        x.destroy()
+
+
+def test_solve_reports_low_memory(f3d, capfd):
+    W, H, D = 37, 21, 27
+    set_budget(budget_for(13 * 8, W, H, 13))   # 8 planes per field: a 6-plane halo on either side cannot fit
+    vols = {n: f3d.HostVolume(np.zeros((D, H, W), np.float32)) for n in
+            ["frame_0", "frame_1", "flow_u", "flow_v", "flow_w", "flow_du", "flow_dv", "flow_dw", "temp_du", "temp_dv", "temp_dw"]}
+    op = make_op(f3d, "solve_p")
+    op.execute(outer_iterations_count=2, inner_iterations_count=5, equation_alpha=7.5, equation_smoothness=0.001,
+               equation_data=0.001, hx=1.0, hy=1.0, hz=1.0, data_size=(W, H, D), **vols)
+    assert op.solve_p_last()[0] == 0
+    op.destroy()
+    for x in vols.values():
+        x.destroy()
+
+
+def run_p(f3d, f0, f1, **kw):
+    d, h, w = f0.shape
+    flow = f3d.PiecemealOpticalFlow()
+    flow.initialize(w, h, d)
+    try:
+        out = flow.compute(f0, f1, silent=True, **kw)
+        return out, flow.stats()
+    finally:
+        flow.destroy()
+
+
+def test_driver_matches_oracle_small(f3d, oracle):
+    """Whole pyramid on 40x36x32 with a budget that streams the upper levels: equals the oracle's pipeline without blur and
+    median, which is what the reference's piecemeal driver computes."""
+    f0, f1 = f3d.synth_pair(40, 36, 32)
+    keep0, keep1 = f0.copy(), f1.copy()
+    (exp, levels) = oracle.compute_flow(f0, f1, gaussian_sigma=0.0, median_radius=1)
+    set_budget(budget_for(13 * 26, 40, 36, 13))
+    got, (passes, streamed) = run_p(f3d, f0, f1)
+    assert streamed >= 1 and passes > levels
+    for g, e, n in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n}: max diff {np.abs(g - e).max()}"
+    assert same(f0, keep0) and same(f1, keep1), "the caller's frames must come back unchanged"
+
+
+def test_driver_matches_resident_driver(f3d):
+    """120^3 default schedule: streamed (about 1/3 of the level resident at a time) vs everything resident, no blur/median."""
+    n = 120
+    f0, f1 = f3d.synth_pair(n, n, n)
+    flow = f3d.OpticalFlow()
+    flow.initialize(n, n, n)
+    try:
+        exp = flow.compute(f0, f1, silent=True, gaussian_sigma=0.0, median_radius=1, outer_iterations_count=6)
+    finally:
+        flow.destroy()
+    set_budget(budget_for(13 * 52, n, n, 13))
+    got, (passes, streamed) = run_p(f3d, f0, f1, outer_iterations_count=6)
+    assert streamed >= 3
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"{c}: max diff {np.abs(g - e).max()}"
+    os.environ["F3D_P_PIN"] = "0"   # staged copies give the same result
+    got2, _ = run_p(f3d, f0, f1, outer_iterations_count=6)
+    for g, e in zip(got2, exp):
+        assert same(g, e)
