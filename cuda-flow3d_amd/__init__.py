@@ -160,6 +160,7 @@ def host():
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
+        "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -534,6 +535,12 @@ class PiecemealOpticalFlow:
                                        v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp), C.byref(secs)), "f3d_pflow_compute")
         self.device_seconds = secs.value
         return u, v, ww
+
+    def operator_seconds(self):
+        """wall seconds of the last compute per operator"""
+        t = (C.c_double * 5)()
+        check(host().f3d_pflow_operator_seconds(self._h, t), "f3d_pflow_operator_seconds")
+        return dict(zip(("frames", "flow_resample", "registration", "solve", "add"), t))
 
     def stats(self):
         """(solver residencies, levels that did not fit the budget) of the last compute"""

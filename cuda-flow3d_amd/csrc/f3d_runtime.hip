@@ -325,10 +325,13 @@ int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, siz
   const size_t wb = width * sizeof(float), sb = src_row_floats * sizeof(float);
   if (height == dev_height && height == src_rows) {
     F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, sb, wb, height * depth, hipMemcpyHostToDevice, S.stream));
-  } else {
-    for (size_t z = 0; z < depth; ++z)
-      F3D_HIP(hipMemcpy2DAsync(d + z * dev_height * dev_pitch, dev_pitch, src + z * src_rows * src_row_floats, sb, wb, height,
-                               hipMemcpyHostToDevice, S.stream));
+  } else {  // one 3-D rectangle copy, not a copy per plane: a coarse level is hundreds of small planes
+    hipMemcpy3DParms p = {};
+    p.srcPtr = make_hipPitchedPtr(const_cast<float*>(src), sb, src_row_floats, src_rows);
+    p.dstPtr = make_hipPitchedPtr(d, dev_pitch, dev_pitch / sizeof(float), dev_height);
+    p.extent = make_hipExtent(wb, height, depth);
+    p.kind = hipMemcpyHostToDevice;
+    F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
   }
   return 0;
 }
@@ -345,9 +348,12 @@ int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size
   if (height == dev_height && height == dst_rows) {
     F3D_HIP(hipMemcpy2DAsync(dst, db, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, S.stream));
   } else {
-    for (size_t z = 0; z < depth; ++z)
-      F3D_HIP(hipMemcpy2DAsync(dst + z * dst_rows * dst_row_floats, db, s + z * dev_height * dev_pitch, dev_pitch, wb, height,
-                               hipMemcpyDeviceToHost, S.stream));
+    hipMemcpy3DParms p = {};
+    p.srcPtr = make_hipPitchedPtr(const_cast<char*>(s), dev_pitch, dev_pitch / sizeof(float), dev_height);
+    p.dstPtr = make_hipPitchedPtr(dst, db, dst_row_floats, dst_rows);
+    p.extent = make_hipExtent(wb, height, depth);
+    p.kind = hipMemcpyDeviceToHost;
+    F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
   }
   return 0;
 }

@@ -279,6 +279,13 @@ int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_level
   return 0;
 }
 
+int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds5)
+{
+  if (!flow || !seconds5) return 1;
+  for (int i = 0; i < 5; ++i) seconds5[i] = flow->driver.LastOperatorSeconds()[i];
+  return 0;
+}
+
 int f3d_pflow_destroy(f3d_pflow flow)
 {
   delete flow;

@@ -4,10 +4,11 @@
 // the nine-key parameter bag, write flow-u/v/w as RAW float32), with the compile-time constants turned into
 // flags:  flow3d --dims W H D --frames f0.raw f1.raw [f2.raw ...] [--f32] [--out prefix] [--levels N] [--scale s]
 //                [--outer N] [--inner N] [--alpha a] [--eps-smooth e] [--eps-data e] [--median r] [--sigma s]
-//                [--synthetic] [--vtk] [--stats] [--silent]
+//                [--synthetic] [--vtk] [--stats] [--silent] [--partial [--budget-mb N]]
 // More than two frames make a sequence: the driver, its containers and operators are set up once (the reference does
 // Initialize / Destroy per pair, src/main.cpp:150,184) and the flow of every consecutive pair is written as
-// <prefix>_<k>_flow-{u,v,w}-W-H-D.raw.
+// <prefix>_<k>_flow-{u,v,w}-W-H-D.raw.  --partial runs the out-of-core driver (the reference's use_partial_gpu branch,
+// src/main.cpp:187-220): volumes stay in host memory, output files end in "-partial.raw".
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,13 +17,14 @@
 
 #include "hip_utils.h"
 #include "optical_flow.h"
+#include "optical_flow_p.h"
 #include "synth.h"
 
 static void Usage()
 {
   std::printf("usage: flow3d --dims W H D (--frames f0.raw f1.raw [f2.raw ...] [--f32] | --synthetic) [--out prefix]\n"
               "              [--levels N] [--scale s] [--outer N] [--inner N] [--alpha a] [--eps-smooth e]\n"
-              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent]\n");
+              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent] [--partial [--budget-mb N]]\n");
 }
 
 int main(int argc, char** argv)
@@ -31,6 +33,7 @@ int main(int argc, char** argv)
   std::vector<std::string> files;
   std::string prefix = "flow3d";
   bool f32_input = false, synthetic = false, write_vtk = false, silent_mode = false, print_stats = false;
+  bool use_partial_gpu = false;
 
   // defaults of src/main.cpp:77-85
   size_t warp_levels_count = 40;
@@ -71,6 +74,8 @@ int main(int argc, char** argv)
     else if (a == "--synthetic") synthetic = true;
     else if (a == "--vtk") write_vtk = true;
     else if (a == "--silent") silent_mode = true;
+    else if (a == "--partial") use_partial_gpu = true;
+    else if (a == "--budget-mb") { need(1); setenv("F3D_P_BUDGET_MB", argv[++i], 1); }
     else { Usage(); return 64; }
   }
   if (width == 0 || height == 0 || depth == 0 || (!synthetic && files.size() < 2)) {
@@ -85,10 +90,6 @@ int main(int argc, char** argv)
   if (!InitDeviceContextWithFirstAvailableDevice()) return 1;
 
   DataSize4 data_size = {width, height, depth, 0};
-  OpticalFlowE optical_flow_e;
-  if (!optical_flow_e.Initialize(data_size)) return 3;
-  if (!optical_flow_e.AllocateResidentFrames()) return 3;
-
   OperationParameters params;
   params.PushValuePtr("warp_levels_count", &warp_levels_count);
   params.PushValuePtr("warp_scale_factor", &warp_scale_factor);
@@ -99,9 +100,6 @@ int main(int argc, char** argv)
   params.PushValuePtr("equation_data", &equation_data);
   params.PushValuePtr("median_radius", &median_radius);
   params.PushValuePtr("gaussian_sigma", &gaussian_sigma);
-  std::printf("Mode: Full GPU mode \n");
-  optical_flow_e.silent = silent_mode;
-
   auto load = [&](Data3D& frame, const std::string& path) {
     return f32_input ? frame.ReadRAWFromFileF32(path.c_str(), width, height, depth)
                      : frame.ReadRAWFromFileU8(path.c_str(), width, height, depth);
@@ -115,8 +113,49 @@ int main(int argc, char** argv)
   } else if (!load(frame_0, files[0])) {
     return 2;
   }
-  const std::string suffix =
-      "-" + std::to_string(width) + "-" + std::to_string(height) + "-" + std::to_string(depth) + ".raw";
+  const std::string suffix = "-" + std::to_string(width) + "-" + std::to_string(height) + "-" + std::to_string(depth) +
+                             (use_partial_gpu ? "-partial.raw" : ".raw");
+
+  if (use_partial_gpu) {
+    OpticalFlowP optical_flow_p;
+    if (!optical_flow_p.Initialize(data_size)) return 3;
+    std::printf("Mode: Partial processing mode \n");
+    optical_flow_p.silent = silent_mode;
+    for (size_t k = 0; k < pairs; ++k) {
+      if (!synthetic && !load(frame_1, files[k + 1])) return 2;
+      optical_flow_p.ComputeFlow(frame_0, frame_1, flow_u, flow_v, flow_w, params);
+      if (print_stats) {
+        CudaOperationStatP stat_p;
+        Stat3 stat = {0.f, 0.f, 0.f};
+        OperationParameters op;
+        op.PushValuePtr("flow_u", &flow_u);
+        op.PushValuePtr("flow_v", &flow_v);
+        op.PushValuePtr("flow_w", &flow_w);
+        op.PushValuePtr("data_size", &data_size);
+        op.PushValuePtr("stat", &stat);
+        stat_p.silent = true;
+        if (stat_p.Initialize()) stat_p.Execute(op);
+        std::printf("Flow magnitude  min: %8.4f  max: %8.4f  avg: %8.4f\n", stat.min, stat.max, stat.avg);
+      }
+      const std::string tag = pairs > 1 ? prefix + "_" + std::to_string(k) : prefix;
+      flow_u.WriteRAWToFileF32((tag + "_flow-u" + suffix).c_str());
+      flow_v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
+      flow_w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
+      if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), flow_u, flow_v, flow_w);
+      std::printf("pair %zu of %zu: %.3f s, %zu solver residencies, %zu levels streamed\n", k + 1, pairs,
+                  optical_flow_p.LastDeviceSeconds(), optical_flow_p.LastSolvePasses(), optical_flow_p.LastStreamedLevels());
+      if (pairs > 1) frame_0.Swap(frame_1);
+    }
+    optical_flow_p.Destroy();
+    f3d_shutdown();
+    return 0;
+  }
+
+  OpticalFlowE optical_flow_e;
+  if (!optical_flow_e.Initialize(data_size)) return 3;
+  if (!optical_flow_e.AllocateResidentFrames()) return 3;
+  std::printf("Mode: Full GPU mode \n");
+  optical_flow_e.silent = silent_mode;
   for (size_t k = 0; k < pairs; ++k) {
     if (!synthetic && !load(frame_1, files[k + 1])) return 2;
     optical_flow_e.UploadResidentFrames(frame_0, frame_1);

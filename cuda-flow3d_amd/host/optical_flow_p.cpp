@@ -4,6 +4,7 @@
 #include "optical_flow_p.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +119,13 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   if (!silent) std::printf("\nStarting optical flow computation...\n");
   solve_passes_ = 0;
   streamed_levels_ = 0;
+  for (double& t : op_seconds_) t = 0.0;
+  // every piecemeal Execute drains the stream before it returns, so host clocks around the calls time the device work
+  auto timed = [this](int slot, CudaOperationBase& cuop, OperationParameters& bag) {
+    const auto t0 = std::chrono::steady_clock::now();
+    cuop.Execute(bag);
+    op_seconds_[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
   cuop_stat_p_.silent = silent;
   OperationParameters op;
 
@@ -141,14 +149,14 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       op.PushValuePtr("output", p_frame_0_res);
       op.PushValuePtr("data_size", &original_data_size);
       op.PushValuePtr("resample_size", &current_data_size);
-      cuop_resample_p_.Execute(op);
+      timed(0, cuop_resample_p_, op);
 
       op.Clear();
       op.PushValuePtr("input", p_frame_1);
       op.PushValuePtr("output", p_frame_1_res_br);
       op.PushValuePtr("data_size", &original_data_size);
       op.PushValuePtr("resample_size", &current_data_size);
-      cuop_resample_p_.Execute(op);
+      timed(0, cuop_resample_p_, op);
     }
 
     /* Flow field resampling (in place) */
@@ -163,7 +171,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
         op.PushValuePtr("output", flow);
         op.PushValuePtr("data_size", &prev_data_size);
         op.PushValuePtr("resample_size", &current_data_size);
-        cuop_resample_p_.Execute(op);
+        timed(1, cuop_resample_p_, op);
       }
     }
 
@@ -182,7 +190,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       op.PushValuePtr("hz", &hz);
       op.PushValuePtr("data_size", &current_data_size);
       op.PushValuePtr("max_mag", &max_magnitude);
-      cuop_register_p_.Execute(op);
+      timed(2, cuop_register_p_, op);
     }
 
     /* Difference problem solver */
@@ -211,7 +219,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       op.PushValuePtr("hy", &hy);
       op.PushValuePtr("hz", &hz);
       cuop_solve_p_.silent = silent;
-      cuop_solve_p_.Execute(op);
+      timed(3, cuop_solve_p_, op);
       solve_passes_ += cuop_solve_p_.LastPasses();
       if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
     }
@@ -225,7 +233,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
         op.PushValuePtr("operand_0", flows[i]);
         op.PushValuePtr("operand_1", incs[i]);
         op.PushValuePtr("data_size", &current_data_size);
-        cuop_add_p_.Execute(op);
+        timed(4, cuop_add_p_, op);
       }
     }
 
@@ -242,7 +250,11 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   CheckDeviceError(f3d_event_sync(ev_stop));
   CheckDeviceError(f3d_event_elapsed_ms(&elapsed_time, ev_start, ev_stop));
   last_device_seconds_ = elapsed_time / 1000.f;
-  if (!silent) std::printf("Total GPU computation time: % 4.4fs\n", elapsed_time / 1000.);
+  if (!silent) {
+    std::printf("Total GPU computation time: % 4.4fs\n", elapsed_time / 1000.);
+    std::printf("  frames %.3fs  flow resample %.3fs  registration %.3fs  solve %.3fs  add %.3fs\n", op_seconds_[0], op_seconds_[1],
+                op_seconds_[2], op_seconds_[3], op_seconds_[4]);
+  }
   f3d_event_destroy(ev_start);
   f3d_event_destroy(ev_stop);
   for (void* p : pinned) f3d_host_unregister(p);

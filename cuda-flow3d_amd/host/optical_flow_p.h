@@ -30,11 +30,14 @@ class OpticalFlowP : public OpticalFlowBase {
   // solver residencies of the last ComputeFlow: levels that fitted the budget count one pass each
   size_t LastSolvePasses() const { return solve_passes_; }
   size_t LastStreamedLevels() const { return streamed_levels_; }
+  // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add}
+  const double* LastOperatorSeconds() const { return op_seconds_; }
 
  private:
   DataSize4 data_size_ = {0, 0, 0, 0};
   float last_device_seconds_ = 0.f;
   size_t solve_passes_ = 0, streamed_levels_ = 0;
+  double op_seconds_[5] = {0, 0, 0, 0, 0};
 
   CudaOperationRegistrationP cuop_register_p_;
   CudaOperationResampleP cuop_resample_p_;

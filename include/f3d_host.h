@@ -88,6 +88,8 @@ int f3d_pflow_initialize(f3d_pflow flow, size_t width, size_t height, size_t dep
 int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1, size_t width, size_t height, size_t depth,
                       const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds);
 int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels);
+/* wall seconds of the last compute in {frame resample, flow resample, registration, solve, add} */
+int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds5);
 int f3d_pflow_destroy(f3d_pflow flow);
 
 size_t f3d_max_warp_level(size_t width, size_t height, size_t depth, float scale_factor);

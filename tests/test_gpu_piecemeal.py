@@ -245,3 +245,33 @@ def test_driver_matches_resident_driver(f3d):
     got2, _ = run_p(f3d, f0, f1, outer_iterations_count=6)
     for g, e in zip(got2, exp):
         assert same(g, e)
+
+
+def test_cli_partial_mode(f3d, tmp_path):
+    """bin/flow3d --partial on two frame pairs with a small --budget-mb: files end in -partial.raw and equal the python
+    binding's result for the same pairs; the second pair starts from the swapped frame like the resident mode."""
+    import subprocess
+    W, H, D = 48, 40, 24
+    f0, f1 = f3d.synth_pair(W, H, D)
+    frames = [np.round(np.clip(f0, 0, 255)), np.round(np.clip(f1, 0, 255)), np.round(np.clip(0.5 * (f0 + f1), 0, 255))]
+    paths = []
+    for k, fr in enumerate(frames):
+        p = tmp_path / f"frame{k}.raw"
+        fr.astype(np.uint8).tofile(p)
+        paths.append(str(p))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow3d_amd", "bin", "flow3d")
+    prefix = str(tmp_path / "seq")
+    mb = budget_for(13 * 20, W, H, 13)
+    run = subprocess.run([exe, "--dims", str(W), str(H), str(D), "--frames", *paths, "--out", prefix, "--levels", "6", "--outer", "3",
+                          "--partial", "--budget-mb", repr(mb), "--stats", "--silent"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Mode: Partial processing mode" in run.stdout and "levels streamed" in run.stdout, run.stdout
+    set_budget(mb)
+    for k in range(2):
+        a = frames[k].astype(np.uint8).astype(np.float32)
+        b = frames[k + 1].astype(np.uint8).astype(np.float32)
+        exp, (_, streamed) = run_p(f3d, a, b, warp_levels_count=6, outer_iterations_count=3)
+        assert streamed >= 1
+        got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}-partial.raw", np.float32).reshape(D, H, W) for c in "uvw"]
+        for g, e in zip(got, exp):
+            assert same(g, e)

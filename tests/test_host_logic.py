@@ -200,3 +200,32 @@ def test_uniform_divisor_identity():
             q_fast = (xs.astype(np.float64) * r).astype(np.float32)
             bad += int(np.count_nonzero(q_ref.view(np.uint32) != q_fast.view(np.uint32)))
     assert bad == 0
+
+
+def test_piecemeal_solver_plan_properties(f3d):
+    """Chunk plan of the out-of-core solver (PlanSolvePiecemeal, pure arithmetic): a level that fits is one residency without
+    halo; otherwise chunk + 2 * halo fills the planes the budget allows, halo = outer_per_pass * (inner + 1), forcing the
+    number of outer iterations per residency is honoured, and a budget below one plane plus halos yields chunk 0."""
+    f3d.host()
+    def planes_budget(planes, w, h):
+        pitch = (w * 4 + 255) // 256 * 256
+        return 13 * (planes * pitch * h + 17 * 256 + 256)
+    for (w, h, d) in [(100, 90, 80), (512, 512, 512), (2048, 2048, 2048), (37, 21, 27)]:
+        for inner in (1, 2, 5):
+            for outer in (1, 3, 40):
+                chunk, per_pass, halo, max_planes = f3d.plan_solve_piecemeal(planes_budget(d, w, h), w, h, d, inner, outer)
+                assert (chunk, per_pass, halo) == (d, outer, 0) and max_planes >= d
+                for planes in (2 * (inner + 1) + 1, 3 * (inner + 1) + 4, d // 2 + 2 * (inner + 1), d - 1):
+                    if planes >= d:
+                        continue
+                    chunk, per_pass, halo, max_planes = f3d.plan_solve_piecemeal(planes_budget(planes, w, h), w, h, d, inner, outer)
+                    assert max_planes == planes
+                    assert 1 <= per_pass <= outer and halo == per_pass * (inner + 1) and chunk == planes - 2 * halo >= 1
+                    forced = f3d.plan_solve_piecemeal(planes_budget(planes, w, h), w, h, d, inner, outer, 1)
+                    assert forced[1] == 1 and forced[2] == inner + 1 and forced[0] == planes - 2 * (inner + 1)
+                too_small = f3d.plan_solve_piecemeal(planes_budget(2 * (inner + 1), w, h), w, h, d, inner, outer)
+                assert too_small[0] == 0 or 2 * (inner + 1) >= d
+    # the cost model: a large level on a 270 GB budget keeps many outer iterations per residency, a tiny budget few
+    big = f3d.plan_solve_piecemeal(270 << 30, 2048, 2048, 2048, 5, 40)
+    small = f3d.plan_solve_piecemeal(planes_budget(40, 2048, 2048), 2048, 2048, 2048, 5, 40)
+    assert big[1] >= 8 and small[1] <= 2

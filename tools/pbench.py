@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Times the out-of-core driver (OpticalFlowP) on a synthetic pair and, beside it, the resident driver on the same
+schedule (no pre-blur, no median, which is what the piecemeal driver computes).
+   python tools/pbench.py --size 512 [--budget-mb 4096] [--outer 40] [--levels 40] [--no-resident] [--check]
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--budget-mb", type=float, default=0)
+    ap.add_argument("--outer", type=int, default=40)
+    ap.add_argument("--levels", type=int, default=40)
+    ap.add_argument("--per-pass", type=int, default=0)
+    ap.add_argument("--no-resident", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare the two results bit for bit")
+    a = ap.parse_args()
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    n = a.size
+    t0 = time.time()
+    f0, f1 = pkg.synth_pair(n, n, n)
+    print(f"synthetic {n}^3 pair in {time.time() - t0:.1f} s", flush=True)
+    kw = dict(outer_iterations_count=a.outer, warp_levels_count=a.levels)
+    exp = None
+    if not a.no_resident:
+        flow = pkg.OpticalFlow()
+        flow.initialize(n, n, n)
+        flow.upload(f0, f1)
+        secs = flow.compute_resident(silent=True, gaussian_sigma=0.0, median_radius=1, **kw)
+        print(f"resident : {secs:8.3f} s on the device  {n ** 3 / secs / 1e6:7.2f} Mvoxels/s", flush=True)
+        if a.check:
+            exp = flow.download()
+        flow.destroy()
+    if a.budget_mb > 0:
+        os.environ["F3D_P_BUDGET_MB"] = repr(a.budget_mb)
+    if a.per_pass > 0:
+        os.environ["F3D_P_OUTER_PER_PASS"] = str(a.per_pass)
+    flow = pkg.PiecemealOpticalFlow()
+    flow.initialize(n, n, n)
+    t0 = time.time()
+    got = flow.compute(f0, f1, silent=True, **kw)
+    wall = time.time() - t0
+    passes, streamed = flow.stats()
+    print(f"piecemeal: {flow.device_seconds:8.3f} s ({wall:.3f} s wall with host allocation and page-locking)  "
+          f"{n ** 3 / flow.device_seconds / 1e6:7.2f} Mvoxels/s  budget {a.budget_mb or 'auto'} MB  "
+          f"{passes} solver residencies, {streamed} levels streamed", flush=True)
+    print("           " + "  ".join(f"{k} {v:.3f}s" for k, v in flow.operator_seconds().items()), flush=True)
+    flow.destroy()
+    if exp is not None:
+        ok = all(bool(np.all(g == e)) for g, e in zip(got, exp))
+        print("results identical" if ok else "RESULTS DIFFER")
+        if not ok:
+            sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
