@@ -76,6 +76,7 @@ def hip():
         "f3d_copy3d_d2h": [_fp, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
         "f3d_copy_planes_h2d": [_dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz, _sz, _sz],
         "f3d_copy_planes_d2h": [_fp, _sz, _sz, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
+        "f3d_copy_rect_d2d": [_dp, _sz, _sz, _sz, _dp, _sz, _sz, _sz, _sz, _sz, _sz],
         "f3d_host_register": [C.c_void_p, _sz], "f3d_host_unregister": [C.c_void_p],
         "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)], "f3d_get_container": [C.POINTER(Size4)],
         "f3d_event_create": [C.POINTER(C.c_void_p)], "f3d_event_record": [C.c_void_p],
@@ -159,7 +160,8 @@ def host():
         "f3d_plan_solve_piecemeal": [_sz, _sz, _sz, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
-        "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
+        "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
+        "f3d_pflow_set_resident": [C.c_void_p, C.c_int],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
@@ -538,15 +540,19 @@ class PiecemealOpticalFlow:
 
     def operator_seconds(self):
         """wall seconds of the last compute per operator"""
-        t = (C.c_double * 5)()
+        t = (C.c_double * 6)()
         check(host().f3d_pflow_operator_seconds(self._h, t), "f3d_pflow_operator_seconds")
-        return dict(zip(("frames", "flow_resample", "registration", "solve", "add"), t))
+        return dict(zip(("frames", "flow_resample", "registration", "solve", "add", "resident_levels"), t))
+
+    def set_resident(self, enabled):
+        """coarse levels that fit the budget stay on the device (default) or every level goes through the host"""
+        check(host().f3d_pflow_set_resident(self._h, int(bool(enabled))), "f3d_pflow_set_resident")
 
     def stats(self):
-        """(solver residencies, levels that did not fit the budget) of the last compute"""
-        a, b = _sz(), _sz()
-        check(host().f3d_pflow_stats(self._h, C.byref(a), C.byref(b)), "f3d_pflow_stats")
-        return a.value, b.value
+        """(solver residencies, levels cut into chunks, coarse levels run wholly on the device) of the last compute"""
+        a, b, c = _sz(), _sz(), _sz()
+        check(host().f3d_pflow_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "f3d_pflow_stats")
+        return a.value, b.value, c.value
 
     def destroy(self):
         if self._h:

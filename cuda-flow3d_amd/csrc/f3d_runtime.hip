@@ -358,6 +358,23 @@ int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size
   return 0;
 }
 
+int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t dst_plane0, f3d_devptr src, size_t src_pitch,
+                      size_t src_rows, size_t src_plane0, size_t width, size_t height, size_t depth)
+{
+  F3D_REQUIRE_READY("f3d_copy_rect_d2d");
+  if (depth == 0) return 0;
+  const size_t wb = width * sizeof(float);
+  if (height > dst_rows || height > src_rows || wb > dst_pitch || wb > src_pitch)
+    return f3d::fail("f3d_copy_rect_d2d: %zux%zu does not fit one of the containers", width, height);
+  hipMemcpy3DParms p = {};
+  p.srcPtr = make_hipPitchedPtr(f3d_ptr<char>(src) + src_plane0 * src_rows * src_pitch, src_pitch, src_pitch / sizeof(float), src_rows);
+  p.dstPtr = make_hipPitchedPtr(f3d_ptr<char>(dst) + dst_plane0 * dst_rows * dst_pitch, dst_pitch, dst_pitch / sizeof(float), dst_rows);
+  p.extent = make_hipExtent(wb, height, depth);
+  p.kind = hipMemcpyDeviceToDevice;
+  F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
+  return 0;
+}
+
 int f3d_host_register(void* ptr, size_t bytes)
 {
   F3D_REQUIRE_READY("f3d_host_register");

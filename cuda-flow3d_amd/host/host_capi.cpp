@@ -271,18 +271,26 @@ int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1
   return (f0.DataPtr() == frame_0 && f1.DataPtr() == frame_1 && fu.DataPtr() == u && fv.DataPtr() == v && fw.DataPtr() == w) ? 0 : 1;
 }
 
-int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels)
+int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels, size_t* resident_levels)
 {
   if (!flow) return 1;
   if (solve_passes) *solve_passes = flow->driver.LastSolvePasses();
   if (streamed_levels) *streamed_levels = flow->driver.LastStreamedLevels();
+  if (resident_levels) *resident_levels = flow->driver.LastResidentLevels();
   return 0;
 }
 
-int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds5)
+int f3d_pflow_set_resident(f3d_pflow flow, int enabled)
 {
-  if (!flow || !seconds5) return 1;
-  for (int i = 0; i < 5; ++i) seconds5[i] = flow->driver.LastOperatorSeconds()[i];
+  if (!flow) return 1;
+  flow->driver.resident_coarse_levels = enabled != 0;
+  return 0;
+}
+
+int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds6)
+{
+  if (!flow || !seconds6) return 1;
+  for (int i = 0; i < 6; ++i) seconds6[i] = flow->driver.LastOperatorSeconds()[i];
   return 0;
 }
 

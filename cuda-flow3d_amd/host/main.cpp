@@ -142,8 +142,9 @@ int main(int argc, char** argv)
       flow_v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
       flow_w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
       if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), flow_u, flow_v, flow_w);
-      std::printf("pair %zu of %zu: %.3f s, %zu solver residencies, %zu levels streamed\n", k + 1, pairs,
-                  optical_flow_p.LastDeviceSeconds(), optical_flow_p.LastSolvePasses(), optical_flow_p.LastStreamedLevels());
+      std::printf("pair %zu of %zu: %.3f s, %zu solver residencies, %zu levels streamed, %zu levels on the device\n", k + 1, pairs,
+                  optical_flow_p.LastDeviceSeconds(), optical_flow_p.LastSolvePasses(), optical_flow_p.LastStreamedLevels(),
+                  optical_flow_p.LastResidentLevels());
       if (pairs > 1) frame_0.Swap(frame_1);
     }
     optical_flow_p.Destroy();

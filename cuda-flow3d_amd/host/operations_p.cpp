@@ -29,6 +29,7 @@ struct Arena {
   DevicePtr base = 0;
   size_t bytes = 0;
 } g_arena;
+size_t g_reserved = 0;
 
 DevicePtr ArenaReserve(size_t bytes)
 {
@@ -134,11 +135,24 @@ size_t PiecemealBudgetBytes()
 {
   if (const char* e = std::getenv("F3D_P_BUDGET_MB")) {
     const double mb = std::atof(e);
-    if (mb > 0) return static_cast<size_t>(mb * 1024.0 * 1024.0);
+    if (mb > 0) {
+      const size_t bytes = static_cast<size_t>(mb * 1024.0 * 1024.0);
+      return bytes > g_reserved ? bytes - g_reserved : 0;
+    }
   }
   size_t free_b = 0, total_b = 0;
   if (CheckDeviceError(f3d_mem_info(&free_b, &total_b))) return 0;
   return static_cast<size_t>(0.85 * static_cast<double>(free_b + g_arena.bytes));
+}
+
+void PiecemealSetReservedBytes(size_t bytes) { g_reserved = bytes; }
+
+size_t PiecemealMinResampleBytes(size_t width, size_t height)
+{
+  // one output plane reads at most ceil(delta) + 1 source planes, delta <= the depth shrink of the coarsest level; 16 covers
+  // scale factors down to 0.95^40 with room to spare, and three buffers hold that span
+  const ChunkBox box(width, height);
+  return 4 * (kFieldSkew + kAlign) + (3 * 16 + 1) * box.plane;
 }
 
 void PiecemealReleaseArena()
@@ -303,9 +317,26 @@ void CudaOperationResampleP::Execute(OperationParameters& params)
     std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
     return;
   }
+  Run(input, data_size, resample_size, output_ptr, 0, 0, 0);
+}
+
+bool CudaOperationResampleP::ExecuteToDevice(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, DevicePtr dst,
+                                             size_t dst_pitch, size_t dst_rows)
+{
+  if (!IsInitialized()) return false;
+  if (!Fits(input, data_size) || !dst || resample_size.height > dst_rows || resample_size.width * sizeof(float) > dst_pitch) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return false;
+  }
+  return Run(input, data_size, resample_size, nullptr, dst, dst_pitch, dst_rows);
+}
+
+bool CudaOperationResampleP::Run(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, Data3D* output, DevicePtr dst,
+                                 size_t dst_pitch, size_t dst_rows)
+{
   const size_t Wi = data_size.width, Hi = data_size.height, Wo = resample_size.width, Ho = resample_size.height;
   const int Di = static_cast<int>(data_size.depth), Do = static_cast<int>(resample_size.depth);
-  if (Wi == 0 || Hi == 0 || Di == 0 || Wo == 0 || Ho == 0 || Do == 0) return;
+  if (Wi == 0 || Hi == 0 || Di == 0 || Wo == 0 || Ho == 0 || Do == 0) return true;
 
   // Buffers per chunk of `c` output planes that read `s` source planes: source, x pass, x+y pass (s planes each), result
   // (c planes), all in one container geometry that holds both boxes.
@@ -326,15 +357,18 @@ void CudaOperationResampleP::Execute(OperationParameters& params)
     }
     chunk = lo;
   }
-  if (chunk < 1) return LowMemory(GetName());
+  if (chunk < 1) {
+    LowMemory(GetName());
+    return false;
+  }
   size_t span = 0;
   for (int z0 = 0; z0 < Do; z0 += chunk) span = std::max<size_t>(span, source_of(z0, std::min(Do, z0 + chunk)).size());
   Carver buf(box);
   for (int i = 0; i < 3; ++i) buf.Add(span);
   buf.Add(chunk);
-  if (!buf.Commit()) return;
+  if (!buf.Commit()) return false;
   ContainerScope scope(box, std::max<size_t>(span, chunk));
-  if (!scope.ok()) return;
+  if (!scope.ok()) return false;
 
   // In place (input == output) a chunk's result lands on host planes [z0, z1) of the volume it is read from.  Going up
   // in z is safe when the depth shrinks or stays (later chunks read planes >= floor(z1 * delta) >= z1), going down when
@@ -345,13 +379,17 @@ void CudaOperationResampleP::Execute(OperationParameters& params)
     const int z0 = (descending ? n_chunks - 1 - k : k) * chunk, z1 = std::min(Do, z0 + chunk);
     const PlaneRange src = source_of(z0, z1);
     const f3d_slab in_slab = {src.lo, src.lo, src.hi}, out_slab = {z0, z0, z1};
-    if (!Upload(buf[0], box, 0, input, Wi, Hi, src.lo, src.size())) return;
-    if (CheckDeviceError(f3d_resample_x(buf[0], buf[1], Wo, Hi, Di, Wi, &in_slab))) return;
-    if (CheckDeviceError(f3d_resample_y(buf[1], buf[2], Wo, Ho, Di, Hi, &in_slab))) return;
-    if (CheckDeviceError(f3d_resample_z(buf[2], buf[3], Wo, Ho, Do, Di, &in_slab, &out_slab))) return;
-    if (!Download(output, Wo, Ho, z0, z1 - z0, buf[3], box, 0)) return;
+    if (!Upload(buf[0], box, 0, input, Wi, Hi, src.lo, src.size())) return false;
+    if (CheckDeviceError(f3d_resample_x(buf[0], buf[1], Wo, Hi, Di, Wi, &in_slab))) return false;
+    if (CheckDeviceError(f3d_resample_y(buf[1], buf[2], Wo, Ho, Di, Hi, &in_slab))) return false;
+    if (CheckDeviceError(f3d_resample_z(buf[2], buf[3], Wo, Ho, Do, Di, &in_slab, &out_slab))) return false;
+    if (output) {
+      if (!Download(*output, Wo, Ho, z0, z1 - z0, buf[3], box, 0)) return false;
+    } else if (CheckDeviceError(f3d_copy_rect_d2d(dst, dst_pitch, dst_rows, z0, buf[3], box.pitch, box.H, 0, Wo, Ho, z1 - z0))) {
+      return false;
+    }
   }
-  CheckDeviceError(f3d_stream_sync());
+  return !CheckDeviceError(f3d_stream_sync());
 }
 
 // ---- registration (cuda_operation_register_p.cpp:54-139: the reference warps on the CPU) ---------------------------

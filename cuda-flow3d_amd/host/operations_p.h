@@ -23,6 +23,10 @@
 size_t PiecemealBudgetBytes();
 // Give the arena's device memory back (the driver's Destroy does).
 void PiecemealReleaseArena();
+// Device memory the driver holds outside the arena (resident coarse levels); counted against a forced budget.
+void PiecemealSetReservedBytes(size_t bytes);
+// Smallest arena the frame resample needs for a W0 x H0 original (one output plane per chunk).
+size_t PiecemealMinResampleBytes(size_t width, size_t height);
 
 // How the solver cuts a level: `chunk` owned planes per residency, `outer_per_pass` outer iterations computed before the
 // increments go back to the host, `halo` = outer_per_pass * (K + 1) planes uploaded on either side (0 when the level fits).
@@ -59,6 +63,14 @@ class CudaOperationResampleP : public CudaOperationPiecemealBase {
  public:
   CudaOperationResampleP() : CudaOperationPiecemealBase("CUDA Resample Piecemeal") {}
   void Execute(OperationParameters& params) override;
+  // Driver-internal variant: the same chunked passes, but the resampled sub-box lands in a device container (planes of
+  // dst_rows rows of dst_pitch bytes) instead of a host volume.
+  bool ExecuteToDevice(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, DevicePtr dst, size_t dst_pitch,
+                       size_t dst_rows);
+
+ private:
+  bool Run(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, Data3D* output, DevicePtr dst, size_t dst_pitch,
+           size_t dst_rows);
 };
 
 // backward trilinear warp of frame_1; the result is written to `temp` and the two volumes are swapped, like the reference

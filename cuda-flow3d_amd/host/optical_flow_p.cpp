@@ -79,38 +79,23 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   const size_t max_warp_level = GetMaxWarpLevel(original_data_size.width, original_data_size.height, original_data_size.depth, warp_scale_factor);
   int current_warp_level = static_cast<int>(std::min(warp_levels_count, max_warp_level)) - 1;
 
-  // Host scratch: eight volumes of the original size (the reference keeps ten: phi and ksi stay on the device here).
   const size_t W0 = original_data_size.width, H0 = original_data_size.height, D0 = original_data_size.depth;
-  if (!silent) {
-    std::printf("Allocating additional memory on the host...\n");
-    std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * (W0 * H0 * D0 * sizeof(float)) / (1024.f * 1024.f));
-  }
-  Data3D frame_0_res, frame_1_res_br, flow_du, flow_dv, flow_dw, temp_0, temp_1, temp_2;
-  Data3D* own[8] = {&frame_0_res, &frame_1_res_br, &flow_du, &flow_dv, &flow_dw, &temp_0, &temp_1, &temp_2};
-  for (Data3D* v : own)
-    if (!v->Allocate(W0, H0, D0)) return;
+  const size_t volume_bytes = W0 * H0 * D0 * sizeof(float);
 
-  // Page-lock everything the copies touch.  Data3D::Swap exchanges storage between volumes of this set only, so the
-  // pointers registered here are the ones to release at the end.
+  // Page-lock what the copies touch.  Data3D::Swap exchanges storage between volumes of this set only, so the pointers
+  // registered here are the ones to release at the end.
   std::vector<void*> pinned;
   const char* pin_env = std::getenv("F3D_P_PIN");
-  if (pin_host_memory && !(pin_env && pin_env[0] == '0')) {
-    const size_t bytes = W0 * H0 * D0 * sizeof(float);
-    Data3D* all[13] = {&frame_0, &frame_1, &flow_u, &flow_v, &flow_w, own[0], own[1], own[2], own[3], own[4], own[5], own[6], own[7]};
-    for (Data3D* v : all) {
-      if (f3d_host_register(v->DataPtr(), bytes) == 0) {
-        pinned.push_back(v->DataPtr());
-      } else if (!silent) {
-        std::printf("'%s': host memory could not be page-locked (%s); copies will be staged.\n", GetName(), f3d_last_error());
-        break;
-      }
+  const bool pin = pin_host_memory && !(pin_env && pin_env[0] == '0');
+  auto pin_volume = [&](Data3D* v) {
+    if (!pin) return;
+    if (f3d_host_register(v->DataPtr(), volume_bytes) == 0) {
+      pinned.push_back(v->DataPtr());
+    } else if (!silent) {
+      std::printf("'%s': host memory could not be page-locked (%s); copies will be staged.\n", GetName(), f3d_last_error());
     }
-  }
-
-  Data3D* p_frame_0 = &frame_0;
-  Data3D* p_frame_1 = &frame_1;
-  Data3D* p_frame_0_res = &frame_0_res;
-  Data3D* p_frame_1_res_br = &frame_1_res_br;
+  };
+  for (Data3D* v : {&frame_0, &frame_1, &flow_u, &flow_v, &flow_w}) pin_volume(v);
 
   f3d_event ev_start = nullptr, ev_stop = nullptr;
   CheckDeviceError(f3d_event_create(&ev_start));
@@ -119,7 +104,80 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   if (!silent) std::printf("\nStarting optical flow computation...\n");
   solve_passes_ = 0;
   streamed_levels_ = 0;
+  resident_levels_ = 0;
   for (double& t : op_seconds_) t = 0.0;
+  auto finish = [&]() {
+    float elapsed_time = 0.f;
+    CheckDeviceError(f3d_event_record(ev_stop));
+    CheckDeviceError(f3d_event_sync(ev_stop));
+    CheckDeviceError(f3d_event_elapsed_ms(&elapsed_time, ev_start, ev_stop));
+    last_device_seconds_ = elapsed_time / 1000.f;
+    if (!silent) {
+      std::printf("Total GPU computation time: % 4.4fs\n", elapsed_time / 1000.);
+      std::printf("  resident levels %.3fs | frames %.3fs  flow resample %.3fs  registration %.3fs  solve %.3fs  add %.3fs\n", op_seconds_[5],
+                  op_seconds_[0], op_seconds_[1], op_seconds_[2], op_seconds_[3], op_seconds_[4]);
+    }
+    f3d_event_destroy(ev_start);
+    f3d_event_destroy(ev_stop);
+    for (void* p : pinned) f3d_host_unregister(p);
+  };
+
+  // ---- coarse levels that fit: on the device -------------------------------------------------------------------------
+  const char* res_env = std::getenv("F3D_P_RESIDENT");
+  if (resident_coarse_levels && !(res_env && res_env[0] == '0') && current_warp_level >= 0) {
+    const size_t budget = PiecemealBudgetBytes();
+    auto container_bytes = [&](int level) {
+      const DataSize4 s = GetLevel(original_data_size, warp_scale_factor, level).size;
+      const size_t pitch = (s.width * sizeof(float) + 255) / 256 * 256;
+      return pitch * s.height * s.depth + 66048;  // + what f3d_alloc_pitched adds for alignment and stagger
+    };
+    auto fits = [&](int level) {
+      const size_t need = 14 * container_bytes(level);
+      const size_t stream = level == 0 && current_warp_level == 0 ? 0 : PiecemealMinResampleBytes(W0, H0);
+      return need <= static_cast<size_t>(0.85 * static_cast<double>(budget)) && need + stream <= budget;
+    };
+    int last = current_warp_level + 1;
+    while (last > 0 && fits(last - 1)) --last;
+    if (last <= current_warp_level) {
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, current_warp_level, last, container_bytes(last));
+      op_seconds_[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (!ok) {
+        std::printf("'%s': Error in the resident levels.\n", GetName());
+        finish();
+        return;
+      }
+      resident_levels_ = static_cast<size_t>(current_warp_level - last + 1);
+      prev_data_size = GetLevel(original_data_size, warp_scale_factor, last).size;
+      current_warp_level = last - 1;
+      if (current_warp_level < 0) {
+        finish();
+        return;
+      }
+    }
+  }
+
+  // ---- the remaining levels go through the host --------------------------------------------------------------------
+  // Host scratch: eight volumes of the original size (the reference keeps ten: phi and ksi stay on the device here).
+  if (!silent) {
+    std::printf("Allocating additional memory on the host...\n");
+    std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * volume_bytes / (1024.f * 1024.f));
+  }
+  Data3D frame_0_res, frame_1_res_br, flow_du, flow_dv, flow_dw, temp_0, temp_1, temp_2;
+  Data3D* own[8] = {&frame_0_res, &frame_1_res_br, &flow_du, &flow_dv, &flow_dw, &temp_0, &temp_1, &temp_2};
+  for (Data3D* v : own) {
+    if (!v->Allocate(W0, H0, D0)) {
+      finish();
+      return;
+    }
+    pin_volume(v);
+  }
+
+  Data3D* p_frame_0 = &frame_0;
+  Data3D* p_frame_1 = &frame_1;
+  Data3D* p_frame_0_res = &frame_0_res;
+  Data3D* p_frame_1_res_br = &frame_1_res_br;
+
   // every piecemeal Execute drains the stream before it returns, so host clocks around the calls time the device work
   auto timed = [this](int slot, CudaOperationBase& cuop, OperationParameters& bag) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -245,17 +303,154 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     --current_warp_level;
   }
 
-  float elapsed_time = 0.f;
-  CheckDeviceError(f3d_event_record(ev_stop));
-  CheckDeviceError(f3d_event_sync(ev_stop));
-  CheckDeviceError(f3d_event_elapsed_ms(&elapsed_time, ev_start, ev_stop));
-  last_device_seconds_ = elapsed_time / 1000.f;
-  if (!silent) {
-    std::printf("Total GPU computation time: % 4.4fs\n", elapsed_time / 1000.);
-    std::printf("  frames %.3fs  flow resample %.3fs  registration %.3fs  solve %.3fs  add %.3fs\n", op_seconds_[0], op_seconds_[1],
-                op_seconds_[2], op_seconds_[3], op_seconds_[4]);
+  finish();
+}
+
+bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
+                                     OperationParameters& params, int first_level, int last_level, size_t container_bytes)
+{
+  size_t outer_iterations_count, inner_iterations_count;
+  float warp_scale_factor, equation_alpha, equation_smoothness, equation_data;
+  GET_PARAM_OR_RETURN_VALUE(params, float, warp_scale_factor, "warp_scale_factor", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, outer_iterations_count, "outer_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, size_t, inner_iterations_count, "inner_iterations_count", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_alpha, "equation_alpha", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_smoothness, "equation_smoothness", false);
+  GET_PARAM_OR_RETURN_VALUE(params, float, equation_data, "equation_data", false);
+
+  DataSize4 original = {frame_0.Width(), frame_0.Height(), frame_0.Depth(), 0};
+  // one compact container geometry for all resident levels: the finest of them
+  DataSize4 container = GetLevel(original, warp_scale_factor, last_level).size;
+  enum { F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, kBuffers };
+  DevicePtr buf[kBuffers] = {0};
+  bool ok = true;
+  const size_t rows = container.height * container.depth;
+  for (int i = 0; i < kBuffers && ok; ++i) {
+    size_t pitch = 0;
+    ok = !CheckDeviceError(f3d_alloc_pitched(&buf[i], &pitch, container.width * sizeof(float), rows));
+    container.pitch = pitch;
   }
-  f3d_event_destroy(ev_start);
-  f3d_event_destroy(ev_stop);
-  for (void* p : pinned) f3d_host_unregister(p);
+  PiecemealSetReservedBytes(kBuffers * container_bytes);
+  auto release = [&]() {
+    f3d_stream_sync();
+    for (DevicePtr& p : buf) {
+      if (p) CheckDeviceError(f3d_free(p));
+      p = 0;
+    }
+    PiecemealSetReservedBytes(0);
+  };
+  if (!ok) {
+    release();
+    return false;
+  }
+  OperationParameters init;
+  init.PushValuePtr("container_size", &container);
+  for (CudaOperationBase* cuop : {static_cast<CudaOperationBase*>(&cuop_resample_e_), static_cast<CudaOperationBase*>(&cuop_register_e_),
+                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_)})
+    ok = cuop->Initialize(&init) && ok;
+
+  OperationParameters op;
+  DataSize4 prev = {0, 0, 0, 0};
+  for (int level = first_level; level >= last_level && ok; --level) {
+    const PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
+    DataSize4 current = lv.size;
+    float hx = lv.hx, hy = lv.hy, hz = lv.hz;
+    if (!silent)
+      std::printf("Solve level %2d (%4zu x%4zu x%4zu) on the device\n", level, current.width, current.height, current.depth);
+
+    // frames of this level straight into device containers
+    if (level == 0) {
+      ok = !CheckDeviceError(f3d_copy_planes_h2d(buf[F0R], container.pitch, container.height, 0, frame_0.DataPtr(), original.width,
+                                                 original.height, original.width, original.height, original.depth)) &&
+           !CheckDeviceError(f3d_copy_planes_h2d(buf[F1R], container.pitch, container.height, 0, frame_1.DataPtr(), original.width,
+                                                 original.height, original.width, original.height, original.depth));
+    } else {
+      ok = cuop_resample_p_.ExecuteToDevice(frame_0, original, current, buf[F0R], container.pitch, container.height) &&
+           cuop_resample_p_.ExecuteToDevice(frame_1, original, current, buf[F1R], container.pitch, container.height);
+    }
+    if (!ok) break;
+
+    // flow of the previous level (values stay in original-voxel units)
+    if (prev.width == 0) {
+      for (int i = FU; i <= FW; ++i)
+        ok = !CheckDeviceError(f3d_memset2d(buf[i], container.pitch, 0, container.width * sizeof(float), rows)) && ok;
+    } else {
+      for (int i = 0; i < 3; ++i) {
+        op.Clear();
+        op.PushValuePtr("dev_input", &buf[FU + i]);
+        op.PushValuePtr("dev_output", &buf[DU + i]);
+        op.PushValuePtr("dev_temp", &buf[TMP]);
+        op.PushValuePtr("data_size", &prev);
+        op.PushValuePtr("resample_size", &current);
+        cuop_resample_e_.Execute(op);
+        std::swap(buf[FU + i], buf[DU + i]);
+      }
+    }
+
+    // backward registration
+    op.Clear();
+    op.PushValuePtr("dev_frame_0", &buf[F0R]);
+    op.PushValuePtr("dev_frame_1", &buf[F1R]);
+    op.PushValuePtr("dev_flow_u", &buf[FU]);
+    op.PushValuePtr("dev_flow_v", &buf[FV]);
+    op.PushValuePtr("dev_flow_w", &buf[FW]);
+    op.PushValuePtr("dev_output", &buf[TMP]);
+    op.PushValuePtr("data_size", &current);
+    op.PushValuePtr("hx", &hx);
+    op.PushValuePtr("hy", &hy);
+    op.PushValuePtr("hz", &hz);
+    cuop_register_e_.Execute(op);
+    std::swap(buf[F1R], buf[TMP]);
+
+    // difference problem
+    op.Clear();
+    op.PushValuePtr("dev_frame_0", &buf[F0R]);
+    op.PushValuePtr("dev_frame_1", &buf[F1R]);
+    op.PushValuePtr("dev_flow_u", &buf[FU]);
+    op.PushValuePtr("dev_flow_v", &buf[FV]);
+    op.PushValuePtr("dev_flow_w", &buf[FW]);
+    op.PushValuePtr("dev_flow_du", &buf[DU]);
+    op.PushValuePtr("dev_flow_dv", &buf[DV]);
+    op.PushValuePtr("dev_flow_dw", &buf[DW]);
+    op.PushValuePtr("dev_phi", &buf[PHI]);
+    op.PushValuePtr("dev_ksi", &buf[KSI]);
+    op.PushValuePtr("dev_temp_du", &buf[TDU]);
+    op.PushValuePtr("dev_temp_dv", &buf[TDV]);
+    op.PushValuePtr("dev_temp_dw", &buf[TDW]);
+    op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
+    op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
+    op.PushValuePtr("equation_alpha", &equation_alpha);
+    op.PushValuePtr("equation_smoothness", &equation_smoothness);
+    op.PushValuePtr("equation_data", &equation_data);
+    op.PushValuePtr("data_size", &current);
+    op.PushValuePtr("hx", &hx);
+    op.PushValuePtr("hy", &hy);
+    op.PushValuePtr("hz", &hz);
+    cuop_solve_e_.silent = true;
+    cuop_solve_e_.Execute(op);
+    ++solve_passes_;
+
+    for (int i = 0; i < 3; ++i) {
+      op.Clear();
+      op.PushValuePtr("operand_0", &buf[FU + i]);
+      op.PushValuePtr("operand_1", &buf[DU + i]);
+      op.PushValuePtr("data_size", &current);
+      cuop_add_e_.Execute(op);
+    }
+    prev = current;
+  }
+
+  // hand the flow to the host: the sub-box of the last resident level (the whole volume when that is level 0)
+  if (ok) {
+    Data3D* flows[3] = {&flow_u, &flow_v, &flow_w};
+    for (int i = 0; i < 3 && ok; ++i)
+      ok = !CheckDeviceError(f3d_copy_planes_d2h(flows[i]->DataPtr(), flows[i]->Width(), flows[i]->Height(), prev.width, prev.height, prev.depth,
+                                                 buf[FU + i], container.pitch, container.height, 0));
+    ok = !CheckDeviceError(f3d_stream_sync()) && ok;
+  }
+  for (CudaOperationBase* cuop : {static_cast<CudaOperationBase*>(&cuop_resample_e_), static_cast<CudaOperationBase*>(&cuop_register_e_),
+                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_)})
+    cuop->Destroy();
+  release();
+  return ok;
 }

@@ -30,14 +30,33 @@ class OpticalFlowP : public OpticalFlowBase {
   // solver residencies of the last ComputeFlow: levels that fitted the budget count one pass each
   size_t LastSolvePasses() const { return solve_passes_; }
   size_t LastStreamedLevels() const { return streamed_levels_; }
-  // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add}
+  // coarse levels of the last ComputeFlow that ran entirely on the device (see resident_coarse_levels)
+  size_t LastResidentLevels() const { return resident_levels_; }
+  // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add} of the levels that
+  // went through the host, and in the resident coarse levels as a whole
   const double* LastOperatorSeconds() const { return op_seconds_; }
+  // Run the coarse levels whose whole working set (14 fields) fits 85 % of the device budget with the "entire data"
+  // operators, flow and increments staying on the device from level to level; only the two original frames stream through
+  // (they are resampled straight into device containers).  The flow goes to the host once, when the first level that does
+  // not fit is reached.  Same kernels, same result; F3D_P_RESIDENT=0 or this flag sends every level through the host.
+  bool resident_coarse_levels = true;
 
  private:
   DataSize4 data_size_ = {0, 0, 0, 0};
   float last_device_seconds_ = 0.f;
-  size_t solve_passes_ = 0, streamed_levels_ = 0;
-  double op_seconds_[5] = {0, 0, 0, 0, 0};
+  // levels first_level .. last_level (descending) on the device; false on a device error
+  bool RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w, OperationParameters& params,
+                         int first_level, int last_level, size_t container_bytes);
+
+  size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0;
+  double op_seconds_[6] = {0, 0, 0, 0, 0, 0};
+
+  // "entire data" operators for the resident coarse levels (not in the list Initialize prints: the reference's piecemeal
+  // driver has five operators)
+  CudaOperationResample cuop_resample_e_;
+  CudaOperationRegistration cuop_register_e_;
+  CudaOperationSolve cuop_solve_e_;
+  CudaOperationAdd cuop_add_e_;
 
   CudaOperationRegistrationP cuop_register_p_;
   CudaOperationResampleP cuop_resample_p_;

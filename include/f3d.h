@@ -85,6 +85,10 @@ int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, siz
                         size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth);
 int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height, size_t depth,
                         f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
+/* width x height x depth floats between two containers of different geometry (pitch in bytes, rows per plane), on the
+ * library stream: moves a chunk staged in one geometry into a resident container of another */
+int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t dst_plane0, f3d_devptr src, size_t src_pitch,
+                      size_t src_rows, size_t src_plane0, size_t width, size_t height, size_t depth);
 /* Page-lock caller memory so the copies above run at full link rate and asynchronously (the reference's
  * ALLOCATE_PINNED_MEMORY switch, src/data_types/data3d.cpp:30,57-61, applied to memory the caller already owns). */
 int f3d_host_register(void* ptr, size_t bytes);

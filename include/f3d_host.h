@@ -87,9 +87,13 @@ int f3d_pflow_create(f3d_pflow* flow);
 int f3d_pflow_initialize(f3d_pflow flow, size_t width, size_t height, size_t depth);
 int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1, size_t width, size_t height, size_t depth,
                       const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds);
-int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels);
-/* wall seconds of the last compute in {frame resample, flow resample, registration, solve, add} */
-int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds5);
+/* of the last compute: solver residencies, levels cut into chunks, coarse levels that ran wholly on the device */
+int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels, size_t* resident_levels);
+/* coarse levels whose working set fits the budget stay on the device (default on; F3D_P_RESIDENT=0 also turns it off) */
+int f3d_pflow_set_resident(f3d_pflow flow, int enabled);
+/* wall seconds of the last compute in {frame resample, flow resample, registration, solve, add} of the levels that went
+ * through the host, and [5] in the resident coarse levels */
+int f3d_pflow_operator_seconds(f3d_pflow flow, double* seconds6);
 int f3d_pflow_destroy(f3d_pflow flow);
 
 size_t f3d_max_warp_level(size_t width, size_t height, size_t depth, float scale_factor);

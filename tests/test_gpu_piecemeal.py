@@ -201,10 +201,11 @@ def test_solve_reports_low_memory(f3d, capfd):
         x.destroy()
 
 
-def run_p(f3d, f0, f1, **kw):
+def run_p(f3d, f0, f1, resident=True, **kw):
     d, h, w = f0.shape
     flow = f3d.PiecemealOpticalFlow()
     flow.initialize(w, h, d)
+    flow.set_resident(resident)
     try:
         out = flow.compute(f0, f1, silent=True, **kw)
         return out, flow.stats()
@@ -219,11 +220,20 @@ def test_driver_matches_oracle_small(f3d, oracle):
     keep0, keep1 = f0.copy(), f1.copy()
     (exp, levels) = oracle.compute_flow(f0, f1, gaussian_sigma=0.0, median_radius=1)
     set_budget(budget_for(13 * 26, 40, 36, 13))
-    got, (passes, streamed) = run_p(f3d, f0, f1)
-    assert streamed >= 1 and passes > levels
-    for g, e, n in zip(got, exp, "uvw"):
-        assert same(g, e), f"{n}: max diff {np.abs(g - e).max()}"
-    assert same(f0, keep0) and same(f1, keep1), "the caller's frames must come back unchanged"
+    for resident in (False, True):
+        got, (passes, streamed, on_device) = run_p(f3d, f0, f1, resident=resident)
+        assert streamed >= 1 and passes > levels
+        assert (on_device >= 10) if resident else (on_device == 0)
+        assert on_device + streamed <= levels
+        for g, e, n in zip(got, exp, "uvw"):
+            assert same(g, e), f"resident={resident} {n}: max diff {np.abs(g - e).max()}"
+        assert same(f0, keep0) and same(f1, keep1), "the caller's frames must come back unchanged"
+    # a budget that holds everything: all levels on the device, the originals uploaded once for level 0
+    set_budget(64.0)
+    got, (passes, streamed, on_device) = run_p(f3d, f0, f1)
+    assert (streamed, on_device, passes) == (0, levels, levels)
+    for g, e in zip(got, exp):
+        assert same(g, e)
 
 
 def test_driver_matches_resident_driver(f3d):
@@ -237,12 +247,13 @@ def test_driver_matches_resident_driver(f3d):
     finally:
         flow.destroy()
     set_budget(budget_for(13 * 52, n, n, 13))
-    got, (passes, streamed) = run_p(f3d, f0, f1, outer_iterations_count=6)
-    assert streamed >= 3
+    got, (passes, streamed, on_device) = run_p(f3d, f0, f1, outer_iterations_count=6)
+    assert streamed >= 3 and on_device >= 20
     for g, e, c in zip(got, exp, "uvw"):
         assert same(g, e), f"{c}: max diff {np.abs(g - e).max()}"
     os.environ["F3D_P_PIN"] = "0"   # staged copies give the same result
-    got2, _ = run_p(f3d, f0, f1, outer_iterations_count=6)
+    got2, (_, _, on_device) = run_p(f3d, f0, f1, resident=False, outer_iterations_count=6)
+    assert on_device == 0
     for g, e in zip(got2, exp):
         assert same(g, e)
 
@@ -270,7 +281,7 @@ def test_cli_partial_mode(f3d, tmp_path):
     for k in range(2):
         a = frames[k].astype(np.uint8).astype(np.float32)
         b = frames[k + 1].astype(np.uint8).astype(np.float32)
-        exp, (_, streamed) = run_p(f3d, a, b, warp_levels_count=6, outer_iterations_count=3)
+        exp, (_, streamed, _) = run_p(f3d, a, b, warp_levels_count=6, outer_iterations_count=3)
         assert streamed >= 1
         got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}-partial.raw", np.float32).reshape(D, H, W) for c in "uvw"]
         for g, e in zip(got, exp):

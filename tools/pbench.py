@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--levels", type=int, default=40)
     ap.add_argument("--per-pass", type=int, default=0)
     ap.add_argument("--no-resident", action="store_true")
+    ap.add_argument("--all-through-host", action="store_true", help="no resident coarse levels in the piecemeal driver")
     ap.add_argument("--check", action="store_true", help="compare the two results bit for bit")
     a = ap.parse_args()
     pkg = importlib.import_module("cuda-flow3d_amd")
@@ -46,13 +47,14 @@ def main():
         os.environ["F3D_P_OUTER_PER_PASS"] = str(a.per_pass)
     flow = pkg.PiecemealOpticalFlow()
     flow.initialize(n, n, n)
+    flow.set_resident(not a.all_through_host)
     t0 = time.time()
     got = flow.compute(f0, f1, silent=True, **kw)
     wall = time.time() - t0
-    passes, streamed = flow.stats()
+    passes, streamed, on_device = flow.stats()
     print(f"piecemeal: {flow.device_seconds:8.3f} s ({wall:.3f} s wall with host allocation and page-locking)  "
           f"{n ** 3 / flow.device_seconds / 1e6:7.2f} Mvoxels/s  budget {a.budget_mb or 'auto'} MB  "
-          f"{passes} solver residencies, {streamed} levels streamed", flush=True)
+          f"{passes} solver residencies, {streamed} levels in chunks, {on_device} levels on the device", flush=True)
     print("           " + "  ".join(f"{k} {v:.3f}s" for k, v in flow.operator_seconds().items()), flush=True)
     flow.destroy()
     if exp is not None:
