@@ -76,6 +76,10 @@ def hip():
         "f3d_copy3d_d2h": [_fp, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
         "f3d_copy_planes_h2d": [_dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz, _sz, _sz],
         "f3d_copy_planes_d2h": [_fp, _sz, _sz, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
+        "f3d_queue_create": [C.POINTER(C.c_void_p)], "f3d_queue_destroy": [C.c_void_p], "f3d_queue_sync": [C.c_void_p],
+        "f3d_event_record_on": [C.c_void_p, C.c_void_p], "f3d_queue_wait_event": [C.c_void_p, C.c_void_p],
+        "f3d_copy_planes_h2d_on": [C.c_void_p, _dp, _sz, _sz, _sz, _fp, _sz, _sz, _sz, _sz, _sz],
+        "f3d_copy_planes_d2h_on": [C.c_void_p, _fp, _sz, _sz, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
         "f3d_copy_rect_d2d": [_dp, _sz, _sz, _sz, _dp, _sz, _sz, _sz, _sz, _sz, _sz],
         "f3d_host_register": [C.c_void_p, _sz], "f3d_host_unregister": [C.c_void_p],
         "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)], "f3d_get_container": [C.POINTER(Size4)],
@@ -156,8 +160,8 @@ def host():
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
         "f3d_plan_resample_source": [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2,
         "f3d_volume_wrap": [C.POINTER(C.c_void_p), _fp, _sz, _sz, _sz], "f3d_volume_destroy": [C.c_void_p],
-        "f3d_op_solve_p_last": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)],
-        "f3d_plan_solve_piecemeal": [_sz, _sz, _sz, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
+        "f3d_op_solve_p_last": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(C.c_int)],
+        "f3d_plan_solve_piecemeal": [_sz, _sz, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5,
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
@@ -384,11 +388,13 @@ class HostVolume:
             HostVolume._storage.pop(self._first, None)
 
 
-def plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass=0):
-    """(chunk, outer_per_pass, halo, max_planes) the piecemeal solver would use for a level (host arithmetic)."""
-    out = [C.c_int() for _ in range(4)]
+def plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass=0,
+                         overlap_mode=0):
+    """(chunk, outer_per_pass, halo, max_planes, overlapped) the piecemeal solver would use for a level (host arithmetic);
+    overlap_mode 0 = serial schedule, 1 = copies beside the kernels, -1 = the cost model's choice."""
+    out = [C.c_int() for _ in range(5)]
     check(host().f3d_plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations,
-                                          forced_outer_per_pass, *[C.byref(o) for o in out]))
+                                          forced_outer_per_pass, overlap_mode, *[C.byref(o) for o in out]))
     return tuple(o.value for o in out)
 
 
@@ -446,10 +452,10 @@ class Operation:
         return self.values
 
     def solve_p_last(self):
-        """(chunk, outer_per_pass, halo, passes) of the last solve_p execute"""
-        c, n, h, p = C.c_int(), C.c_int(), C.c_int(), _sz()
-        check(host().f3d_op_solve_p_last(self._h, C.byref(c), C.byref(n), C.byref(h), C.byref(p)), "f3d_op_solve_p_last")
-        return c.value, n.value, h.value, p.value
+        """(chunk, outer_per_pass, halo, passes, overlapped) of the last solve_p execute"""
+        c, n, h, p, o = C.c_int(), C.c_int(), C.c_int(), _sz(), C.c_int()
+        check(host().f3d_op_solve_p_last(self._h, C.byref(c), C.byref(n), C.byref(h), C.byref(p), C.byref(o)), "f3d_op_solve_p_last")
+        return c.value, n.value, h.value, p.value, bool(o.value)
 
     def destroy(self):
         if self._h:

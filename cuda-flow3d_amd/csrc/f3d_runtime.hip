@@ -314,24 +314,36 @@ int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_de
 // Plane-range copies between a host volume with its own row / plane strides (a level's sub-box inside a full-size dense
 // volume) and a pitched container.  Asynchronous on the library stream: with page-locked host memory (f3d_host_register)
 // the call returns at once and the caller orders reuse of the host planes with f3d_stream_sync().
+struct f3d_queue_s {
+  hipStream_t stream;
+};
+static hipStream_t stream_of(f3d_queue q) { return q ? q->stream : S.stream; }
+
 int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
                         size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth)
 {
+  return f3d_copy_planes_h2d_on(nullptr, dst, dev_pitch, dev_height, dev_plane0, src, src_row_floats, src_rows, width, height, depth);
+}
+
+int f3d_copy_planes_h2d_on(f3d_queue queue, f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
+                           size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth)
+{
   F3D_REQUIRE_READY("f3d_copy_planes_h2d");
+  const hipStream_t stream = stream_of(queue);
   if (depth == 0) return 0;
   if (!src || height > dev_height || width * sizeof(float) > dev_pitch || width > src_row_floats || height > src_rows)
     return f3d::fail("f3d_copy_planes_h2d: %zux%zu does not fit the container or the host volume", width, height);
   char* d = f3d_ptr<char>(dst) + dev_plane0 * dev_height * dev_pitch;
   const size_t wb = width * sizeof(float), sb = src_row_floats * sizeof(float);
   if (height == dev_height && height == src_rows) {
-    F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, sb, wb, height * depth, hipMemcpyHostToDevice, S.stream));
+    F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, sb, wb, height * depth, hipMemcpyHostToDevice, stream));
   } else {  // one 3-D rectangle copy, not a copy per plane: a coarse level is hundreds of small planes
     hipMemcpy3DParms p = {};
     p.srcPtr = make_hipPitchedPtr(const_cast<float*>(src), sb, src_row_floats, src_rows);
     p.dstPtr = make_hipPitchedPtr(d, dev_pitch, dev_pitch / sizeof(float), dev_height);
     p.extent = make_hipExtent(wb, height, depth);
     p.kind = hipMemcpyHostToDevice;
-    F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
+    F3D_HIP(hipMemcpy3DAsync(&p, stream));
   }
   return 0;
 }
@@ -339,21 +351,28 @@ int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, siz
 int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height, size_t depth,
                         f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0)
 {
+  return f3d_copy_planes_d2h_on(nullptr, dst, dst_row_floats, dst_rows, width, height, depth, src, dev_pitch, dev_height, dev_plane0);
+}
+
+int f3d_copy_planes_d2h_on(f3d_queue queue, float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height,
+                           size_t depth, f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0)
+{
   F3D_REQUIRE_READY("f3d_copy_planes_d2h");
+  const hipStream_t stream = stream_of(queue);
   if (depth == 0) return 0;
   if (!dst || height > dev_height || width * sizeof(float) > dev_pitch || width > dst_row_floats || height > dst_rows)
     return f3d::fail("f3d_copy_planes_d2h: %zux%zu does not fit the container or the host volume", width, height);
   const char* s = f3d_ptr<const char>(src) + dev_plane0 * dev_height * dev_pitch;
   const size_t wb = width * sizeof(float), db = dst_row_floats * sizeof(float);
   if (height == dev_height && height == dst_rows) {
-    F3D_HIP(hipMemcpy2DAsync(dst, db, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, S.stream));
+    F3D_HIP(hipMemcpy2DAsync(dst, db, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, stream));
   } else {
     hipMemcpy3DParms p = {};
     p.srcPtr = make_hipPitchedPtr(const_cast<char*>(s), dev_pitch, dev_pitch / sizeof(float), dev_height);
     p.dstPtr = make_hipPitchedPtr(dst, db, dst_row_floats, dst_rows);
     p.extent = make_hipExtent(wb, height, depth);
     p.kind = hipMemcpyDeviceToHost;
-    F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
+    F3D_HIP(hipMemcpy3DAsync(&p, stream));
   }
   return 0;
 }
@@ -443,6 +462,52 @@ int f3d_event_record(f3d_event ev)
 {
   F3D_REQUIRE_READY("f3d_event_record");
   F3D_HIP(hipEventRecord(ev->ev, S.stream));
+  return 0;
+}
+
+int f3d_queue_create(f3d_queue* queue)
+{
+  F3D_REQUIRE_READY("f3d_queue_create");
+  if (!queue) return f3d::fail("f3d_queue_create: null output");
+  f3d_queue q = new f3d_queue_s;
+  hipError_t r = hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking);
+  if (r != hipSuccess) {
+    delete q;
+    return f3d::hip_fail(r, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+  }
+  *queue = q;
+  return 0;
+}
+
+int f3d_queue_destroy(f3d_queue queue)
+{
+  if (!queue) return 0;
+  (void)hipStreamSynchronize(queue->stream);
+  (void)hipStreamDestroy(queue->stream);
+  delete queue;
+  return 0;
+}
+
+int f3d_queue_sync(f3d_queue queue)
+{
+  F3D_REQUIRE_READY("f3d_queue_sync");
+  F3D_HIP(hipStreamSynchronize(stream_of(queue)));
+  return 0;
+}
+
+int f3d_event_record_on(f3d_event ev, f3d_queue queue)
+{
+  F3D_REQUIRE_READY("f3d_event_record_on");
+  if (!ev) return f3d::fail("f3d_event_record_on: null event");
+  F3D_HIP(hipEventRecord(ev->ev, stream_of(queue)));
+  return 0;
+}
+
+int f3d_queue_wait_event(f3d_queue queue, f3d_event ev)
+{
+  F3D_REQUIRE_READY("f3d_queue_wait_event");
+  if (!ev) return f3d::fail("f3d_queue_wait_event: null event");
+  F3D_HIP(hipStreamWaitEvent(stream_of(queue), ev->ev, 0));
   return 0;
 }
 

@@ -209,7 +209,7 @@ int f3d_op_destroy(f3d_op op)
   return 0;
 }
 
-int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes)
+int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes, int* overlapped)
 {
   auto* solve_p = op ? dynamic_cast<CudaOperationSolveP*>(op->op) : nullptr;
   if (!solve_p) return 1;
@@ -217,6 +217,7 @@ int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, s
   if (outer_per_pass) *outer_per_pass = solve_p->LastPlan().outer_per_pass;
   if (halo) *halo = solve_p->LastPlan().halo;
   if (passes) *passes = solve_p->LastPasses();
+  if (overlapped) *overlapped = solve_p->LastPlan().overlapped ? 1 : 0;
   return 0;
 }
 
@@ -303,10 +304,12 @@ int f3d_pflow_destroy(f3d_pflow flow)
 size_t f3d_piecemeal_budget_bytes(void) { return PiecemealBudgetBytes(); }
 
 int f3d_plan_solve_piecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations, int outer_iterations,
-                             int forced_outer_per_pass, int* chunk, int* outer_per_pass, int* halo, int* max_planes)
+                             int forced_outer_per_pass, int overlap_mode, int* chunk, int* outer_per_pass, int* halo, int* max_planes,
+                             int* overlapped)
 {
-  const SolvePiecemealPlan plan =
-      PlanSolvePiecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass);
+  const SolvePiecemealPlan plan = PlanSolvePiecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations,
+                                                     forced_outer_per_pass, overlap_mode);
+  if (overlapped) *overlapped = plan.overlapped ? 1 : 0;
   if (chunk) *chunk = plan.chunk;
   if (outer_per_pass) *outer_per_pass = plan.outer_per_pass;
   if (halo) *halo = plan.halo;

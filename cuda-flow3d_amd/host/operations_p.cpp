@@ -31,10 +31,50 @@ struct Arena {
 } g_arena;
 size_t g_reserved = 0;
 
+// Copy queues and the events that order them against the kernels (overlapped solver schedule); created on first use.
+struct Pipeline {
+  f3d_queue up = nullptr, down = nullptr;
+  f3d_event uploaded[2] = {nullptr, nullptr}, computed[2] = {nullptr, nullptr}, downloaded[2] = {nullptr, nullptr};
+  bool ready = false;
+} g_pipe;
+
+bool PipelineReady()
+{
+  if (g_pipe.ready) return true;
+  bool ok = !CheckDeviceError(f3d_queue_create(&g_pipe.up)) && !CheckDeviceError(f3d_queue_create(&g_pipe.down));
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = !CheckDeviceError(f3d_event_create(&g_pipe.uploaded[i])) && !CheckDeviceError(f3d_event_create(&g_pipe.computed[i])) &&
+         !CheckDeviceError(f3d_event_create(&g_pipe.downloaded[i]));
+  g_pipe.ready = ok;
+  return ok;
+}
+
+void PipelineRelease()
+{
+  for (int i = 0; i < 2; ++i) {
+    f3d_event_destroy(g_pipe.uploaded[i]);
+    f3d_event_destroy(g_pipe.computed[i]);
+    f3d_event_destroy(g_pipe.downloaded[i]);
+  }
+  f3d_queue_destroy(g_pipe.up);
+  f3d_queue_destroy(g_pipe.down);
+  g_pipe = Pipeline();
+}
+
+void ArenaFree()
+{
+  if (g_arena.base) {
+    f3d_stream_sync();
+    CheckDeviceError(f3d_free(g_arena.base));
+  }
+  g_arena.base = 0;
+  g_arena.bytes = 0;
+}
+
 DevicePtr ArenaReserve(size_t bytes)
 {
   if (bytes <= g_arena.bytes) return g_arena.base;
-  PiecemealReleaseArena();
+  ArenaFree();
   size_t pitch = 0;
   DevicePtr p = 0;
   if (CheckDeviceError(f3d_alloc_pitched(&p, &pitch, bytes, 1))) return 0;
@@ -107,14 +147,16 @@ bool Fits(const Data3D& v, const DataSize4& s) { return s.width <= v.Width() && 
 
 float* PlanePtr(Data3D& v, int z) { return v.DataPtr() + static_cast<size_t>(z) * v.Width() * v.Height(); }
 
-bool Upload(DevicePtr dst, const ChunkBox& b, int dev_plane0, Data3D& v, size_t w, size_t h, int z0, int count)
+bool Upload(DevicePtr dst, const ChunkBox& b, int dev_plane0, Data3D& v, size_t w, size_t h, int z0, int count, f3d_queue queue = nullptr)
 {
-  return !CheckDeviceError(f3d_copy_planes_h2d(dst, b.pitch, b.H, dev_plane0, PlanePtr(v, z0), v.Width(), v.Height(), w, h, count));
+  return !CheckDeviceError(
+      f3d_copy_planes_h2d_on(queue, dst, b.pitch, b.H, dev_plane0, PlanePtr(v, z0), v.Width(), v.Height(), w, h, count));
 }
 
-bool Download(Data3D& v, size_t w, size_t h, int z0, int count, DevicePtr src, const ChunkBox& b, int dev_plane0)
+bool Download(Data3D& v, size_t w, size_t h, int z0, int count, DevicePtr src, const ChunkBox& b, int dev_plane0, f3d_queue queue = nullptr)
 {
-  return !CheckDeviceError(f3d_copy_planes_d2h(PlanePtr(v, z0), v.Width(), v.Height(), w, h, count, src, b.pitch, b.H, dev_plane0));
+  return !CheckDeviceError(
+      f3d_copy_planes_d2h_on(queue, PlanePtr(v, z0), v.Width(), v.Height(), w, h, count, src, b.pitch, b.H, dev_plane0));
 }
 
 // pointer under which container plane (z - new_base) is the plane the buffer holds for z at (z - old_base)
@@ -157,51 +199,71 @@ size_t PiecemealMinResampleBytes(size_t width, size_t height)
 
 void PiecemealReleaseArena()
 {
-  if (g_arena.base) {
-    f3d_stream_sync();
-    CheckDeviceError(f3d_free(g_arena.base));
-  }
-  g_arena.base = 0;
-  g_arena.bytes = 0;
+  ArenaFree();
+  PipelineRelease();
 }
 
-SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass)
+namespace {
+
+// Best number of outer iterations per residency for one schedule.  Cost per owned voxel of one full solve: link bytes at
+// ~50 GB/s each way (eight fields up with their halos, three down, per pass) and device bytes at ~5 TB/s (300 B per voxel
+// and outer iteration on windows that average chunk + halo planes).  Serial: the three add up.  Overlapped (two chunk
+// sets, half the planes each): the slowest of the three, plus the other two once per level for filling the pipeline.
+SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_iterations, int forced, bool overlapped)
 {
   SolvePiecemealPlan plan;
-  const ChunkBox box(width, height);
-  const size_t total = box.TotalPlanes(budget_bytes, 13);
-  plan.max_planes = static_cast<int>(std::min<size_t>(total / 13, static_cast<size_t>(std::numeric_limits<int>::max())));
-  if (depth <= 0 || outer_iterations <= 0) return plan;
-  if (plan.max_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
-    plan.chunk = depth;
-    plan.outer_per_pass = outer_iterations;
-    plan.halo = 0;
-    return plan;
-  }
-  const int step = inner_iterations + 1;
-  // Cost per owned plane of one full solve, in arbitrary time units: link bytes at ~50 GB/s (eight fields up with their
-  // halos, three down, per pass) against device bytes at ~5 TB/s (300 B per voxel and outer iteration on windows that
-  // average chunk + halo planes).
-  double best = 0.0;
+  plan.max_planes = max_planes;
+  plan.overlapped = overlapped;
   for (int n = 1; n <= outer_iterations; ++n) {
-    if (forced_outer_per_pass > 0 && n != std::min(forced_outer_per_pass, outer_iterations)) continue;
+    if (forced > 0 && n != std::min(forced, outer_iterations)) continue;
     const int halo = n * step;
-    const int chunk = plan.max_planes - 2 * halo;
+    const int chunk = max_planes - 2 * halo;
     if (chunk < 1) break;
     const double passes = std::ceil(static_cast<double>(outer_iterations) / n);
     const double wide = static_cast<double>(chunk + 2 * halo) / chunk, mid = static_cast<double>(chunk + halo) / chunk;
-    const double link = passes * (8.0 * wide + 3.0) * 4.0 / 50e9;
+    const double up = passes * 8.0 * wide * 4.0 / 50e9, down = passes * 3.0 * 4.0 / 50e9;
     const double device = outer_iterations * 300.0 * mid / 5e12;
-    const double cost = link + device;
-    if (plan.chunk == 0 || cost < best) {
-      best = cost;
+    double cost = up + down + device;
+    if (overlapped) {
+      const double slowest = std::max(up, std::max(down, device));
+      const double chunks = std::ceil(static_cast<double>(depth) / chunk) * passes;
+      cost = slowest + (cost - slowest) / std::max(1.0, chunks);
+    }
+    if (plan.chunk == 0 || cost < plan.cost) {
+      plan.cost = cost;
       plan.chunk = chunk;
       plan.outer_per_pass = n;
       plan.halo = halo;
     }
   }
   return plan;
+}
+
+}  // namespace
+
+SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode)
+{
+  SolvePiecemealPlan plan;
+  const ChunkBox box(width, height);
+  const size_t cap = static_cast<size_t>(std::numeric_limits<int>::max());
+  const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 13) / 13, cap));
+  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 26) / 26, cap));
+  plan.max_planes = serial_planes;
+  if (depth <= 0 || outer_iterations <= 0) return plan;
+  if (serial_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
+    plan.chunk = depth;
+    plan.outer_per_pass = outer_iterations;
+    plan.halo = 0;
+    plan.cost = (8.0 + 3.0) * 4.0 / 50e9 + outer_iterations * 300.0 / 5e12;
+    return plan;
+  }
+  const int step = inner_iterations + 1;
+  const SolvePiecemealPlan serial = PlanSchedule(serial_planes, depth, step, outer_iterations, forced_outer_per_pass, false);
+  const SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true);
+  if (overlap_mode == 0) return serial;
+  if (overlap_mode == 1) return overlapped;
+  return (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
 }
 
 bool CudaOperationPiecemealBase::Initialize(const OperationParameters*)
@@ -530,45 +592,66 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     return;
   }
 
-  int forced = 0;
+  int forced = 0, overlap_mode = -1;
   if (const char* e = std::getenv("F3D_P_OUTER_PER_PASS")) forced = std::atoi(e);
-  const SolvePiecemealPlan plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced);
+  if (const char* e = std::getenv("F3D_P_OVERLAP")) overlap_mode = std::atoi(e);
+  SolvePiecemealPlan plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode);
+  if (plan.overlapped && !PipelineReady()) plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0);
   last_plan_ = plan;
   if (plan.chunk < 1) return LowMemory(GetName());
   const int chunk = plan.chunk, halo = plan.halo, planes = std::min(D, chunk + 2 * halo);
+  const int n_sets = plan.overlapped ? 2 : 1;
 
   enum { F0, F1, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, kFields };
   const ChunkBox box(W, H);
   Carver carve(box);
-  for (int i = 0; i < kFields; ++i) carve.Add(planes);
+  for (int i = 0; i < n_sets * kFields; ++i) carve.Add(planes);
   if (!carve.Commit()) return;
   ContainerScope scope(box, planes);
   if (!scope.ok()) return;
-  DevicePtr buf[kFields];
-  for (int i = 0; i < kFields; ++i) buf[i] = carve[i];
+  DevicePtr sets[2][kFields];
+  for (int s = 0; s < n_sets; ++s)
+    for (int i = 0; i < kFields; ++i) sets[s][i] = carve[s * kFields + i];
+  // Serial: copies and kernels in order on the library stream.  Overlapped: uploads on one queue, downloads on another,
+  // kernels on the library stream; a chunk set is reused once the download of its previous chunk has finished.
+  const f3d_queue q_up = plan.overlapped ? g_pipe.up : nullptr, q_down = plan.overlapped ? g_pipe.down : nullptr;
+  bool set_used[2] = {false, false};
 
   if (!silent) {
-    std::printf("%d x %d planes, %d outer iterations per pass\n", (D + chunk - 1) / chunk, chunk, plan.outer_per_pass);
+    std::printf("%d x %d planes, %d outer iterations per pass%s\n", (D + chunk - 1) / chunk, chunk, plan.outer_per_pass,
+                plan.overlapped ? ", copies beside the kernels" : "");
     Utils::PrintProgressBar(0.f);
   }
   const size_t rows = static_cast<size_t>(planes) * H;
   const bool fused = FusedSweepsEnabled();
+  size_t chunk_counter = 0;
   for (int i0 = 0; i0 < outer; i0 += plan.outer_per_pass) {
     const int n = std::min(plan.outer_per_pass, outer - i0);
     const int reach = halo ? n * (K + 1) : 0;  // planes of input this pass reads beyond the chunk
-    for (int z0 = 0; z0 < D; z0 += chunk) {
+    for (int z0 = 0; z0 < D; z0 += chunk, ++chunk_counter) {
       const int z1 = std::min(D, z0 + chunk);
+      const int set = plan.overlapped ? static_cast<int>(chunk_counter & 1) : 0;
+      DevicePtr* buf = sets[set];
       const int base = halo ? z0 - halo : 0;  // global plane held by container plane 0
       const int lo = std::max(0, z0 - reach), hi = std::min(D, z1 + reach);
       auto window = [&](int grow) { return f3d_slab{base, std::max(0, z0 - grow), std::min(D, z1 + grow)}; };
+      if (plan.overlapped && set_used[set]) {
+        // the set's previous chunk must have left: its increments are still being read by the download queue
+        if (CheckDeviceError(f3d_queue_wait_event(q_up, g_pipe.downloaded[set]))) return;
+        if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.downloaded[set]))) return;
+      }
       for (int i = 0; i < 5; ++i)
-        if (!Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo)) return;
+        if (!Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo, q_up)) return;
       for (int i = 0; i < 3; ++i) {
         if (i0 == 0) {
           if (CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
-        } else if (!Upload(buf[DU + i], box, lo - base, *inc[i], W, H, lo, hi - lo)) {
+        } else if (!Upload(buf[DU + i], box, lo - base, *inc[i], W, H, lo, hi - lo, q_up)) {
           return;
         }
+      }
+      if (plan.overlapped) {
+        if (CheckDeviceError(f3d_event_record_on(g_pipe.uploaded[set], q_up))) return;
+        if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.uploaded[set]))) return;
       }
       // Outer iteration j of this pass leaves the increments valid on the chunk widened by g = (n-1-j)(K+1) planes:
       // phi/ksi on g + K, sweep s on g + K-1-s; a fused pair runs on the window of its second sweep.
@@ -593,9 +676,19 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
           s += pair ? 2 : 1;
         }
       }
+      if (plan.overlapped) {
+        if (CheckDeviceError(f3d_event_record_on(g_pipe.computed[set], nullptr))) return;
+        if (CheckDeviceError(f3d_queue_wait_event(q_down, g_pipe.computed[set]))) return;
+      }
       for (int i = 0; i < 3; ++i)
-        if (!Download(*next[i], W, H, z0, z1 - z0, buf[DU + i], box, z0 - base)) return;
+        if (!Download(*next[i], W, H, z0, z1 - z0, buf[DU + i], box, z0 - base, q_down)) return;
+      if (plan.overlapped) {
+        if (CheckDeviceError(f3d_event_record_on(g_pipe.downloaded[set], q_down))) return;
+        set_used[set] = true;
+      }
     }
+    // the pass is complete when its last download is: the next pass reads what this one wrote
+    if (plan.overlapped && CheckDeviceError(f3d_queue_sync(q_down))) return;
     if (CheckDeviceError(f3d_stream_sync())) return;
     for (int i = 0; i < 3; ++i) inc[i]->Swap(*next[i]);
     ++last_passes_;

@@ -34,12 +34,15 @@ struct SolvePiecemealPlan {
   int chunk = 0;
   int outer_per_pass = 0;
   int halo = 0;
-  int max_planes = 0;  // planes of one field the budget allows
+  int max_planes = 0;       // planes of one field the budget allows (per chunk set when overlapped)
+  bool overlapped = false;  // two chunk sets: upload of the next and download of the previous chunk beside the kernels
+  double cost = 0.0;        // the model's seconds per owned voxel
 };
-// Pure host arithmetic (CPU-testable).  forced_outer_per_pass > 0 pins n (F3D_P_OUTER_PER_PASS); chunk == 0 means the
-// budget cannot hold even one plane with its halo.
+// Pure host arithmetic (CPU-testable).  forced_outer_per_pass > 0 pins n (F3D_P_OUTER_PER_PASS); overlap_mode 0 / 1 pins
+// the serial / overlapped schedule, anything else lets the cost model choose (F3D_P_OVERLAP); chunk == 0 means the budget
+// cannot hold even one plane with its halo.
 SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass);
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode = -1);
 
 class CudaOperationPiecemealBase : public CudaOperationBase {
  public:

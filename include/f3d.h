@@ -48,6 +48,7 @@ typedef struct f3d_slab {
 } f3d_slab;
 
 typedef struct f3d_event_s* f3d_event;
+typedef struct f3d_queue_s* f3d_queue; /* a side stream for copies; NULL always means the library stream */
 
 /* ---- runtime: context, memory, copies, events ------------------------------------------------ */
 
@@ -85,6 +86,19 @@ int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, siz
                         size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth);
 int f3d_copy_planes_d2h(float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height, size_t depth,
                         f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
+/* Copy queues: the piecemeal solver uploads the next chunk and downloads the previous one beside the kernels of the current
+ * one.  Work on a queue is ordered; order BETWEEN queues (and the library stream, queue == NULL) is expressed with events:
+ * f3d_event_record_on(ev, a); f3d_queue_wait_event(b, ev) makes everything issued to b afterwards wait for what a had been
+ * given before the record.  (The reference has one NULL stream and synchronous cuMemcpy3D, cuda_operation_solve_p.cpp:226.) */
+int f3d_queue_create(f3d_queue* queue);
+int f3d_queue_destroy(f3d_queue queue);
+int f3d_queue_sync(f3d_queue queue);
+int f3d_event_record_on(f3d_event ev, f3d_queue queue);
+int f3d_queue_wait_event(f3d_queue queue, f3d_event ev);
+int f3d_copy_planes_h2d_on(f3d_queue queue, f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
+                           size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth);
+int f3d_copy_planes_d2h_on(f3d_queue queue, float* dst, size_t dst_row_floats, size_t dst_rows, size_t width, size_t height,
+                           size_t depth, f3d_devptr src, size_t dev_pitch, size_t dev_height, size_t dev_plane0);
 /* width x height x depth floats between two containers of different geometry (pitch in bytes, rows per plane), on the
  * library stream: moves a chunk staged in one geometry into a resident container of another */
 int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t dst_plane0, f3d_devptr src, size_t src_pitch,

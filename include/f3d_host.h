@@ -75,10 +75,12 @@ void* f3d_volume_object(f3d_volume vol);
 float* f3d_volume_data(f3d_volume vol);
 int f3d_volume_destroy(f3d_volume vol);
 /* what the last solve_p Execute did */
-int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes);
-/* chunk plan of solve_p for a level (pure host arithmetic) and the device budget it would use now */
+int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes, int* overlapped);
+/* chunk plan of solve_p for a level (pure host arithmetic) and the device budget it would use now.  overlap_mode 0 = copies
+ * and kernels in order, 1 = two chunk sets with the copies beside the kernels, -1 = whichever the cost model prefers */
 int f3d_plan_solve_piecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations, int outer_iterations,
-                             int forced_outer_per_pass, int* chunk, int* outer_per_pass, int* halo, int* max_planes);
+                             int forced_outer_per_pass, int overlap_mode, int* chunk, int* outer_per_pass, int* halo, int* max_planes,
+                             int* overlapped);
 size_t f3d_piecemeal_budget_bytes(void);
 
 /* OpticalFlowP (src/optical_flow/optical_flow_p.h:35-57; ComputeFlow optical_flow_p.cpp:57-318): no pre-blur, no median */

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _env():
-    keep = {k: os.environ.get(k) for k in ("F3D_P_BUDGET_MB", "F3D_P_OUTER_PER_PASS", "F3D_P_PIN")}
+    keep = {k: os.environ.get(k) for k in ("F3D_P_BUDGET_MB", "F3D_P_OUTER_PER_PASS", "F3D_P_PIN", "F3D_P_OVERLAP", "F3D_P_RESIDENT")}
     yield
     for k, v in keep.items():
         if v is None:
@@ -144,35 +144,41 @@ def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, e
     return du, dv, dw
 
 
-@pytest.mark.parametrize("planes,forced,outer,inner", [
-    (1000, 0, 3, 5),   # fits: one residency
-    (22, 1, 3, 5),     # 10-plane chunks, increments go home after every outer iteration
-    (34, 2, 5, 5),     # two outer iterations per residency, last pass shorter
-    (30, 0, 4, 3),     # planner's own choice, odd inner count
-    (26, 3, 3, 2),     # three per residency with pairs only
+@pytest.mark.parametrize("planes,forced,outer,inner,overlap,D", [
+    (1000, 0, 3, 5, 0, 27),   # fits: one residency
+    (22, 1, 3, 5, 0, 27),     # 10-plane chunks, increments go home after every outer iteration
+    (34, 2, 5, 5, 0, 40),     # two outer iterations per residency, last pass shorter
+    (30, 0, 4, 3, 0, 33),     # planner's own choice, odd inner count
+    (26, 3, 3, 2, 0, 27),     # three per residency with pairs only
+    (13, 1, 4, 5, 1, 27),     # two chunk sets of 13 planes: one-plane chunks, 27 of them through the pipeline per pass
+    (28, 2, 5, 5, 1, 61),     # overlapped, two outer iterations per residency, odd number of chunks per pass
+    (1000, 0, 3, 5, 1, 27),   # overlap asked for but the level fits: still one residency
 ])
-def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner):
+def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap, D):
     rng = np.random.default_rng(planes)
-    W, H, D = 37, 21, 27
-    cd = (40, 24, 30)
+    W, H = 37, 21
+    cd = (40, 24, D + 3)
     dims, h = (W, H, D), (1.25, 1.0, 1.6)
     f0 = box_in_container(rng, dims, cd, 0, 255)
     f1 = np.full_like(f0, np.nan)
     f1[:D, :H, :W] = f0[:D, :H, :W] + rng.uniform(-8, 8, size=(D, H, W)).astype(np.float32)
     u, v, w = (box_in_container(rng, dims, cd, -2, 2) for _ in range(3))
     expect = oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, 7.5, 0.001, 0.001)
-    set_budget(budget_for(13 * planes, W, H, 13))
+    fields = 26 if overlap and planes < D else 13
+    set_budget(budget_for(fields * planes, W, H, fields))
     os.environ["F3D_P_OUTER_PER_PASS"] = str(forced)
+    os.environ["F3D_P_OVERLAP"] = str(overlap)
     names = ["frame_0", "frame_1", "flow_u", "flow_v", "flow_w", "flow_du", "flow_dv", "flow_dw", "temp_du", "temp_dv", "temp_dw"]
     arrays = [f0, f1, u, v, w] + [np.full(f0.shape, np.nan, np.float32) for _ in range(6)]
     vols = {n: f3d.HostVolume(a.copy()) for n, a in zip(names, arrays)}
     op = make_op(f3d, "solve_p")
     op.execute(outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5, equation_smoothness=0.001,
                equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **vols)
-    chunk, per_pass, halo, passes = op.solve_p_last()
+    chunk, per_pass, halo, passes, overlapped = op.solve_p_last()
     if planes >= D:
-        assert (chunk, per_pass, halo, passes) == (D, outer, 0, 1)
+        assert (chunk, per_pass, halo, passes, overlapped) == (D, outer, 0, 1, False)
     else:
+        assert overlapped == bool(overlap) and chunk == planes - 2 * halo
         assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
         if forced:
             assert per_pass == forced
@@ -256,6 +262,15 @@ def test_driver_matches_resident_driver(f3d):
     assert on_device == 0
     for g, e in zip(got2, exp):
         assert same(g, e)
+    os.environ["F3D_P_PIN"] = "1"   # copies beside the kernels, pinned and staged
+    os.environ["F3D_P_OVERLAP"] = "1"
+    set_budget(budget_for(26 * 40, n, n, 26))
+    for pin in ("1", "0"):
+        os.environ["F3D_P_PIN"] = pin
+        got3, (passes, streamed, _) = run_p(f3d, f0, f1, outer_iterations_count=6)
+        assert streamed >= 3
+        for g, e in zip(got3, exp):
+            assert same(g, e)
 
 
 def test_cli_partial_mode(f3d, tmp_path):

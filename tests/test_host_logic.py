@@ -213,13 +213,13 @@ def test_piecemeal_solver_plan_properties(f3d):
     for (w, h, d) in [(100, 90, 80), (512, 512, 512), (2048, 2048, 2048), (37, 21, 27)]:
         for inner in (1, 2, 5):
             for outer in (1, 3, 40):
-                chunk, per_pass, halo, max_planes = f3d.plan_solve_piecemeal(planes_budget(d, w, h), w, h, d, inner, outer)
+                chunk, per_pass, halo, max_planes, _ = f3d.plan_solve_piecemeal(planes_budget(d, w, h), w, h, d, inner, outer)
                 assert (chunk, per_pass, halo) == (d, outer, 0) and max_planes >= d
                 for planes in (2 * (inner + 1) + 1, 3 * (inner + 1) + 4, d // 2 + 2 * (inner + 1), d - 1):
                     if planes >= d:
                         continue
-                    chunk, per_pass, halo, max_planes = f3d.plan_solve_piecemeal(planes_budget(planes, w, h), w, h, d, inner, outer)
-                    assert max_planes == planes
+                    chunk, per_pass, halo, max_planes, overlapped = f3d.plan_solve_piecemeal(planes_budget(planes, w, h), w, h, d, inner, outer)
+                    assert max_planes == planes and not overlapped
                     assert 1 <= per_pass <= outer and halo == per_pass * (inner + 1) and chunk == planes - 2 * halo >= 1
                     forced = f3d.plan_solve_piecemeal(planes_budget(planes, w, h), w, h, d, inner, outer, 1)
                     assert forced[1] == 1 and forced[2] == inner + 1 and forced[0] == planes - 2 * (inner + 1)
@@ -229,3 +229,10 @@ def test_piecemeal_solver_plan_properties(f3d):
     big = f3d.plan_solve_piecemeal(270 << 30, 2048, 2048, 2048, 5, 40)
     small = f3d.plan_solve_piecemeal(planes_budget(40, 2048, 2048), 2048, 2048, 2048, 5, 40)
     assert big[1] >= 8 and small[1] <= 2
+    # two chunk sets halve the planes per set; the model takes them when chunks stay much thicker than their halos
+    auto_big = f3d.plan_solve_piecemeal(270 << 30, 2048, 2048, 2048, 5, 40, 0, -1)
+    forced_on = f3d.plan_solve_piecemeal(270 << 30, 2048, 2048, 2048, 5, 40, 0, 1)
+    assert forced_on[4] == 1 and forced_on[3] <= big[3] // 2 and forced_on[0] == forced_on[3] - 2 * forced_on[2]
+    assert auto_big[:4] in (big[:4], forced_on[:4])
+    auto_small = f3d.plan_solve_piecemeal(planes_budget(40, 2048, 2048), 2048, 2048, 2048, 5, 40, 0, -1)
+    assert auto_small[4] == 0, "a budget of 40 planes cannot afford two sets"
