@@ -1192,6 +1192,21 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   if (nzc > max_chunks) nzc = max_chunks;
   if (nzc < 1) nzc = 1;
   int zchunk = static_cast<int>((planes + nzc - 1) / nzc);
+  // Small launches (up to 128^3) are bound by the latency of the serial march, ~1.35 us per plane step after ~6 us, not by
+  // bandwidth: there the chunk is the one that minimises rounds x (planes per chunk + 4.5), 512 workgroups running per
+  // round (64^3: 2-plane chunks, 11.3 -> 8.8 us per sweep; measured with tools/kbench.py, F3D_ZCHUNK sweeps).
+  const long tiles_xy = static_cast<long>(ntx) * nty;
+  if (tiles_xy * planes <= 4096) {
+    double best = -1.0;
+    for (int zc = 1; zc <= planes; ++zc) {
+      const long wgs = tiles_xy * ((planes + zc - 1) / zc);
+      const double cost = static_cast<double>((wgs + 511) / 512) * (zc + 4.5);
+      if (best < 0.0 || cost < best) {
+        best = cost;
+        zchunk = zc;
+      }
+    }
+  }
   if (t.zchunk > 0) zchunk = t.zchunk;
   const int nz = (planes + zchunk - 1) / zchunk;
   const int n_tiles = ntx * nty * nz;
@@ -1219,7 +1234,9 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
   // One workgroup per CU at a time (LDS, registers), so the chunking is chosen by a round model: a z-chunk costs its
   // planes plus ~6 steps of prologue and repeated stage-1 planes, and 256 workgroups run per round.
   const long tiles = static_cast<long>(ntx) * nty;
-  const int max_chunks = planes / 8 > 0 ? planes / 8 : 1;
+  // chunks of at least two planes: a coarse level is latency-bound and prefers many short marches (64^3: 2-plane chunks in
+  // one round, 28 -> 16 us per launch), a fine one never gets near the limit
+  const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
   int zchunk = planes;
   if (want_wg > 0) {  // experiments: aim at a workgroup count
     long nzc = (want_wg + tiles - 1) / tiles;
