@@ -13,7 +13,8 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(dst, exist_ok=True)
 bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)  # the directory keeps the files of earlier runs
+stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_bench512_rocprofv3_kernel_stats.csv"))
 lines = [f"# {tag}: rocprofv3 evidence for `python bench.py` (512^3, full default pyramid, 1x MI355X)", ""]
 lines += ["## bench line", "```json", json.dumps(bench), "```", ""]
@@ -30,7 +31,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not f:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         for name in ("k_sweep7", "k_sweep6", "k_phiksi6"):
             if name in r["Kernel_Name"]:
                 agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
