@@ -183,7 +183,7 @@ def run_multi(args):
     pkg.comm_init(box[0], rank, world, device=device)
 
     S = args.size
-    halo = 16
+    halo = 32  # room for four outer iterations per exchange on thin slabs (24 planes) plus the warp reach
     lo, hi = pkg.plan_owned(S, rank, world)
     zlo, zhi = max(0, lo - halo), min(S, hi + halo)
     if rank == 0:
@@ -243,7 +243,8 @@ def run_multi(args):
                                    "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
                                    "frames resident in HBM",
                        "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
-                                      "iteration (6 planes of du, dv, dw)"
+                                      "iteration (6 planes of du, dv, dw; thin slabs of small levels: 6n planes once per "
+                                      "n <= 4 outer iterations)"
                                       + (" -- REHEARSAL: shared-memory transport, ranks share devices"
                                          if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
             "roofline": {"bound": "hbm", "kernel": "k_sweep7 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "

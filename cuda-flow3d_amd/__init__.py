@@ -155,6 +155,7 @@ def host():
         "f3d_slabflow_compute_resident": [C.c_void_p, pp, _fp],
         "f3d_slabflow_download": [C.c_void_p, _fp, _fp, _fp],
         "f3d_slabflow_overlapped_iterations": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_slabflow_batched_exchanges": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_destroy": [C.c_void_p],
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
@@ -651,6 +652,12 @@ class SlabOpticalFlow:
     def overlapped_iterations(self):
         n = _sz()
         check(host().f3d_slabflow_overlapped_iterations(self._h, C.byref(n)))
+        return n.value
+
+    def batched_exchanges(self):
+        """groups of several outer iterations the last compute ran between two exchanges"""
+        n = _sz()
+        check(host().f3d_slabflow_batched_exchanges(self._h, C.byref(n)))
         return n.value
 
     def destroy(self):

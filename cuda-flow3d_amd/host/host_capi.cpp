@@ -471,6 +471,13 @@ int f3d_slabflow_overlapped_iterations(f3d_slabflow flow, size_t* count)
   return 0;
 }
 
+int f3d_slabflow_batched_exchanges(f3d_slabflow flow, size_t* count)
+{
+  if (!flow || !flow->driver || !count) return 1;
+  *count = flow->driver->BatchedExchanges();
+  return 0;
+}
+
 int f3d_slabflow_destroy(f3d_slabflow flow)
 {
   delete flow;

@@ -15,6 +15,9 @@ OpticalFlowSlab::OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int 
   // slabs at least this thick run the overlapped order (0 = never); thinner ones have too little interior to hide anything
   const char* e = std::getenv("F3D_OVERLAP_MIN_PLANES");
   overlap_min_planes_ = e ? std::atoi(e) : 32;
+  // thin slabs of small levels: several outer iterations per exchange (0 = the rule in Pyramid(), n = force n)
+  if (const char* f = std::getenv("F3D_SLAB_OUTER_PER_EXCHANGE")) forced_outer_per_exchange_ = std::atoi(f);
+  if (const char* f = std::getenv("F3D_SLAB_SMALL_LEVEL_VOXELS")) small_level_voxels_ = std::atof(f);
 }
 
 OpticalFlowSlab::~OpticalFlowSlab() { Destroy(); }
@@ -330,6 +333,7 @@ bool OpticalFlowSlab::ComputeResident(OperationParameters& params)
 bool OpticalFlowSlab::Pyramid(OperationParameters& params)
 {
   overlapped_iterations_ = 0;
+  batched_exchanges_ = 0;
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
   GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
@@ -461,7 +465,34 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     }
     if (locals_.size() == 1 && n_ranks_ > 1 && !Check(f3d_comm_allreduce_max_f32(&max_w))) return false;
     const int reach = static_cast<int>(std::ceil(max_w / hz)) + 1;
-    const int wide = K + 1;
+    // Outer iterations per exchange of the increments.  Thick slabs exchange after every outer iteration (K + 1 planes, hidden
+    // behind the interior where possible).  Thin slabs of a small level are latency-bound -- a launch costs the same with a
+    // few planes more, an exchange costs a fixed ~50 us -- so they take n (K + 1) planes at once and run n outer iterations
+    // on nested windows before the next exchange, like the out-of-core solver does per residency.  The rule uses only
+    // quantities every rank agrees on.
+    int n_ex = 1;
+    {
+      int min_slab = D, max_slab = 0;
+      for (int r = 0; r < n_ranks_; ++r) {
+        const int p = OwnedPlanes(D, r, n_ranks_).size();
+        min_slab = std::min(min_slab, p);
+        max_slab = std::max(max_slab, p);
+      }
+      const bool thick = overlap_min_planes_ > 0 && min_slab >= std::max(overlap_min_planes_, 4 * K + 4);
+      auto affordable = [&](int n) {
+        return n * (K + 1) + reach <= halo_ &&
+               static_cast<double>(W) * static_cast<double>(H) * (max_slab + 2 * n * (K + 1)) <= small_level_voxels_;
+      };
+      if (n_ranks_ > 1 && !thick)
+        for (int n = std::min<int>(max_outer_per_exchange_, static_cast<int>(outer_iterations_count)); n >= 2; --n)
+          if (affordable(n)) {
+            n_ex = n;
+            break;
+          }
+      if (forced_outer_per_exchange_ > 0)
+        n_ex = std::max(1, std::min(forced_outer_per_exchange_, std::min((halo_ - reach) / (K + 1), static_cast<int>(outer_iterations_count))));
+    }
+    const int wide = n_ex * (K + 1);
     if (!Exchange(D, W, H, {FU, FV, FW, F0R}, wide, wide)) return false;
     if (!Exchange(D, W, H, {F1R}, wide + reach, wide + reach)) return false;
 
@@ -472,47 +503,58 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       std::swap(l.buf[F1R], l.buf[TMP]);
     }
 
-    // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per outer iteration
+    // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per n_ex outer iterations
     for (Local& l : locals_)
       for (Role r : {DU, DV, DW})
         if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, W * sizeof(float), crows))) return false;
     // Overlapped order: one rank per process, a slab thick enough that zones and interior are distinct, and an exchange
     // to hide (not after the last outer iteration)
     const PlaneRange own_here = OwnedPlanes(D, locals_[0].rank, n_ranks_);
-    const bool can_overlap = locals_.size() == 1 && n_ranks_ > 1 && overlap_min_planes_ > 0 &&
+    const bool can_overlap = n_ex == 1 && locals_.size() == 1 && n_ranks_ > 1 && overlap_min_planes_ > 0 &&
                              own_here.size() >= std::max(overlap_min_planes_, 4 * K + 4) && (own_here.lo > 0 || own_here.hi < D);
-    for (size_t i = 0; i < outer_iterations_count; ++i) {
+    for (size_t i = 0; i < outer_iterations_count;) {
       if (can_overlap && i + 1 < outer_iterations_count) {
         if (!SweepsOverlapped(locals_[0], D, W, H, K, hx, hy, hz, equation_alpha, equation_smoothness, equation_data)) return false;
         ++overlapped_iterations_;
+        ++i;
         continue;
       }
+      const int n = static_cast<int>(std::min<size_t>(n_ex, outer_iterations_count - i));
       for (Local& l : locals_) {
-        const f3d_slab pw = Window(D, l.rank, K, K);
-        if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy,
-                               hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &pw)))
-          return false;
-        // sweep j runs on the slab widened by K-1-j planes; a fused pair (j, j+1) is launched on the window of sweep
-        // j+1 and computes sweep j on one plane more on either side by itself
-        for (int j = 0; j < K;) {
-          const bool pair = FusedSweepsEnabled() && j + 2 <= K;
-          const int shrink = K - 1 - j - (pair ? 1 : 0);
-          const f3d_slab sw = Window(D, l.rank, shrink, shrink);
-          const int status =
-              pair ? f3d_solve_sweep2(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
-                                      l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
-                                      l.buf[TDW], &sw)
-                   : f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
-                                     l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
-                                     l.buf[TDW], &sw);
-          if (!Check(status)) return false;
-          std::swap(l.buf[DU], l.buf[TDU]);
-          std::swap(l.buf[DV], l.buf[TDV]);
-          std::swap(l.buf[DW], l.buf[TDW]);
-          j += pair ? 2 : 1;
+        // iteration j of the n leaves the increments valid on the slab widened by g = (n-1-j)(K+1) planes
+        for (int j = 0; j < n; ++j) {
+          const int g = (n - 1 - j) * (K + 1);
+          const f3d_slab pw = Window(D, l.rank, g + K, g + K);
+          if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx,
+                                 hy, hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &pw)))
+            return false;
+          // sweep s runs on the slab widened by g + K-1-s planes; a fused pair (s, s+1) is launched on the window of
+          // sweep s+1 and computes sweep s on one plane more on either side by itself
+          for (int s = 0; s < K;) {
+            const bool pair = FusedSweepsEnabled() && s + 2 <= K;
+            const int shrink = g + K - 1 - s - (pair ? 1 : 0);
+            const f3d_slab sw = Window(D, l.rank, shrink, shrink);
+            const int status =
+                pair ? f3d_solve_sweep2(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
+                                        l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
+                                        l.buf[TDW], &sw)
+                     : f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
+                                       l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
+                                       l.buf[TDW], &sw);
+            if (!Check(status)) return false;
+            std::swap(l.buf[DU], l.buf[TDU]);
+            std::swap(l.buf[DV], l.buf[TDV]);
+            std::swap(l.buf[DW], l.buf[TDW]);
+            s += pair ? 2 : 1;
+          }
         }
       }
-      if (i + 1 < outer_iterations_count && !Exchange(D, W, H, {DU, DV, DW}, wide, wide)) return false;
+      i += n;
+      if (n > 1) ++batched_exchanges_;
+      if (i < outer_iterations_count) {
+        const int next = static_cast<int>(std::min<size_t>(n_ex, outer_iterations_count - i)) * (K + 1);
+        if (!Exchange(D, W, H, {DU, DV, DW}, next, next)) return false;
+      }
     }
 
     // flow += increment on the slab, then the median with its own halo

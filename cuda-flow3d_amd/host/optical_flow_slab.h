@@ -7,6 +7,7 @@
 //   * Halos are communication-avoiding: increments du, dv, dw are exchanged once per OUTER iteration, K + 1 planes
 //     deep (K = inner sweeps); sweep j then runs on the slab widened by K-1-j planes, phi/ksi on the slab widened
 //     by K.  The sweep is a Jacobi update, so the redundant planes reproduce the neighbour's values exactly.
+//     Thin slabs of small (latency-bound) levels go further: n (K + 1) planes once per n outer iterations, nested windows.
 //   * Per level: level-size halos of the two-pass-resampled frames and flows (z pass sources), K+1 planes of
 //     u, v, w, f0; K+1+reach planes of f1 for the warp (reach = ceil(max|w| / hz) + 1, one all-reduce(max));
 //     2 planes of u, v, w for the 5^3 median.
@@ -42,6 +43,8 @@ class OpticalFlowSlab : public OpticalFlowBase {
   bool failed() const { return failed_; }
   // outer iterations of the last solve that ran in the overlapped order (exchange beside the interior)
   size_t OverlappedIterations() const { return overlapped_iterations_; }
+  // groups of more than one outer iteration of the last solve that ran between two exchanges (thin slabs of small levels)
+  size_t BatchedExchanges() const { return batched_exchanges_; }
   DataSize4 FullSize() const { return full_size_; }
 
   bool silent = true;
@@ -83,6 +86,10 @@ class OpticalFlowSlab : public OpticalFlowBase {
   } unpack_;
   int overlap_min_planes_ = 0;
   size_t overlapped_iterations_ = 0;
+  size_t batched_exchanges_ = 0;
+  int forced_outer_per_exchange_ = 0;
+  int max_outer_per_exchange_ = 4;
+  double small_level_voxels_ = 1.5e6;  // slab + halos below this many voxels: launches are latency-bound
   bool failed_ = false;
   float last_device_seconds_ = 0.f;
   CudaOperationConvolution3D taps_;  // only for ComputeGaussianKernel (host arithmetic)

@@ -130,6 +130,9 @@ int f3d_slabflow_compute_resident(f3d_slabflow flow, const f3d_flow_params* para
 int f3d_slabflow_download(f3d_slabflow flow, float* u, float* v, float* w);
 /* outer iterations of the last solve whose halo exchange ran beside the interior of the slab (diagnostics) */
 int f3d_slabflow_overlapped_iterations(f3d_slabflow flow, size_t* count);
+/* groups of several outer iterations the last compute ran between two exchanges (thin slabs of small levels take
+ * n (K + 1) halo planes at once; F3D_SLAB_OUTER_PER_EXCHANGE=n forces n, 1 = one exchange per outer iteration) */
+int f3d_slabflow_batched_exchanges(f3d_slabflow flow, size_t* count);
 int f3d_slabflow_destroy(f3d_slabflow flow);
 
 /* the decomposition plan (pure host arithmetic, usable without a device) */

@@ -18,13 +18,40 @@ def single(f3d, f0, f1, **kw):
     return out
 
 
-def slabbed(f3d, f0, f1, n_ranks, **kw):
+def slabbed(f3d, f0, f1, n_ranks, halo_capacity=16, counters=None, **kw):
     d, h, w = f0.shape
-    flow = f3d.SlabOpticalFlow(n_ranks, list(range(n_ranks)))
+    flow = f3d.SlabOpticalFlow(n_ranks, list(range(n_ranks)), halo_capacity=halo_capacity)
     flow.initialize(w, h, d)
     out = flow.compute(f0, f1, **kw)
+    if counters is not None:
+        counters["batched"] = flow.batched_exchanges()
     flow.destroy()
     return out
+
+
+@pytest.mark.parametrize("forced,halo,n_ranks", [("1", 16, 4), ("", 16, 4), ("", 32, 8), ("4", 32, 3), ("3", 40, 8)])
+def test_outer_iterations_per_exchange(f3d, monkeypatch, forced, halo, n_ranks):
+    """Thin slabs of small levels take n (K + 1) halo planes at once and run n outer iterations between exchanges, on nested
+    windows: forced to 1 (the plain order), chosen by the rule, forced to 3 and 4 -- always the single-GPU bits."""
+    if forced:
+        monkeypatch.setenv("F3D_SLAB_OUTER_PER_EXCHANGE", forced)
+    else:
+        monkeypatch.delenv("F3D_SLAB_OUTER_PER_EXCHANGE", raising=False)
+    f0, f1 = f3d.synth_pair(44, 36, 50)
+    kw = dict(warp_levels_count=12, outer_iterations_count=7)
+    exp = single(f3d, f0, f1, **kw)
+    c = {}
+    got = slabbed(f3d, f0, f1, n_ranks, halo_capacity=halo, counters=c, **kw)
+    for g, e, n in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} slabs, forced={forced!r}: component {n} differs, max {np.abs(g - e).max():.3e}"
+    if forced == "1":
+        assert c["batched"] == 0
+    elif forced == "4":
+        assert c["batched"] == 12 * 2          # 7 outer iterations = 4 + 3 on every level
+    elif forced == "3":
+        assert c["batched"] == 12 * 2          # 3 + 3 + 1: two groups of more than one
+    else:
+        assert c["batched"] > 0
 
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
