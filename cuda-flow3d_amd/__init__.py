@@ -166,7 +166,7 @@ def host():
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
-        "f3d_pflow_set_resident": [C.c_void_p, C.c_int],
+        "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
@@ -550,6 +550,12 @@ class PiecemealOpticalFlow:
         t = (C.c_double * 6)()
         check(host().f3d_pflow_operator_seconds(self._h, t), "f3d_pflow_operator_seconds")
         return dict(zip(("frames", "flow_resample", "registration", "solve", "add", "resident_levels"), t))
+
+    def originals_on_device(self):
+        """True when the resident levels of the last compute read the original frames from device copies"""
+        y = C.c_int()
+        check(host().f3d_pflow_originals_on_device(self._h, C.byref(y)), "f3d_pflow_originals_on_device")
+        return bool(y.value)
 
     def set_resident(self, enabled):
         """coarse levels that fit the budget stay on the device (default) or every level goes through the host"""

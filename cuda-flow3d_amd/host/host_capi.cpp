@@ -281,6 +281,13 @@ int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_level
   return 0;
 }
 
+int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes)
+{
+  if (!flow || !yes) return 1;
+  *yes = flow->driver.LastOriginalsOnDevice() ? 1 : 0;
+  return 0;
+}
+
 int f3d_pflow_set_resident(f3d_pflow flow, int enabled)
 {
   if (!flow) return 1;

@@ -379,7 +379,7 @@ void CudaOperationResampleP::Execute(OperationParameters& params)
     std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
     return;
   }
-  Run(input, data_size, resample_size, output_ptr, 0, 0, 0);
+  Run(&input, 0, 0, 0, data_size, resample_size, output_ptr, 0, 0, 0);
 }
 
 bool CudaOperationResampleP::ExecuteToDevice(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, DevicePtr dst,
@@ -390,11 +390,23 @@ bool CudaOperationResampleP::ExecuteToDevice(Data3D& input, const DataSize4& dat
     std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
     return false;
   }
-  return Run(input, data_size, resample_size, nullptr, dst, dst_pitch, dst_rows);
+  return Run(&input, 0, 0, 0, data_size, resample_size, nullptr, dst, dst_pitch, dst_rows);
 }
 
-bool CudaOperationResampleP::Run(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, Data3D* output, DevicePtr dst,
-                                 size_t dst_pitch, size_t dst_rows)
+bool CudaOperationResampleP::ExecuteDeviceToDevice(DevicePtr src, size_t src_pitch, size_t src_rows, const DataSize4& data_size,
+                                                   const DataSize4& resample_size, DevicePtr dst, size_t dst_pitch, size_t dst_rows)
+{
+  if (!IsInitialized()) return false;
+  if (!src || !dst || data_size.height > src_rows || data_size.width * sizeof(float) > src_pitch || resample_size.height > dst_rows ||
+      resample_size.width * sizeof(float) > dst_pitch) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return false;
+  }
+  return Run(nullptr, src, src_pitch, src_rows, data_size, resample_size, nullptr, dst, dst_pitch, dst_rows);
+}
+
+bool CudaOperationResampleP::Run(Data3D* input, DevicePtr src_dev, size_t src_pitch, size_t src_rows, const DataSize4& data_size,
+                                 const DataSize4& resample_size, Data3D* output, DevicePtr dst, size_t dst_pitch, size_t dst_rows)
 {
   const size_t Wi = data_size.width, Hi = data_size.height, Wo = resample_size.width, Ho = resample_size.height;
   const int Di = static_cast<int>(data_size.depth), Do = static_cast<int>(resample_size.depth);
@@ -441,7 +453,11 @@ bool CudaOperationResampleP::Run(Data3D& input, const DataSize4& data_size, cons
     const int z0 = (descending ? n_chunks - 1 - k : k) * chunk, z1 = std::min(Do, z0 + chunk);
     const PlaneRange src = source_of(z0, z1);
     const f3d_slab in_slab = {src.lo, src.lo, src.hi}, out_slab = {z0, z0, z1};
-    if (!Upload(buf[0], box, 0, input, Wi, Hi, src.lo, src.size())) return false;
+    if (input) {
+      if (!Upload(buf[0], box, 0, *input, Wi, Hi, src.lo, src.size())) return false;
+    } else if (CheckDeviceError(f3d_copy_rect_d2d(buf[0], box.pitch, box.H, 0, src_dev, src_pitch, src_rows, src.lo, Wi, Hi, src.size()))) {
+      return false;
+    }
     if (CheckDeviceError(f3d_resample_x(buf[0], buf[1], Wo, Hi, Di, Wi, &in_slab))) return false;
     if (CheckDeviceError(f3d_resample_y(buf[1], buf[2], Wo, Ho, Di, Hi, &in_slab))) return false;
     if (CheckDeviceError(f3d_resample_z(buf[2], buf[3], Wo, Ho, Do, Di, &in_slab, &out_slab))) return false;

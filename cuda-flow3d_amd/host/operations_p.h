@@ -70,10 +70,14 @@ class CudaOperationResampleP : public CudaOperationPiecemealBase {
   // dst_rows rows of dst_pitch bytes) instead of a host volume.
   bool ExecuteToDevice(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, DevicePtr dst, size_t dst_pitch,
                        size_t dst_rows);
+  // ... and with the source on the device as well (a container of src_rows rows of src_pitch bytes per plane): the chunked
+  // passes keep the working set small, nothing crosses the link.
+  bool ExecuteDeviceToDevice(DevicePtr src, size_t src_pitch, size_t src_rows, const DataSize4& data_size, const DataSize4& resample_size,
+                             DevicePtr dst, size_t dst_pitch, size_t dst_rows);
 
  private:
-  bool Run(Data3D& input, const DataSize4& data_size, const DataSize4& resample_size, Data3D* output, DevicePtr dst, size_t dst_pitch,
-           size_t dst_rows);
+  bool Run(Data3D* input, DevicePtr src, size_t src_pitch, size_t src_rows, const DataSize4& data_size, const DataSize4& resample_size,
+           Data3D* output, DevicePtr dst, size_t dst_pitch, size_t dst_rows);
 };
 
 // backward trilinear warp of frame_1; the result is written to `temp` and the two volumes are swapped, like the reference

@@ -131,22 +131,48 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       const size_t pitch = (s.width * sizeof(float) + 255) / 256 * 256;
       return pitch * s.height * s.depth + 66048;  // + what f3d_alloc_pitched adds for alignment and stagger
     };
-    auto fits = [&](int level) {
-      const size_t need = 14 * container_bytes(level);
-      const size_t stream = level == 0 && current_warp_level == 0 ? 0 : PiecemealMinResampleBytes(W0, H0);
+    const size_t originals_bytes = 2 * (((W0 * sizeof(float) + 255) / 256 * 256) * H0 * D0 + 66048);
+    auto fits = [&](int level, bool with_originals) {
+      const size_t need = 14 * container_bytes(level) + (with_originals ? originals_bytes : 0);
+      const size_t stream = level == 0 && current_warp_level == 0 && !with_originals ? 0 : PiecemealMinResampleBytes(W0, H0);
       return need <= static_cast<size_t>(0.85 * static_cast<double>(budget)) && need + stream <= budget;
     };
-    int last = current_warp_level + 1;
-    while (last > 0 && fits(last - 1)) --last;
+    auto last_resident = [&](bool with_originals) {
+      int last = current_warp_level + 1;
+      while (last > 0 && fits(last - 1, with_originals)) --last;
+      return last;
+    };
+    // Two ways to spend the budget: more resident levels with both original frames streamed through for every one of them
+    // (8 B per original voxel and level over the link), or the originals kept on the device beside somewhat fewer resident
+    // levels (the levels given up go through the host: ~144 B per voxel of theirs).  Link bytes decide.
+    const int last_plain = last_resident(false), last_with = last_resident(true);
+    bool keep_originals = false;
+    int last = last_plain;
+    if (last_with <= current_warp_level) {
+      const double n0 = static_cast<double>(W0) * static_cast<double>(H0) * static_cast<double>(D0);
+      double given_up = 0.0;
+      for (int l = last_plain; l < last_with; ++l) {
+        const DataSize4 sz = GetLevel(original_data_size, warp_scale_factor, l).size;
+        given_up += 144.0 * static_cast<double>(sz.width) * static_cast<double>(sz.height) * static_cast<double>(sz.depth);
+      }
+      const double streamed = 8.0 * n0 * (current_warp_level - last_plain + 1);
+      if (given_up + 8.0 * n0 < streamed) {
+        keep_originals = true;
+        last = last_with;
+      }
+    }
+    originals_on_device_ = false;
     if (last <= current_warp_level) {
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, current_warp_level, last, container_bytes(last));
+      const bool ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, current_warp_level, last, container_bytes(last),
+                                        keep_originals);
       op_seconds_[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (!ok) {
         std::printf("'%s': Error in the resident levels.\n", GetName());
         finish();
         return;
       }
+      originals_on_device_ = keep_originals;
       resident_levels_ = static_cast<size_t>(current_warp_level - last + 1);
       prev_data_size = GetLevel(original_data_size, warp_scale_factor, last).size;
       current_warp_level = last - 1;
@@ -307,7 +333,8 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 }
 
 bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
-                                     OperationParameters& params, int first_level, int last_level, size_t container_bytes)
+                                     OperationParameters& params, int first_level, int last_level, size_t container_bytes,
+                                     bool originals_on_device)
 {
   size_t outer_iterations_count, inner_iterations_count;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data;
@@ -330,10 +357,27 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
     ok = !CheckDeviceError(f3d_alloc_pitched(&buf[i], &pitch, container.width * sizeof(float), rows));
     container.pitch = pitch;
   }
-  PiecemealSetReservedBytes(kBuffers * container_bytes);
+  // the two original frames on the device, in their own geometry, when the caller found room for them
+  DevicePtr orig[2] = {0, 0};
+  size_t orig_pitch = 0;
+  size_t reserved = kBuffers * container_bytes;
+  if (ok && originals_on_device) {
+    Data3D* frames[2] = {&frame_0, &frame_1};
+    for (int i = 0; i < 2 && ok; ++i) {
+      ok = !CheckDeviceError(f3d_alloc_pitched(&orig[i], &orig_pitch, original.width * sizeof(float), original.height * original.depth)) &&
+           !CheckDeviceError(f3d_copy_planes_h2d(orig[i], orig_pitch, original.height, 0, frames[i]->DataPtr(), original.width,
+                                                 original.height, original.width, original.height, original.depth));
+      reserved += orig_pitch * original.height * original.depth + 66048;
+    }
+  }
+  PiecemealSetReservedBytes(reserved);
   auto release = [&]() {
     f3d_stream_sync();
     for (DevicePtr& p : buf) {
+      if (p) CheckDeviceError(f3d_free(p));
+      p = 0;
+    }
+    for (DevicePtr& p : orig) {
       if (p) CheckDeviceError(f3d_free(p));
       p = 0;
     }
@@ -359,11 +403,21 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
       std::printf("Solve level %2d (%4zu x%4zu x%4zu) on the device\n", level, current.width, current.height, current.depth);
 
     // frames of this level straight into device containers
-    if (level == 0) {
+    if (level == 0 && originals_on_device) {
+      ok = !CheckDeviceError(f3d_copy_rect_d2d(buf[F0R], container.pitch, container.height, 0, orig[0], orig_pitch, original.height, 0,
+                                               original.width, original.height, original.depth)) &&
+           !CheckDeviceError(f3d_copy_rect_d2d(buf[F1R], container.pitch, container.height, 0, orig[1], orig_pitch, original.height, 0,
+                                               original.width, original.height, original.depth));
+    } else if (level == 0) {
       ok = !CheckDeviceError(f3d_copy_planes_h2d(buf[F0R], container.pitch, container.height, 0, frame_0.DataPtr(), original.width,
                                                  original.height, original.width, original.height, original.depth)) &&
            !CheckDeviceError(f3d_copy_planes_h2d(buf[F1R], container.pitch, container.height, 0, frame_1.DataPtr(), original.width,
                                                  original.height, original.width, original.height, original.depth));
+    } else if (originals_on_device) {
+      ok = cuop_resample_p_.ExecuteDeviceToDevice(orig[0], orig_pitch, original.height, original, current, buf[F0R], container.pitch,
+                                                  container.height) &&
+           cuop_resample_p_.ExecuteDeviceToDevice(orig[1], orig_pitch, original.height, original, current, buf[F1R], container.pitch,
+                                                  container.height);
     } else {
       ok = cuop_resample_p_.ExecuteToDevice(frame_0, original, current, buf[F0R], container.pitch, container.height) &&
            cuop_resample_p_.ExecuteToDevice(frame_1, original, current, buf[F1R], container.pitch, container.height);

@@ -32,6 +32,8 @@ class OpticalFlowP : public OpticalFlowBase {
   size_t LastStreamedLevels() const { return streamed_levels_; }
   // coarse levels of the last ComputeFlow that ran entirely on the device (see resident_coarse_levels)
   size_t LastResidentLevels() const { return resident_levels_; }
+  // whether those levels resampled their frames from device copies of the two originals (they fitted beside the working set)
+  bool LastOriginalsOnDevice() const { return originals_on_device_; }
   // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add} of the levels that
   // went through the host, and in the resident coarse levels as a whole
   const double* LastOperatorSeconds() const { return op_seconds_; }
@@ -46,9 +48,10 @@ class OpticalFlowP : public OpticalFlowBase {
   float last_device_seconds_ = 0.f;
   // levels first_level .. last_level (descending) on the device; false on a device error
   bool RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w, OperationParameters& params,
-                         int first_level, int last_level, size_t container_bytes);
+                         int first_level, int last_level, size_t container_bytes, bool originals_on_device);
 
   size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0;
+  bool originals_on_device_ = false;
   double op_seconds_[6] = {0, 0, 0, 0, 0, 0};
 
   // "entire data" operators for the resident coarse levels (not in the list Initialize prints: the reference's piecemeal

@@ -91,6 +91,8 @@ int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1
                       const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds);
 /* of the last compute: solver residencies, levels cut into chunks, coarse levels that ran wholly on the device */
 int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels, size_t* resident_levels);
+/* whether the resident levels of the last compute resampled their frames from device copies of the two originals */
+int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes);
 /* coarse levels whose working set fits the budget stay on the device (default on; F3D_P_RESIDENT=0 also turns it off) */
 int f3d_pflow_set_resident(f3d_pflow flow, int enabled);
 /* wall seconds of the last compute in {frame resample, flow resample, registration, solve, add} of the levels that went

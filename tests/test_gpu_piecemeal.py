@@ -214,6 +214,7 @@ def run_p(f3d, f0, f1, resident=True, **kw):
     flow.set_resident(resident)
     try:
         out = flow.compute(f0, f1, silent=True, **kw)
+        run_p.originals_on_device = flow.originals_on_device()
         return out, flow.stats()
     finally:
         flow.destroy()
@@ -230,6 +231,7 @@ def test_driver_matches_oracle_small(f3d, oracle):
         got, (passes, streamed, on_device) = run_p(f3d, f0, f1, resident=resident)
         assert streamed >= 1 and passes > levels
         assert (on_device >= 10) if resident else (on_device == 0)
+        assert resident or not run_p.originals_on_device
         assert on_device + streamed <= levels
         for g, e, n in zip(got, exp, "uvw"):
             assert same(g, e), f"resident={resident} {n}: max diff {np.abs(g - e).max()}"
@@ -237,9 +239,19 @@ def test_driver_matches_oracle_small(f3d, oracle):
     # a budget that holds everything: all levels on the device, the originals uploaded once for level 0
     set_budget(64.0)
     got, (passes, streamed, on_device) = run_p(f3d, f0, f1)
-    assert (streamed, on_device, passes) == (0, levels, levels)
+    assert (streamed, on_device, passes) == (0, levels, levels) and run_p.originals_on_device
     for g, e in zip(got, exp):
         assert same(g, e)
+    # budgets in between: whichever way the driver splits them between resident levels and device copies of the originals
+    seen = set()
+    for planes in (14, 18, 22, 30, 40):
+        set_budget(budget_for(13 * planes, 40, 36, 13))
+        got, (passes, streamed, on_device) = run_p(f3d, f0, f1)
+        seen.add(run_p.originals_on_device)
+        assert on_device < levels
+        for g, e in zip(got, exp):
+            assert same(g, e), f"{planes} planes per field"
+    assert seen == {False, True}, "the sweep of budgets should exercise both ways of fetching the frames"
 
 
 def test_driver_matches_resident_driver(f3d):
