@@ -142,37 +142,32 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       while (last > 0 && fits(last - 1, with_originals)) --last;
       return last;
     };
-    // Two ways to spend the budget: more resident levels with both original frames streamed through for every one of them
-    // (8 B per original voxel and level over the link), or the originals kept on the device beside somewhat fewer resident
-    // levels (the levels given up go through the host: ~144 B per voxel of theirs).  Link bytes decide.
+    // The coarsest levels leave room for device copies of the two original frames beside their working set: those levels
+    // resample from the copies (phase A).  Finer levels that still fit without the copies follow with the originals streamed
+    // through for each of them (phase B, 8 B per original voxel and level over the link); the flow crosses between the two
+    // phases through the host, three small sub-boxes.
     const int last_plain = last_resident(false), last_with = last_resident(true);
-    bool keep_originals = false;
-    int last = last_plain;
-    if (last_with <= current_warp_level) {
-      const double n0 = static_cast<double>(W0) * static_cast<double>(H0) * static_cast<double>(D0);
-      double given_up = 0.0;
-      for (int l = last_plain; l < last_with; ++l) {
-        const DataSize4 sz = GetLevel(original_data_size, warp_scale_factor, l).size;
-        given_up += 144.0 * static_cast<double>(sz.width) * static_cast<double>(sz.height) * static_cast<double>(sz.depth);
-      }
-      const double streamed = 8.0 * n0 * (current_warp_level - last_plain + 1);
-      if (given_up + 8.0 * n0 < streamed) {
-        keep_originals = true;
-        last = last_with;
-      }
-    }
+    const int last = last_plain;
     originals_on_device_ = false;
     if (last <= current_warp_level) {
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, current_warp_level, last, container_bytes(last),
-                                        keep_originals);
+      bool ok = true;
+      DataSize4 carried = {0, 0, 0, 0};
+      int next = current_warp_level;
+      if (last_with <= next) {
+        ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, next, last_with, container_bytes(last_with), true, carried);
+        originals_on_device_ = true;
+        carried = GetLevel(original_data_size, warp_scale_factor, last_with).size;
+        next = last_with - 1;
+      }
+      if (ok && last <= next)
+        ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, next, last, container_bytes(last), false, carried);
       op_seconds_[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (!ok) {
         std::printf("'%s': Error in the resident levels.\n", GetName());
         finish();
         return;
       }
-      originals_on_device_ = keep_originals;
       resident_levels_ = static_cast<size_t>(current_warp_level - last + 1);
       prev_data_size = GetLevel(original_data_size, warp_scale_factor, last).size;
       current_warp_level = last - 1;
@@ -334,7 +329,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 
 bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
                                      OperationParameters& params, int first_level, int last_level, size_t container_bytes,
-                                     bool originals_on_device)
+                                     bool originals_on_device, const DataSize4& carried_flow_size)
 {
   size_t outer_iterations_count, inner_iterations_count;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data;
@@ -394,7 +389,13 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
     ok = cuop->Initialize(&init) && ok;
 
   OperationParameters op;
-  DataSize4 prev = {0, 0, 0, 0};
+  DataSize4 prev = carried_flow_size;
+  if (ok && prev.width != 0) {  // the flow an earlier phase left in the host volumes' sub-box
+    Data3D* flows[3] = {&flow_u, &flow_v, &flow_w};
+    for (int i = 0; i < 3 && ok; ++i)
+      ok = !CheckDeviceError(f3d_copy_planes_h2d(buf[FU + i], container.pitch, container.height, 0, flows[i]->DataPtr(), flows[i]->Width(),
+                                                 flows[i]->Height(), prev.width, prev.height, prev.depth));
+  }
   for (int level = first_level; level >= last_level && ok; --level) {
     const PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
     DataSize4 current = lv.size;

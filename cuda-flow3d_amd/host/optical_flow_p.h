@@ -32,7 +32,7 @@ class OpticalFlowP : public OpticalFlowBase {
   size_t LastStreamedLevels() const { return streamed_levels_; }
   // coarse levels of the last ComputeFlow that ran entirely on the device (see resident_coarse_levels)
   size_t LastResidentLevels() const { return resident_levels_; }
-  // whether those levels resampled their frames from device copies of the two originals (they fitted beside the working set)
+  // whether the coarsest of those levels resampled their frames from device copies of the two originals (phase A)
   bool LastOriginalsOnDevice() const { return originals_on_device_; }
   // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add} of the levels that
   // went through the host, and in the resident coarse levels as a whole
@@ -48,7 +48,8 @@ class OpticalFlowP : public OpticalFlowBase {
   float last_device_seconds_ = 0.f;
   // levels first_level .. last_level (descending) on the device; false on a device error
   bool RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w, OperationParameters& params,
-                         int first_level, int last_level, size_t container_bytes, bool originals_on_device);
+                         int first_level, int last_level, size_t container_bytes, bool originals_on_device,
+                         const DataSize4& carried_flow_size);
 
   size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0;
   bool originals_on_device_ = false;

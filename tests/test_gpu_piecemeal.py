@@ -242,16 +242,17 @@ def test_driver_matches_oracle_small(f3d, oracle):
     assert (streamed, on_device, passes) == (0, levels, levels) and run_p.originals_on_device
     for g, e in zip(got, exp):
         assert same(g, e)
-    # budgets in between: whichever way the driver splits them between resident levels and device copies of the originals
+    # budgets in between: the coarsest levels beside device copies of the originals, then levels with the originals streamed,
+    # then levels through the host -- wherever the boundaries fall
     seen = set()
     for planes in (14, 18, 22, 30, 40):
         set_budget(budget_for(13 * planes, 40, 36, 13))
         got, (passes, streamed, on_device) = run_p(f3d, f0, f1)
         seen.add(run_p.originals_on_device)
-        assert on_device < levels
+        assert 0 < on_device < levels
         for g, e in zip(got, exp):
             assert same(g, e), f"{planes} planes per field"
-    assert seen == {False, True}, "the sweep of budgets should exercise both ways of fetching the frames"
+    assert seen == {False, True}, "the budgets should cover levels with and without device copies of the originals"
 
 
 def test_driver_matches_resident_driver(f3d):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true")
     ap.add_argument("--all-through-host", action="store_true", help="no resident coarse levels in the piecemeal driver")
     ap.add_argument("--check", action="store_true", help="compare the two results bit for bit")
+    ap.add_argument("--verbose", action="store_true", help="the driver's own log (levels, chunk plans)")
     a = ap.parse_args()
     pkg = importlib.import_module("cuda-flow3d_amd")
     n = a.size
@@ -49,7 +50,7 @@ def main():
     flow.initialize(n, n, n)
     flow.set_resident(not a.all_through_host)
     t0 = time.time()
-    got = flow.compute(f0, f1, silent=True, **kw)
+    got = flow.compute(f0, f1, silent=not a.verbose, **kw)
     wall = time.time() - t0
     passes, streamed, on_device = flow.stats()
     print(f"piecemeal: {flow.device_seconds:8.3f} s ({wall:.3f} s wall with host allocation and page-locking)  "
