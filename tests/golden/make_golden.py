@@ -7,6 +7,8 @@ Expected: outputs of the CPU oracle (oracle/f3d_oracle.c) on those inputs.  The 
           be re-run at inside a quick test, and detect drift of either side.
 
   python tests/golden/make_golden.py            # ~5 minutes on 8 cores
+  python tests/golden/make_golden.py --piecemeal   # only expected_piecemeal.npz (seconds): the two crops through the pipeline
+                                                   # of the reference's piecemeal driver (no pre-blur, no median)
 """
 import hashlib
 import os
@@ -38,7 +40,28 @@ def digest(*vols):
     return h.hexdigest()
 
 
+def piecemeal_only():
+    """The out-of-core driver's semantics (src/optical_flow/optical_flow_p.cpp: no Gaussian, median commented out) on the
+    two crops of the whole-pipeline fixtures; inputs come from the committed inputs_*.npz."""
+    i128 = np.load(os.path.join(HERE, "inputs_128.npz"))
+    irub = np.load(os.path.join(HERE, "inputs_rub.npz"))
+    F0, F1 = i128["frame_0"].astype(np.float32), i128["frame_1"].astype(np.float32)
+    R0 = np.repeat(irub["slice_0"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    R1 = np.repeat(irub["slice_1"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    out = {}
+    crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+    (u, v, w), lv = orc.compute_flow(F0[crop].copy(), F1[crop].copy(), gaussian_sigma=0.0, median_radius=1)
+    out.update(crop128_flow=np.stack([u, v, w]), crop128_levels=lv)
+    rc = (slice(0, 5), slice(100, 164), slice(200, 296))
+    (u, v, w), lv = orc.compute_flow(R0[rc].copy(), R1[rc].copy(), gaussian_sigma=0.0, median_radius=1)
+    out.update(croprub_flow=np.stack([u, v, w]), croprub_levels=lv)
+    np.savez_compressed(os.path.join(HERE, "expected_piecemeal.npz"), **out)
+    print("piecemeal crops done", out["crop128_levels"], out["croprub_levels"])
+
+
 def main():
+    if "--piecemeal" in sys.argv:
+        return piecemeal_only()
     f0 = load_u8("frame_0_128-128-128.raw", (128, 128, 128))
     f1 = load_u8("frame_1_128-128-128.raw", (128, 128, 128))
     r0 = load_u8("rub1-584-388-5.raw", (5, 388, 584))

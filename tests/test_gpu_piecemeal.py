@@ -255,6 +255,31 @@ def test_driver_matches_oracle_small(f3d, oracle):
     assert seen == {False, True}, "the budgets should cover levels with and without device copies of the originals"
 
 
+def test_driver_matches_golden_crops(f3d):
+    """The committed piecemeal fixtures (tests/golden/expected_piecemeal.npz: oracle, no blur, no median) on the crops of the
+    reference's data volumes, with a budget that puts the finest levels through chunks; the thin 96x64x5 crop runs with
+    chunks of single planes' worth of halo."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    e = np.load(os.path.join(gold, "expected_piecemeal.npz"))
+    i128 = np.load(os.path.join(gold, "inputs_128.npz"))
+    irub = np.load(os.path.join(gold, "inputs_rub.npz"))
+    crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+    f0 = i128["frame_0"].astype(np.float32)[crop].copy()
+    f1 = i128["frame_1"].astype(np.float32)[crop].copy()
+    set_budget(budget_for(13 * 20, 48, 40, 13))
+    got, (passes, streamed, on_device) = run_p(f3d, f0, f1)
+    assert streamed >= 1 and on_device >= 1
+    for g, x, n in zip(got, e["crop128_flow"], "uvw"):
+        assert same(g, x), f"crop128 {n}: max diff {np.abs(g - x).max()}"
+    rc = (slice(0, 5), slice(100, 164), slice(200, 296))
+    r0 = np.repeat(irub["slice_0"][None], int(irub["depth"]), axis=0).astype(np.float32)[rc].copy()
+    r1 = np.repeat(irub["slice_1"][None], int(irub["depth"]), axis=0).astype(np.float32)[rc].copy()
+    set_budget(64.0)
+    got, _ = run_p(f3d, r0, r1)
+    for g, x, n in zip(got, e["croprub_flow"], "uvw"):
+        assert same(g, x), f"croprub {n}: max diff {np.abs(g - x).max()}"
+
+
 def test_driver_matches_resident_driver(f3d):
     """120^3 default schedule: streamed (about 1/3 of the level resident at a time) vs everything resident, no blur/median."""
     n = 120
