@@ -82,6 +82,7 @@ def hip():
         "f3d_copy_planes_d2h_on": [C.c_void_p, _fp, _sz, _sz, _sz, _sz, _sz, _dp, _sz, _sz, _sz],
         "f3d_copy_rect_d2d": [_dp, _sz, _sz, _sz, _dp, _sz, _sz, _sz, _sz, _sz, _sz],
         "f3d_host_register": [C.c_void_p, _sz], "f3d_host_unregister": [C.c_void_p],
+        "f3d_host_is_pinned": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_copy_d2d": [_dp, _dp, _sz], "f3d_set_container": [C.POINTER(Size4)], "f3d_get_container": [C.POINTER(Size4)],
         "f3d_event_create": [C.POINTER(C.c_void_p)], "f3d_event_record": [C.c_void_p],
         "f3d_event_sync": [C.c_void_p], "f3d_event_elapsed_ms": [_fp, C.c_void_p, C.c_void_p],
@@ -364,7 +365,7 @@ class HostVolume:
     the current storage up among all wrapped arrays."""
     _storage = {}
 
-    def __init__(self, array):
+    def __init__(self, array, pin=False):
         a = np.ascontiguousarray(array, dtype=np.float32)
         if a.ndim != 3:
             raise ValueError("volume must be [z, y, x]")
@@ -373,6 +374,11 @@ class HostVolume:
         check(host().f3d_volume_wrap(C.byref(self._h), a.ctypes.data_as(_fp), w, h, d), "f3d_volume_wrap")
         HostVolume._storage[a.ctypes.data] = a
         self._first = a.ctypes.data
+        self._pinned = False
+        if pin:  # page-locked: full link rate, and a precondition of the solver's overlapped schedule
+            check(hip().f3d_init(-1), "f3d_init")
+            check(hip().f3d_host_register(C.c_void_p(self._first), a.nbytes), "f3d_host_register")
+            self._pinned = True
 
     @property
     def object(self):
@@ -386,6 +392,9 @@ class HostVolume:
         if self._h:
             host().f3d_volume_destroy(self._h)
             self._h = C.c_void_p()
+            if self._pinned:
+                hip().f3d_host_unregister(C.c_void_p(self._first))
+                self._pinned = False
             HostVolume._storage.pop(self._first, None)
 
 

@@ -402,6 +402,21 @@ int f3d_host_register(void* ptr, size_t bytes)
   return 0;
 }
 
+int f3d_host_is_pinned(const void* ptr, int* yes)
+{
+  F3D_REQUIRE_READY("f3d_host_is_pinned");
+  if (!ptr || !yes) return f3d::fail("f3d_host_is_pinned: null argument");
+  hipPointerAttribute_t attr;
+  const hipError_t r = hipPointerGetAttributes(&attr, ptr);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();  // ordinary pageable memory is not an error for the caller
+    *yes = 0;
+    return 0;
+  }
+  *yes = attr.type == hipMemoryTypeHost ? 1 : 0;
+  return 0;
+}
+
 int f3d_host_unregister(void* ptr)
 {
   F3D_REQUIRE_READY("f3d_host_unregister");

@@ -38,8 +38,11 @@ struct Pipeline {
   bool ready = false;
 } g_pipe;
 
+void ReleaseAtExit();
+
 bool PipelineReady()
 {
+  ReleaseAtExit();
   if (g_pipe.ready) return true;
   bool ok = !CheckDeviceError(f3d_queue_create(&g_pipe.up)) && !CheckDeviceError(f3d_queue_create(&g_pipe.down));
   for (int i = 0; i < 2 && ok; ++i)
@@ -71,8 +74,17 @@ void ArenaFree()
   g_arena.bytes = 0;
 }
 
+// The arena, the copy queues and their events are released before the process tears the HIP runtime down (an exit handler
+// registered at first use runs before the destructors of libraries loaded earlier), not left to whatever order that takes.
+void ReleaseAtExit()
+{
+  static const bool registered = (std::atexit([] { PiecemealReleaseArena(); }), true);
+  (void)registered;
+}
+
 DevicePtr ArenaReserve(size_t bytes)
 {
+  ReleaseAtExit();
   if (bytes <= g_arena.bytes) return g_arena.base;
   ArenaFree();
   size_t pitch = 0;
@@ -611,6 +623,14 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   int forced = 0, overlap_mode = -1;
   if (const char* e = std::getenv("F3D_P_OUTER_PER_PASS")) forced = std::atoi(e);
   if (const char* e = std::getenv("F3D_P_OVERLAP")) overlap_mode = std::atoi(e);
+  // Copies beside the kernels only from page-locked volumes: from pageable memory the runtime stages every copy through
+  // its own buffers and blocks the caller, which serialises the three queues anyway.
+  bool all_pinned = true;
+  for (Data3D* v : {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w, p_flow_du, p_flow_dv, p_flow_dw, p_temp_du, p_temp_dv, p_temp_dw}) {
+    int yes = 0;
+    if (f3d_host_is_pinned(v->DataPtr(), &yes) != 0 || !yes) all_pinned = false;
+  }
+  if (!all_pinned) overlap_mode = 0;
   SolvePiecemealPlan plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode);
   if (plan.overlapped && !PipelineReady()) plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0);
   last_plan_ = plan;

@@ -91,7 +91,8 @@ class CudaOperationRegistrationP : public CudaOperationPiecemealBase {
 // lagged-nonlinearity solver on host volumes.  keys: frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw,
 // temp_du, temp_dv, temp_dw (Data3D*), outer_iterations_count, inner_iterations_count, equation_alpha,
 // equation_smoothness, equation_data, hx, hy, hz, data_size.  "phi" and "ksi" are accepted and ignored: the
-// nonlinearities stay on the device.  The name string keeps the reference's spelling.
+// nonlinearities stay on the device.  The name string keeps the reference's spelling.  The overlapped schedule (copies beside
+// the kernels) is only considered when all eleven volumes are page-locked (f3d_host_register or pinned by the caller).
 class CudaOperationSolveP : public CudaOperationPiecemealBase {
  public:
   CudaOperationSolveP() : CudaOperationPiecemealBase("CUDA Sove Piecemeal") {}

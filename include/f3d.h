@@ -107,6 +107,8 @@ int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t 
  * ALLOCATE_PINNED_MEMORY switch, src/data_types/data3d.cpp:30,57-61, applied to memory the caller already owns). */
 int f3d_host_register(void* ptr, size_t bytes);
 int f3d_host_unregister(void* ptr);
+/* *yes = 1 when ptr lies in page-locked host memory (registered here or allocated pinned by the caller) */
+int f3d_host_is_pinned(const void* ptr, int* yes);
 /* cuMemcpyDtoD: src/cuda_operations/entire_data/cuda_operation_median.cpp:96-98 */
 int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes);
 /* cuModuleGetGlobal("container_size") + cuMemcpyHtoD in every op's Initialize, e.g. cuda_operation_solve.cpp:59-61 */

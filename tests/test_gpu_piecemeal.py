@@ -153,6 +153,7 @@ def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, e
     (13, 1, 4, 5, 1, 27),     # two chunk sets of 13 planes: one-plane chunks, 27 of them through the pipeline per pass
     (28, 2, 5, 5, 1, 61),     # overlapped, two outer iterations per residency, odd number of chunks per pass
     (1000, 0, 3, 5, 1, 27),   # overlap asked for but the level fits: still one residency
+    (13, 1, 4, 5, 2, 27),     # overlap asked for on pageable volumes: the solver keeps the serial schedule
 ])
 def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap, D):
     rng = np.random.default_rng(planes)
@@ -167,10 +168,11 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     fields = 26 if overlap and planes < D else 13
     set_budget(budget_for(fields * planes, W, H, fields))
     os.environ["F3D_P_OUTER_PER_PASS"] = str(forced)
-    os.environ["F3D_P_OVERLAP"] = str(overlap)
+    os.environ["F3D_P_OVERLAP"] = str(min(overlap, 1))
+    pinned = overlap == 1
     names = ["frame_0", "frame_1", "flow_u", "flow_v", "flow_w", "flow_du", "flow_dv", "flow_dw", "temp_du", "temp_dv", "temp_dw"]
     arrays = [f0, f1, u, v, w] + [np.full(f0.shape, np.nan, np.float32) for _ in range(6)]
-    vols = {n: f3d.HostVolume(a.copy()) for n, a in zip(names, arrays)}
+    vols = {n: f3d.HostVolume(a.copy(), pin=pinned) for n, a in zip(names, arrays)}  # overlap needs page-locked volumes
     op = make_op(f3d, "solve_p")
     op.execute(outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5, equation_smoothness=0.001,
                equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **vols)
@@ -178,7 +180,8 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     if planes >= D:
         assert (chunk, per_pass, halo, passes, overlapped) == (D, outer, 0, 1, False)
     else:
-        assert overlapped == bool(overlap) and chunk == planes - 2 * halo
+        assert overlapped == pinned
+        assert chunk == (planes if pinned or not overlap else 2 * planes) - 2 * halo
         assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
         if forced:
             assert per_pass == forced
@@ -300,8 +303,7 @@ def test_driver_matches_resident_driver(f3d):
     assert on_device == 0
     for g, e in zip(got2, exp):
         assert same(g, e)
-    os.environ["F3D_P_PIN"] = "1"   # copies beside the kernels, pinned and staged
-    os.environ["F3D_P_OVERLAP"] = "1"
+    os.environ["F3D_P_OVERLAP"] = "1"   # copies beside the kernels; without page-locked volumes the solver stays serial
     set_budget(budget_for(26 * 40, n, n, 26))
     for pin in ("1", "0"):
         os.environ["F3D_P_PIN"] = pin
