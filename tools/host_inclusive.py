@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""512^3: OpticalFlowE::ComputeFlow including the host <-> device copies (the reference's timed region) beside the
+device-resident solve, and what page-locking the frames costs and buys.   python tools/host_inclusive.py"""
 import importlib, sys, time, ctypes as C
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pkg = importlib.import_module("cuda-flow3d_amd")
 n = 512

@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Whole default pyramids on small cubes (64^3 ... 256^3), device-resident: the latency floor of the launch sequence
+("Small levels are latency-bound").   python tools/latency_floor.py"""
 import importlib, sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("cuda-flow3d_amd")
 for n in (64, 96, 128, 192, 256):
     f0, f1 = pkg.synth_pair(n, n, n)
