@@ -278,11 +278,24 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
   return (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
 }
 
+namespace {
+int g_live_operators = 0;
+}
+
 bool CudaOperationPiecemealBase::Initialize(const OperationParameters*)
 {
   size_t free_b = 0, total_b = 0;
+  const bool was = initialized_;
   initialized_ = !CheckDeviceError(f3d_mem_info(&free_b, &total_b));  // needs a live device context, nothing else
+  if (initialized_ && !was) ++g_live_operators;
+  if (!initialized_ && was) --g_live_operators;
   return initialized_;
+}
+
+void CudaOperationPiecemealBase::Destroy()
+{
+  if (initialized_ && --g_live_operators == 0) PiecemealReleaseArena();
+  initialized_ = false;
 }
 
 // ---- add (cuda_operation_add_p.cpp:52-214) ----------------------------------------------------------------------

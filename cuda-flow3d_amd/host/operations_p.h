@@ -48,6 +48,12 @@ class CudaOperationPiecemealBase : public CudaOperationBase {
  public:
   // the reference's piecemeal operators take no container at Initialize (cuda_operation_solve_p.cpp:34-58)
   bool Initialize(const OperationParameters* params = nullptr) override;
+  // the shared chunk arena goes back to the device when the last initialised piecemeal operator is destroyed
+  void Destroy() override;
+  ~CudaOperationPiecemealBase() override
+  {
+    if (initialized_) Destroy();
+  }
 
  protected:
   explicit CudaOperationPiecemealBase(const char* name) : CudaOperationBase(name) {}
