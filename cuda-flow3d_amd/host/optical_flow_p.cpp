@@ -122,6 +122,14 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     for (void* p : pinned) f3d_host_unregister(p);
   };
 
+  if (current_warp_level < 0) {  // no level requested: the flow is identically zero
+    flow_u.ZeroData();
+    flow_v.ZeroData();
+    flow_w.ZeroData();
+    finish();
+    return;
+  }
+
   // ---- coarse levels that fit: on the device -------------------------------------------------------------------------
   const char* res_env = std::getenv("F3D_P_RESIDENT");
   if (resident_coarse_levels && !(res_env && res_env[0] == '0') && current_warp_level >= 0) {

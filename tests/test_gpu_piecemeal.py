@@ -258,6 +258,14 @@ def test_driver_matches_oracle_small(f3d, oracle):
     assert seen == {False, True}, "the budgets should cover levels with and without device copies of the originals"
 
 
+def test_driver_without_levels_returns_zero_flow(f3d):
+    f0, f1 = f3d.synth_pair(24, 20, 16)
+    got, (passes, streamed, on_device) = run_p(f3d, f0, f1, warp_levels_count=0)
+    assert (passes, streamed, on_device) == (0, 0, 0)
+    for g in got:
+        assert not g.any()
+
+
 def test_driver_matches_golden_crops(f3d):
     """The committed piecemeal fixtures (tests/golden/expected_piecemeal.npz: oracle, no blur, no median) on the crops of the
     reference's data volumes, with a budget that puts the finest levels through chunks; the thin 96x64x5 crop runs with
