@@ -38,6 +38,7 @@ def run_ranks(n, dims, tmp_path, env=None, **kw):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-2000:]}"
     parts = [np.load(o) for o in outs]
     run_ranks.overlapped = [int(p["overlapped"]) for p in parts]
+    run_ranks.batched = [int(p["batched"]) for p in parts]
     return [sum(p[c] for p in parts) for c in "uvw"]   # slabs are disjoint, the other planes are zero
 
 
@@ -76,3 +77,21 @@ def test_overlapped_exchange_order(f3d, tmp_path, n_ranks, dims, min_planes):
         assert all(8 <= c <= 24 for c in run_ranks.overlapped), run_ranks.overlapped
     for g, e, c in zip(got, exp, "uvw"):
         assert same(g, e), f"{n_ranks} processes: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+@pytest.mark.parametrize("n_ranks,forced,halo", [(4, "4", "32"), (3, "1", "16"), (4, "3", "40")])
+def test_outer_iterations_per_exchange_across_processes(f3d, tmp_path, n_ranks, forced, halo):
+    """Thin slabs with n (K + 1) halo planes per exchange (n forced to 4, 1 and 3): the pack / transfer / unpack path of the
+    one-rank-per-process driver with halos that reach across several ranks.  Same bits as one GPU, same count on every rank."""
+    dims = (44, 36, 50)
+    kw = dict(warp_levels_count=10, outer_iterations_count=7)
+    f0, f1 = f3d.synth_pair(*dims)
+    flow = f3d.OpticalFlow()
+    flow.initialize(*dims)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(n_ranks, dims, tmp_path, env={"F3D_SLAB_OUTER_PER_EXCHANGE": forced, "F3D_TEST_HALO_CAPACITY": halo}, **kw)
+    expect = 0 if forced == "1" else 10 * 2   # 7 outer iterations = 4 + 3 or 3 + 3 + 1: two groups of more than one per level
+    assert run_ranks.batched == [expect] * n_ranks, run_ranks.batched
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} processes, n = {forced}: component {c} differs, max {np.abs(g - e).max():.3e}"
