@@ -19,6 +19,7 @@
 // of earlier variants (register rows, LDS rows, buffer loads, halos two planes ahead, ...) is in DESIGN.md section 3
 // and in the git history.
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1179,6 +1180,18 @@ const Tuning& tuning()
   return t;
 }
 
+// The kernels address a z-chunk with 32-bit byte offsets from the chunk's first plane: a chunk, with the halo planes it
+// reads on either side, must stay below 4 GiB of one array.  Planes of a container larger than 1024 x 1024 floats leave room
+// for fewer than 1024 of them.
+inline int max_planes_per_chunk(const F3dGeo& g)
+{
+  static const bool off = std::getenv("F3D_CHUNK_LIMIT") && std::atoi(std::getenv("F3D_CHUNK_LIMIT")) == 0;
+  if (off) return 0x3fffffff;  // only to show that tests/test_gpu_big.py catches the overflow
+  const unsigned long long plane_bytes = static_cast<unsigned long long>(g.Hc) * static_cast<unsigned long long>(g.pitch) * 4ull;
+  const long long planes = static_cast<long long>(0xffffffffull / plane_bytes) - 8;  // 3-4 halo planes each way and slack
+  return planes < 1 ? 1 : (planes > 0x3fffffff ? 0x3fffffff : static_cast<int>(planes));
+}
+
 // k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
 template <bool SWEEP>
 void launch_solver(const SolveArgs& a, const F3dGeo& g)
@@ -1208,6 +1221,7 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
     }
   }
   if (t.zchunk > 0) zchunk = t.zchunk;
+  zchunk = std::min(zchunk, max_planes_per_chunk(g));
   const int nz = (planes + zchunk - 1) / zchunk;
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;
@@ -1237,7 +1251,8 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
   // chunks of at least two planes: a coarse level is latency-bound and prefers many short marches (64^3: 2-plane chunks in
   // one round, 28 -> 16 us per launch), a fine one never gets near the limit
   const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
-  int zchunk = planes;
+  const int zc_limit = max_planes_per_chunk(g);
+  int zchunk = std::min(planes, zc_limit);
   if (want_wg > 0) {  // experiments: aim at a workgroup count
     long nzc = (want_wg + tiles - 1) / tiles;
     if (nzc > max_chunks) nzc = max_chunks;
@@ -1247,6 +1262,7 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
     long best = -1;
     for (int nzc = 1; nzc <= max_chunks; ++nzc) {
       const int zc = (planes + nzc - 1) / nzc;
+      if (zc > zc_limit) continue;
       const long wgs = tiles * ((planes + zc - 1) / zc);
       const long cost = ((wgs + 255) / 256) * (zc + 6);
       if (best < 0 || cost < best) {
@@ -1256,6 +1272,7 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
     }
   }
   if (force_zchunk > 0) zchunk = force_zchunk;
+  zchunk = std::min(zchunk, zc_limit);
   const int nz = (planes + zchunk - 1) / zchunk;
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;

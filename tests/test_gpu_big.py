@@ -59,3 +59,52 @@ def test_full_volume_1024_cubed(f3d, oracle):
     finally:
         f3d.sync()
         box.free()
+
+
+def test_level_in_a_container_with_planes_above_4_mib(f3d, oracle):
+    """A 1000^3 level in the corner of a 1280 x 1280 container (6.25 MiB planes, the geometry of a 1280^3 run): the solver
+    kernels address a z-chunk with 32-bit byte offsets, so no chunk may span 4 GiB of an array -- 655 of these planes -- while
+    the chunk rules would otherwise give the fused pair ONE chunk of 1000 planes here (wrong addresses, NaN: found with
+    tools/pbench.py --size 1280).  Whole-level launches of phi/ksi, one sweep and the fused pair; the oracle restates
+    windows at the front, around plane 655 and at the rear."""
+    free, _total = f3d.mem_info()
+    if free < 120 * 2**30:
+        pytest.skip("needs 120 GiB of free device memory")
+    L, C, period = 1000, 1280, 8
+    windows = [(0, 3), (652, 660), (L - 3, L)]
+    margin = 4
+    rng = np.random.default_rng(1280)
+    mk = lambda lo, hi: rng.uniform(lo, hi, (period, L, L)).astype(np.float32)
+    chunk = [mk(0, 255), mk(0, 255), mk(-3, 3), mk(-3, 3), mk(-3, 3), mk(-0.5, 0.5), mk(-0.5, 0.5), mk(-0.5, 0.5)]
+    h, eps, alpha = (1.28, 1.28, 1.28), 0.001, 7.5
+    hip = f3d.hip()
+    box = f3d.Containers(C, C, L)
+    try:
+        ptr = [box.alloc() for _ in chunk]
+        box.set_current()
+        for p, c in zip(ptr, chunk):
+            for z in range(0, L, period):
+                box.upload(p, c, plane0=z)
+        phi, ksi, s1u, s1v, s1w, s2u, s2v, s2w = (box.alloc(fill=0xFF) for _ in range(8))
+        f3d.check(hip.f3d_phi_ksi(*ptr, L, L, L, *h, eps, eps, phi, ksi, None))
+        f3d.check(hip.f3d_solve_sweep(*ptr, phi, ksi, L, L, L, *h, alpha, s1u, s1v, s1w, None))
+        f3d.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, L, L, L, *h, alpha, s2u, s2v, s2w, None))
+        f3d.sync()
+        for a, b in windows:
+            zb, ze = max(0, a - margin), min(L, b + margin)
+            sub = [np.ascontiguousarray(np.stack([c[z % period] for z in range(zb, ze)])) for c in chunk]
+            wide = (max(0, a - 2), min(L, b + 2))     # phi/ksi and the first sweep of the pair on two planes more
+            g = lambda lo, hi: oracle.geom(sub[0], z_base=zb, z_lo=lo, z_hi=hi)
+            phi_o, ksi_o = oracle.phi_ksi(*sub, (L, L, L), h, eps, eps, g=g(*wide))
+            first = oracle.solve_sweep(*sub, phi_o, ksi_o, (L, L, L), h, alpha, g=g(max(0, a - 1), min(L, b + 1)))
+            second = oracle.solve_sweep(*sub[:5], *first, phi_o, ksi_o, (L, L, L), h, alpha, g=g(a, b))
+            rows = slice(a - zb, b - zb)
+            get = lambda p: box.download(p, (L, L, b - a), plane0=a)
+            assert bit_same(get(phi), phi_o[rows]), f"phi planes [{a},{b})"
+            for name, p, e in zip(("du", "dv", "dw"), (s1u, s1v, s1w), first):
+                assert bit_same(get(p), e[rows]), f"one sweep, {name} planes [{a},{b})"
+            for name, p, e in zip(("du", "dv", "dw"), (s2u, s2v, s2w), second):
+                assert bit_same(get(p), e[rows]), f"fused pair, {name} planes [{a},{b})"
+    finally:
+        f3d.sync()
+        box.free()

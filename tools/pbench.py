@@ -63,6 +63,13 @@ def main():
         ok = all(bool(np.all(g == e)) for g, e in zip(got, exp))
         print("results identical" if ok else "RESULTS DIFFER")
         if not ok:
+            inner = (slice(n // 4, -n // 4),) * 3
+            for name, g, e in zip("uvw", got, exp):
+                bad = g != e
+                zs = np.flatnonzero(bad.any(axis=(1, 2)))
+                print(f"  {name}: {int(bad.sum())} voxels differ, z planes {zs[:4].tolist()} .. {zs[-4:].tolist()} ({len(zs)} planes), "
+                      f"max |diff| {float(np.abs(g - e).max()):.3e}; interior mean resident {float(e[inner].mean()):+.4f} "
+                      f"piecemeal {float(g[inner].mean()):+.4f}", flush=True)
             sys.exit(1)
 
 
