@@ -2,6 +2,8 @@
 offsets inside one array run up to 2^32 - 4 and anything that keeps them in a signed 32-bit integer breaks in the rear
 half of the volume.  The launchers run over the WHOLE volume on the MI355X; the oracle restates three z-windows of it
 (front, the 2 GiB crossing, rear) from the same data and the planes must agree bit for bit."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -70,25 +72,32 @@ def test_level_in_a_container_with_planes_above_4_mib(f3d, oracle):
     free, _total = f3d.mem_info()
     if free < 120 * 2**30:
         pytest.skip("needs 120 GiB of free device memory")
-    L, C, period = 1000, 1280, 8
+    L, CS, period = 1000, 1280, 8
     windows = [(0, 3), (652, 660), (L - 3, L)]
-    margin = 4
+    margin = 6   # the warp reaches ceil(3 / 1.28) + 1 = 4 planes, the median 2, the pair 2
     rng = np.random.default_rng(1280)
     mk = lambda lo, hi: rng.uniform(lo, hi, (period, L, L)).astype(np.float32)
     chunk = [mk(0, 255), mk(0, 255), mk(-3, 3), mk(-3, 3), mk(-3, 3), mk(-0.5, 0.5), mk(-0.5, 0.5), mk(-0.5, 0.5)]
     h, eps, alpha = (1.28, 1.28, 1.28), 0.001, 7.5
     hip = f3d.hip()
-    box = f3d.Containers(C, C, L)
+    box = f3d.Containers(CS, CS, L)
     try:
         ptr = [box.alloc() for _ in chunk]
         box.set_current()
         for p, c in zip(ptr, chunk):
             for z in range(0, L, period):
                 box.upload(p, c, plane0=z)
-        phi, ksi, s1u, s1v, s1w, s2u, s2v, s2w = (box.alloc(fill=0xFF) for _ in range(8))
+        phi, ksi, s1u, s1v, s1w, s2u, s2v, s2w, med, wrp, blur, tmp = (box.alloc(fill=0xFF) for _ in range(12))
         f3d.check(hip.f3d_phi_ksi(*ptr, L, L, L, *h, eps, eps, phi, ksi, None))
         f3d.check(hip.f3d_solve_sweep(*ptr, phi, ksi, L, L, L, *h, alpha, s1u, s1v, s1w, None))
         f3d.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, L, L, L, *h, alpha, s2u, s2v, s2w, None))
+        f3d.check(hip.f3d_median(ptr[2], L, L, L, 5, med, None))
+        f3d.check(hip.f3d_warp(ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], L, L, L, *h, wrp, None))
+        radius, taps = f3d.gaussian_taps(2.0)
+        f3d.check(hip.f3d_set_conv_taps(taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps)))
+        f3d.check(hip.f3d_conv_rows(blur, ptr[0], L, L, L, radius, None))
+        f3d.check(hip.f3d_conv_cols(tmp, blur, L, L, L, radius, None))
+        f3d.check(hip.f3d_conv_slices(blur, tmp, L, L, L, radius, None))
         f3d.sync()
         for a, b in windows:
             zb, ze = max(0, a - margin), min(L, b + margin)
@@ -105,6 +114,13 @@ def test_level_in_a_container_with_planes_above_4_mib(f3d, oracle):
                 assert bit_same(get(p), e[rows]), f"one sweep, {name} planes [{a},{b})"
             for name, p, e in zip(("du", "dv", "dw"), (s2u, s2v, s2w), second):
                 assert bit_same(get(p), e[rows]), f"fused pair, {name} planes [{a},{b})"
+            assert np.array_equal(get(med), oracle.median(sub[2], (L, L, L), 5, g=g(a, b))[rows]), f"median planes [{a},{b})"
+            assert bit_same(get(wrp), oracle.warp(*sub[:5], (L, L, L), h, g=g(a, b))[rows]), f"warp planes [{a},{b})"
+            ta, tb = np.full_like(sub[0], np.nan), np.full_like(sub[0], np.nan)
+            oracle.conv_axis(ta, sub[0], (L, L, L), radius, taps, 0, g(zb, ze))
+            oracle.conv_axis(tb, ta, (L, L, L), radius, taps, 1, g(zb, ze))
+            oracle.conv_axis(ta, tb, (L, L, L), radius, taps, 2, g(a, b))
+            assert bit_same(get(blur), ta[rows]), f"Gaussian planes [{a},{b})"
     finally:
         f3d.sync()
         box.free()
