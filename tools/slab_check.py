@@ -21,6 +21,8 @@ ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--procs", type=int, default=4)
 ap.add_argument("--proc-size", type=int, default=256)
 a = ap.parse_args()
+if a.procs > 5:
+    sys.exit("at most 5 rank processes: this process holds the GPU too and a gpurun box allows 6")
 pkg = importlib.import_module("cuda-flow3d_amd")
 
 
