@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dims", type=int, nargs=3, help="W H D instead of a cube")
     ap.add_argument("--budget-mb", type=float, default=0)
     ap.add_argument("--outer", type=int, default=40)
     ap.add_argument("--levels", type=int, default=40)
@@ -28,17 +29,18 @@ def main():
     a = ap.parse_args()
     pkg = importlib.import_module("cuda-flow3d_amd")
     n = a.size
+    W, H, D = a.dims if a.dims else (n, n, n)
     t0 = time.time()
-    f0, f1 = pkg.synth_pair(n, n, n)
-    print(f"synthetic {n}^3 pair in {time.time() - t0:.1f} s", flush=True)
+    f0, f1 = pkg.synth_pair(W, H, D)
+    print(f"synthetic {W}x{H}x{D} pair in {time.time() - t0:.1f} s", flush=True)
     kw = dict(outer_iterations_count=a.outer, warp_levels_count=a.levels)
     exp = None
     if not a.no_resident:
         flow = pkg.OpticalFlow()
-        flow.initialize(n, n, n)
+        flow.initialize(W, H, D)
         flow.upload(f0, f1)
         secs = flow.compute_resident(silent=True, gaussian_sigma=0.0, median_radius=1, **kw)
-        print(f"resident : {secs:8.3f} s on the device  {n ** 3 / secs / 1e6:7.2f} Mvoxels/s", flush=True)
+        print(f"resident : {secs:8.3f} s on the device  {W * H * D / secs / 1e6:7.2f} Mvoxels/s", flush=True)
         if a.check:
             exp = flow.download()
         flow.destroy()
@@ -47,14 +49,14 @@ def main():
     if a.per_pass > 0:
         os.environ["F3D_P_OUTER_PER_PASS"] = str(a.per_pass)
     flow = pkg.PiecemealOpticalFlow()
-    flow.initialize(n, n, n)
+    flow.initialize(W, H, D)
     flow.set_resident(not a.all_through_host)
     t0 = time.time()
     got = flow.compute(f0, f1, silent=not a.verbose, **kw)
     wall = time.time() - t0
     passes, streamed, on_device = flow.stats()
     print(f"piecemeal: {flow.device_seconds:8.3f} s ({wall:.3f} s wall with host allocation and page-locking)  "
-          f"{n ** 3 / flow.device_seconds / 1e6:7.2f} Mvoxels/s  budget {a.budget_mb or 'auto'} MB  "
+          f"{W * H * D / flow.device_seconds / 1e6:7.2f} Mvoxels/s  budget {a.budget_mb or 'auto'} MB  "
           f"{passes} solver residencies, {streamed} levels in chunks, {on_device} levels on the device"
           f"{' with the originals' if flow.originals_on_device() else ''}", flush=True)
     print("           " + "  ".join(f"{k} {v:.3f}s" for k, v in flow.operator_seconds().items()), flush=True)
@@ -63,7 +65,7 @@ def main():
         ok = all(bool(np.all(g == e)) for g, e in zip(got, exp))
         print("results identical" if ok else "RESULTS DIFFER")
         if not ok:
-            inner = (slice(n // 4, -n // 4),) * 3
+            inner = tuple(slice(k // 4, -(k // 4)) for k in (D, H, W))
             for name, g, e in zip("uvw", got, exp):
                 bad = g != e
                 zs = np.flatnonzero(bad.any(axis=(1, 2)))
