@@ -143,7 +143,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     auto fits = [&](int level, bool with_originals) {
       const size_t need = 14 * container_bytes(level) + (with_originals ? originals_bytes : 0);
       const size_t stream = level == 0 && current_warp_level == 0 && !with_originals ? 0 : PiecemealMinResampleBytes(W0, H0);
-      return need <= static_cast<size_t>(0.85 * static_cast<double>(budget)) && need + stream <= budget;
+      return need <= static_cast<size_t>(0.97 * static_cast<double>(budget)) && need + stream <= budget;
     };
     auto last_resident = [&](bool with_originals) {
       int last = current_warp_level + 1;

@@ -37,7 +37,7 @@ class OpticalFlowP : public OpticalFlowBase {
   // wall seconds the last ComputeFlow spent in {frame resample, flow resample, registration, solve, add} of the levels that
   // went through the host, and in the resident coarse levels as a whole
   const double* LastOperatorSeconds() const { return op_seconds_; }
-  // Run the coarse levels whose whole working set (14 fields) fits 85 % of the device budget with the "entire data"
+  // Run the coarse levels whose whole working set (14 fields) fits the device budget (97 %, and room for the frame streaming arena) with the "entire data"
   // operators, flow and increments staying on the device from level to level; only the two original frames stream through
   // (they are resampled straight into device containers).  The flow goes to the host once, when the first level that does
   // not fit is reached.  Same kernels, same result; F3D_P_RESIDENT=0 or this flag sends every level through the host.
