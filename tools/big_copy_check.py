@@ -1,5 +1,8 @@
-import importlib, sys, ctypes as C
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Whole-volume host <-> device copies above 4 GiB (1024 x 1024 x 1200 floats), pageable and page-locked, whole and in
+pieces: every plane must come back as it went.   python tools/big_copy_check.py"""
+import importlib, os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pkg = importlib.import_module("cuda-flow3d_amd")
 hip = pkg.hip()
