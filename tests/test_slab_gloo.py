@@ -26,7 +26,9 @@ WORKER = textwrap.dedent('''
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     W, H, D = 23, 14, int(os.environ["F3D_DEPTH"])
-    K, OUTER, HALO = 5, 3, 8
+    K, OUTER = 5, int(os.environ.get("F3D_OUTER", "3"))
+    NEX = int(os.environ.get("F3D_NEX", "1"))        # outer iterations per exchange (thin slabs of small levels)
+    HALO = max(8, NEX * (K + 1))
     dims, h = (W, H, D), (1.3, 0.8, 1.6)
     rng = np.random.default_rng(7)
     full = [rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32)
@@ -60,18 +62,23 @@ WORKER = textwrap.dedent('''
         return orc.Geom(H, W, base, max(0, lo - grow), min(D, hi + grow)) if hi > lo else orc.Geom(H, W, base, lo, lo)
 
     f0, f1, u, v, w = (container(x) for x in full)
-    exchange([f0, f1, u, v, w], K + 1)                                                 # level-static halos
+    exchange([f0, f1, u, v, w], NEX * (K + 1))                                         # level-static halos
     du, dv, dw = (container() for _ in range(3))
     for c in (du, dv, dw):
         c[:] = 0
     tmp = [container() for _ in range(3)]
-    for it in range(OUTER):
-        phi, ksi = orc.phi_ksi(f0, f1, u, v, w, du, dv, dw, dims, h, 0.001, 0.001, g=window(K))
-        for j in range(K):
-            orc.solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, 7.5, g=window(K - 1 - j), out=tuple(tmp))
-            (du, dv, dw), tmp = tuple(tmp), [du, dv, dw]
-        if it + 1 < OUTER:
-            exchange([du, dv, dw], K + 1)
+    it = 0
+    while it < OUTER:
+        n = min(NEX, OUTER - it)
+        for j in range(n):             # iteration j of the group leaves du, dv, dw valid on the slab widened by g planes
+            g = (n - 1 - j) * (K + 1)
+            phi, ksi = orc.phi_ksi(f0, f1, u, v, w, du, dv, dw, dims, h, 0.001, 0.001, g=window(g + K))
+            for s in range(K):
+                orc.solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, 7.5, g=window(g + K - 1 - s), out=tuple(tmp))
+                (du, dv, dw), tmp = tuple(tmp), [du, dv, dw]
+        it += n
+        if it < OUTER:
+            exchange([du, dv, dw], min(NEX, OUTER - it) * (K + 1))
     own = window(0)
     for a, b in ((u, du), (v, dv), (w, dw)):
         orc.add(a, b, dims, g=own)
@@ -108,11 +115,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("depth", [17, 6])   # 6 planes on 2 ranks: slabs thinner than the 6-plane solver halo
-def test_two_ranks_over_gloo_match_the_unsplit_oracle(tmp_path, depth):
+# 6 planes on 2 ranks: slabs thinner than the 6-plane solver halo; nex > 1: several outer iterations between two exchanges
+# on nested windows (OpticalFlowSlab's rule for thin slabs of small levels), groups of 2 + 2 + 1 and of 3
+@pytest.mark.parametrize("depth,nex,outer", [(17, 1, 3), (6, 1, 3), (17, 2, 5), (9, 3, 3)])
+def test_two_ranks_over_gloo_match_the_unsplit_oracle(tmp_path, depth, nex, outer):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, F3D_ROOT=ROOT, F3D_DEPTH=str(depth), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, F3D_ROOT=ROOT, F3D_DEPTH=str(depth), F3D_NEX=str(nex), F3D_OUTER=str(outer), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
