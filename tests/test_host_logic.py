@@ -236,3 +236,63 @@ def test_piecemeal_solver_plan_properties(f3d):
     assert auto_big[:4] in (big[:4], forced_on[:4])
     auto_small = f3d.plan_solve_piecemeal(planes_budget(40, 2048, 2048), 2048, 2048, 2048, 5, 40, 0, -1)
     assert auto_small[4] == 0, "a budget of 40 planes cannot afford two sets"
+
+
+@pytest.mark.parametrize("planes,forced,outer,inner", [(20, 1, 3, 5), (28, 2, 5, 5), (17, 0, 4, 3)])
+def test_piecemeal_solver_windows_reproduce_the_unsplit_solve(f3d, oracle, planes, forced, outer, inner):
+    """The out-of-core solver's residency scheme on the CPU, with the ORACLE as the compute and the PRODUCT's plan
+    (PlanSolvePiecemeal) deciding chunk, halo and outer iterations per pass: every chunk is staged with its halo in a
+    container of its own, outer iteration j of a pass runs phi/ksi on the chunk widened by (n-1-j)(K+1) + K planes and sweep s
+    on (n-1-j)(K+1) + K-1-s, only the owned planes go back.  Bit-identical to the unsplit oracle loop."""
+    f3d.host()
+    W, H, D = 19, 12, 31
+    K = inner
+    pitch = (W * 4 + 255) // 256 * 256
+    budget = 13 * (planes * pitch * H + 17 * 256 + 256)
+    chunk, n_pass, halo, max_planes, _ = f3d.plan_solve_piecemeal(budget, W, H, D, K, outer, forced)
+    assert max_planes == planes and chunk == planes - 2 * halo and halo == n_pass * (K + 1)
+    rng = np.random.default_rng(planes)
+    dims, h = (W, H, D), (1.1, 0.9, 1.4)
+    full = [rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32) for lo, hi in [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2)]]
+    # unsplit
+    du, dv, dw = (np.zeros((D, H, W), np.float32) for _ in range(3))
+    for _ in range(outer):
+        phi, ksi = oracle.phi_ksi(*full, du, dv, dw, dims, h, 0.001, 0.001)
+        for _ in range(K):
+            du, dv, dw = oracle.solve_sweep(*full, du, dv, dw, phi, ksi, dims, h, 7.5)
+    expect = (du, dv, dw)
+    # chunked: host increments inc -> nxt per pass, like flow_du / temp_du
+    inc = [np.zeros((D, H, W), np.float32) for _ in range(3)]
+    nxt = [np.full((D, H, W), np.nan, np.float32) for _ in range(3)]
+    it = 0
+    while it < outer:
+        n = min(n_pass, outer - it)
+        reach = n * (K + 1)
+        for z0 in range(0, D, chunk):
+            z1 = min(D, z0 + chunk)
+            base = z0 - halo
+            lo, hi = max(0, z0 - reach), min(D, z1 + reach)
+            stage = lambda vol: _staged(vol, base, planes, lo, hi)
+            fixed = [stage(v) for v in full]
+            d = [stage(v) for v in inc]
+            tmp = [np.full_like(fixed[0], np.nan) for _ in range(3)]
+            win = lambda grow: oracle.Geom(H, W, base, max(0, z0 - grow), min(D, z1 + grow))
+            for j in range(n):
+                g = (n - 1 - j) * (K + 1)
+                phi, ksi = oracle.phi_ksi(*fixed, *d, dims, h, 0.001, 0.001, g=win(g + K))
+                for s in range(K):
+                    oracle.solve_sweep(*fixed, *d, phi, ksi, dims, h, 7.5, g=win(g + K - 1 - s), out=tuple(tmp))
+                    d, tmp = tmp, d
+            for k in range(3):
+                nxt[k][z0:z1] = d[k][z0 - base:z1 - base]
+        inc, nxt = nxt, inc
+        it += n
+    for got, e, name in zip(inc, expect, ("du", "dv", "dw")):
+        assert bit_same(got, e), name
+
+
+def _staged(vol, base, planes, lo, hi):
+    """planes [lo, hi) of a volume in a NaN-poisoned container whose plane 0 holds global plane `base`"""
+    c = np.full((planes,) + vol.shape[1:], np.nan, np.float32)
+    c[lo - base:hi - base] = vol[lo:hi]
+    return c
