@@ -153,7 +153,11 @@ int main(int argc, char** argv)
   }
 
   OpticalFlowE optical_flow_e;
-  if (!optical_flow_e.Initialize(data_size)) return 3;
+  if (!optical_flow_e.Initialize(data_size)) {
+    std::printf("The resident driver needs 15 containers of the volume on the device; for larger volumes run with --partial\n"
+                "(host-resident volumes streamed through the GPU, no pre-blur and no median like the reference's piecemeal driver).\n");
+    return 3;
+  }
   if (!optical_flow_e.AllocateResidentFrames()) return 3;
   std::printf("Mode: Full GPU mode \n");
   optical_flow_e.silent = silent_mode;
