@@ -167,7 +167,7 @@ def host():
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
-        "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
+        "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_set_full_pipeline": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
@@ -565,6 +565,10 @@ class PiecemealOpticalFlow:
         y = C.c_int()
         check(host().f3d_pflow_originals_on_device(self._h, C.byref(y)), "f3d_pflow_originals_on_device")
         return bool(y.value)
+
+    def set_full_pipeline(self, enabled):
+        """also run the Gaussian pre-blur and the per-level median: OpticalFlowE's whole pipeline on host volumes"""
+        check(host().f3d_pflow_set_full_pipeline(self._h, int(bool(enabled))), "f3d_pflow_set_full_pipeline")
 
     def set_resident(self, enabled):
         """coarse levels that fit the budget stay on the device (default) or every level goes through the host"""

@@ -165,6 +165,8 @@ int f3d_op_create(f3d_op* op, const char* name)
   else if (n == "registration_p") impl = new CudaOperationRegistrationP;
   else if (n == "solve_p") impl = new CudaOperationSolveP;
   else if (n == "stat_p") impl = new CudaOperationStatP;
+  else if (n == "convolution_p") impl = new CudaOperationConvolution3DP;
+  else if (n == "median_p") impl = new CudaOperationMedianP;
   if (!impl) return 1;
   *op = new f3d_op_s;
   (*op)->op = impl;
@@ -285,6 +287,13 @@ int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes)
 {
   if (!flow || !yes) return 1;
   *yes = flow->driver.LastOriginalsOnDevice() ? 1 : 0;
+  return 0;
+}
+
+int f3d_pflow_set_full_pipeline(f3d_pflow flow, int enabled)
+{
+  if (!flow) return 1;
+  flow->driver.full_pipeline = enabled != 0;
   return 0;
 }
 

@@ -4,11 +4,12 @@
 // the nine-key parameter bag, write flow-u/v/w as RAW float32), with the compile-time constants turned into
 // flags:  flow3d --dims W H D --frames f0.raw f1.raw [f2.raw ...] [--f32] [--out prefix] [--levels N] [--scale s]
 //                [--outer N] [--inner N] [--alpha a] [--eps-smooth e] [--eps-data e] [--median r] [--sigma s]
-//                [--synthetic] [--vtk] [--stats] [--silent] [--partial [--budget-mb N]]
+//                [--synthetic] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]]
 // More than two frames make a sequence: the driver, its containers and operators are set up once (the reference does
 // Initialize / Destroy per pair, src/main.cpp:150,184) and the flow of every consecutive pair is written as
 // <prefix>_<k>_flow-{u,v,w}-W-H-D.raw.  --partial runs the out-of-core driver (the reference's use_partial_gpu branch,
-// src/main.cpp:187-220): volumes stay in host memory, output files end in "-partial.raw".
+// src/main.cpp:187-220): volumes stay in host memory, output files end in "-partial.raw"; --full adds the pre-blur and the
+// median the reference's piecemeal driver leaves out, which makes the result equal the resident mode's.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,7 +25,7 @@ static void Usage()
 {
   std::printf("usage: flow3d --dims W H D (--frames f0.raw f1.raw [f2.raw ...] [--f32] | --synthetic) [--out prefix]\n"
               "              [--levels N] [--scale s] [--outer N] [--inner N] [--alpha a] [--eps-smooth e]\n"
-              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent] [--partial [--budget-mb N]]\n");
+              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]]\n");
 }
 
 int main(int argc, char** argv)
@@ -33,7 +34,7 @@ int main(int argc, char** argv)
   std::vector<std::string> files;
   std::string prefix = "flow3d";
   bool f32_input = false, synthetic = false, write_vtk = false, silent_mode = false, print_stats = false;
-  bool use_partial_gpu = false;
+  bool use_partial_gpu = false, partial_full = false;
 
   // defaults of src/main.cpp:77-85
   size_t warp_levels_count = 40;
@@ -75,6 +76,7 @@ int main(int argc, char** argv)
     else if (a == "--vtk") write_vtk = true;
     else if (a == "--silent") silent_mode = true;
     else if (a == "--partial") use_partial_gpu = true;
+    else if (a == "--full") partial_full = true;
     else if (a == "--budget-mb") { need(1); setenv("F3D_P_BUDGET_MB", argv[++i], 1); }
     else { Usage(); return 64; }
   }
@@ -121,6 +123,7 @@ int main(int argc, char** argv)
     if (!optical_flow_p.Initialize(data_size)) return 3;
     std::printf("Mode: Partial processing mode \n");
     optical_flow_p.silent = silent_mode;
+    optical_flow_p.full_pipeline = partial_full;  // pre-blur and median as in the resident mode (the reference's piecemeal driver has neither)
     for (size_t k = 0; k < pairs; ++k) {
       if (!synthetic && !load(frame_1, files[k + 1])) return 2;
       optical_flow_p.ComputeFlow(frame_0, frame_1, flow_u, flow_v, flow_w, params);

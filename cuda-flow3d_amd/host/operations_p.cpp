@@ -749,3 +749,130 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   }
   if (!silent) std::printf("\n");
 }
+
+// ---- Gaussian on host volumes (cuda_operation_convolution.cpp:134-184 chunked) ------------------------------------
+
+void CudaOperationConvolution3DP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_input, *p_output;
+  DataSize4 data_size;
+  float gaussian_sigma;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_input, "input");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_output, "output");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, float, gaussian_sigma, "gaussian_sigma");
+  if (p_input == p_output || p_input->DataPtr() == p_output->DataPtr()) {
+    std::printf("Operation '%s': Error. Input buffer cannot serve as output buffer.", GetName());
+    return;
+  }
+  if (!Fits(*p_input, data_size) || !Fits(*p_output, data_size)) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return;
+  }
+  if (!(gaussian_sigma > 0.f)) {
+    std::printf("Operation '%s': Error. gaussian_sigma must be positive.\n", GetName());
+    return;
+  }
+  taps_.ComputeGaussianKernel(gaussian_sigma, 3, 1.0);  // prints and leaves no taps when the radius exceeds the 51-tap limit
+  const int R = static_cast<int>(taps_.KernelRadius());
+  if (2 * R + 1 > 51) return;
+  if (CheckDeviceError(f3d_set_conv_taps(taps_.Kernel(), 2 * static_cast<size_t>(R) + 1))) return;
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  if (W == 0 || H == 0 || D == 0) return;
+
+  // three buffers of chunk + 2 R planes: rows and columns on the chunk widened by the tap radius, slices on the chunk
+  const ChunkBox box(W, H);
+  const size_t total = box.TotalPlanes(PiecemealBudgetBytes(), 3) / 3;
+  const int planes = static_cast<int>(std::min<size_t>(total, static_cast<size_t>(D)));
+  const int chunk = planes >= D ? D : planes - 2 * R;
+  if (chunk < 1) return LowMemory(GetName());
+  Carver buf(box);
+  for (int i = 0; i < 3; ++i) buf.Add(planes);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, planes);
+  if (!scope.ok()) return;
+  for (int z0 = 0; z0 < D; z0 += chunk) {
+    const int z1 = std::min(D, z0 + chunk);
+    const int lo = std::max(0, z0 - R), hi = std::min(D, z1 + R);
+    const int base = chunk == D ? 0 : z0 - R;
+    const f3d_slab wide = {base, lo, hi}, own = {base, z0, z1};
+    if (!Upload(buf[0], box, lo - base, *p_input, W, H, lo, hi - lo)) return;
+    if (CheckDeviceError(f3d_conv_rows(buf[1], buf[0], W, H, D, R, &wide))) return;
+    if (CheckDeviceError(f3d_conv_cols(buf[2], buf[1], W, H, D, R, &wide))) return;
+    if (CheckDeviceError(f3d_conv_slices(buf[1], buf[2], W, H, D, R, &own))) return;
+    if (!Download(*p_output, W, H, z0, z1 - z0, buf[1], box, z0 - base)) return;
+  }
+  CheckDeviceError(f3d_stream_sync());
+}
+
+// ---- median on host volumes (cuda_operation_median.cpp:72-149 chunked) ---------------------------------------------
+
+void CudaOperationMedianP::Execute(OperationParameters& params)
+{
+  if (!IsInitialized()) return;
+  Data3D *p_input, *p_output;
+  DataSize4 data_size;
+  size_t radius;
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_input, "input");
+  GET_PARAM_PTR_OR_RETURN(params, Data3D, p_output, "output");
+  GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  GET_PARAM_OR_RETURN(params, size_t, radius, "radius");
+  if (!Fits(*p_input, data_size) || !Fits(*p_output, data_size)) {
+    std::printf("Error: Operation '%s'. Wrong dimensions.\n", GetName());
+    return;
+  }
+  const size_t W = data_size.width, H = data_size.height;
+  const int D = static_cast<int>(data_size.depth);
+  if (W == 0 || H == 0 || D == 0) return;
+  const bool in_place = p_input == p_output || p_input->DataPtr() == p_output->DataPtr();
+  if (radius != 1 && radius % 2 == 0) {
+    std::printf("Warning. Median raduis is even (%zu), decresaing by 1...\n", radius);
+    radius -= 1;
+  }
+  if (radius == 1) {  // nothing to filter
+    if (!in_place)
+      for (int z = 0; z < D; ++z)
+        for (size_t y = 0; y < H; ++y)
+          std::copy_n(PlanePtr(*p_input, z) + y * p_input->Width(), W, PlanePtr(*p_output, z) + y * p_output->Width());
+    return;
+  }
+  if (radius < 3 || radius > 7) {
+    std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", radius);
+    return;
+  }
+  const int half = static_cast<int>(radius) / 2;
+
+  // input: chunk + 2 half planes, output: chunk planes.  A later chunk reads `half` planes an earlier one has already
+  // replaced in the host volume when the filter runs in place, so those planes are carried over on the device: the tail of
+  // the input buffer moves to its head before the rest of the next chunk is uploaded.
+  const ChunkBox box(W, H);
+  const size_t total = box.TotalPlanes(PiecemealBudgetBytes(), 2);
+  int chunk = D;
+  if (total < 2 * static_cast<size_t>(D)) chunk = static_cast<int>((total - std::min<size_t>(total, 2 * static_cast<size_t>(half))) / 2);
+  if (chunk < 2 * half + 1 && chunk < D) return LowMemory(GetName());
+  const int in_planes = std::min(D, chunk + 2 * half);
+  Carver buf(box);
+  buf.Add(in_planes);
+  buf.Add(chunk);
+  if (!buf.Commit()) return;
+  ContainerScope scope(box, in_planes);
+  if (!scope.ok()) return;
+  for (int z0 = 0; z0 < D; z0 += chunk) {
+    const int z1 = std::min(D, z0 + chunk);
+    const int lo = std::max(0, z0 - half), hi = std::min(D, z1 + half);
+    const int base = chunk == D ? 0 : z0 - half;
+    int fresh_lo = lo;
+    if (z0 > 0) {
+      // planes [z0 - half, z0 + half) sit at the tail of the buffer from the previous chunk (its planes chunk .. chunk + 2 half)
+      if (CheckDeviceError(f3d_copy_planes(buf[0], 0, buf[0], chunk, 2 * half, W, H))) return;
+      fresh_lo = std::min(hi, z0 + half);
+    }
+    if (hi > fresh_lo && !Upload(buf[0], box, fresh_lo - base, *p_input, W, H, fresh_lo, hi - fresh_lo)) return;
+    const f3d_slab own = {base, z0, z1};
+    if (CheckDeviceError(f3d_median(buf[0], W, H, D, radius, Rebase(buf[1], box, z0, base), &own))) return;
+    if (!Download(*p_output, W, H, z0, z1 - z0, buf[1], box, 0)) return;
+  }
+  CheckDeviceError(f3d_stream_sync());
+}

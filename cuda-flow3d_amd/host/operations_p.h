@@ -114,6 +114,29 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   size_t last_passes_ = 0;
 };
 
+// The two filters the reference's piecemeal driver leaves out (its median is commented out, optical_flow_p.cpp:268-302, and
+// it never blurs), as host-volume operators in the same style, so that OpticalFlowP can reproduce OpticalFlowE's full
+// pipeline on volumes that do not fit the device (OpticalFlowP::full_pipeline).  No reference counterpart: names and keys
+// follow the "entire data" operators with Data3D* values.
+
+// separable Gaussian, rows -> columns -> slices     keys: input, output (Data3D*, different volumes), data_size, gaussian_sigma
+class CudaOperationConvolution3DP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationConvolution3DP() : CudaOperationPiecemealBase("CUDA Convolution 3D Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+
+ private:
+  CudaOperationConvolution3D taps_;  // host arithmetic of the tap generator only
+};
+
+// 3-D median, "radius" is the window diameter (1 = copy, even = one less, 3 / 5 / 7).  input == output is allowed: the planes
+// a later chunk still needs of what an earlier chunk overwrote stay on the device.   keys: input, output, data_size, radius
+class CudaOperationMedianP : public CudaOperationPiecemealBase {
+ public:
+  CudaOperationMedianP() : CudaOperationPiecemealBase("CUDA Median Piecemeal") {}
+  void Execute(OperationParameters& params) override;
+};
+
 // min / max / average flow magnitude            keys: flow_u, flow_v, flow_w (Data3D*), data_size, stat (Stat3*)
 class CudaOperationStatP : public CudaOperationPiecemealBase {
  public:

@@ -27,6 +27,8 @@ bool OpticalFlowP::Initialize(const DataSize4& data_size)
 {
   initialized_ = true;
   data_size_ = data_size;
+  // the two filters of the full pipeline are not part of the reference's list and stay out of its console lines
+  if (!cuop_convolution_p_.Initialize() || !cuop_median_p_.Initialize()) initialized_ = false;
   std::printf("Initialization of cuda operations...\n");
   for (CudaOperationBase* cuop : cuda_operations_) {
     std::printf("%-18s: ", cuop->GetName());
@@ -43,6 +45,8 @@ bool OpticalFlowP::Initialize(const DataSize4& data_size)
 void OpticalFlowP::Destroy()
 {
   for (CudaOperationBase* cuop : cuda_operations_) cuop->Destroy();
+  cuop_convolution_p_.Destroy();
+  cuop_median_p_.Destroy();
   PiecemealReleaseArena();
   initialized_ = false;
 }
@@ -62,8 +66,17 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   GET_PARAM_OR_RETURN(params, float, equation_data, "equation_data");
   GET_PARAM_OR_RETURN(params, size_t, median_radius, "median_radius");   // read like the reference, not used by this driver
   GET_PARAM_OR_RETURN(params, float, gaussian_sigma, "gaussian_sigma");  // likewise
-  (void)median_radius;
-  (void)gaussian_sigma;
+  const char* full_env = std::getenv("F3D_P_FULL");
+  const bool full = full_pipeline || (full_env && full_env[0] == '1');
+  size_t level_median = 1;  // 1 = no median, the reference's piecemeal behaviour
+  if (full) {
+    level_median = median_radius;
+    if (level_median != 1 && level_median % 2 == 0) level_median -= 1;
+    if (level_median != 1 && (level_median < 3 || level_median > 7)) {
+      std::printf("Error. Wrong median raduis (%zu). Supported values: 3, 5, 7\n", level_median);
+      return;
+    }
+  }
 
   float hx, hy, hz;
   DataSize4 original_data_size = {frame_0.Width(), frame_0.Height(), frame_0.Depth(), 0};
@@ -97,6 +110,23 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   };
   for (Data3D* v : {&frame_0, &frame_1, &flow_u, &flow_v, &flow_w}) pin_volume(v);
 
+  // Full pipeline: the pyramid reads Gaussian-blurred copies of the two frames (optical_flow_e.cpp:213-242), made here chunk
+  // by chunk into two more host volumes; the caller's frames are only read.
+  Data3D blur_0, blur_1;
+  Data3D* src_0 = &frame_0;
+  Data3D* src_1 = &frame_1;
+  const bool blur = full && gaussian_sigma > 0.f;
+  if (blur) {
+    if (!blur_0.Allocate(W0, H0, D0) || !blur_1.Allocate(W0, H0, D0)) {
+      for (void* p : pinned) f3d_host_unregister(p);
+      return;
+    }
+    pin_volume(&blur_0);
+    pin_volume(&blur_1);
+    src_0 = &blur_0;
+    src_1 = &blur_1;
+  }
+
   f3d_event ev_start = nullptr, ev_stop = nullptr;
   CheckDeviceError(f3d_event_create(&ev_start));
   CheckDeviceError(f3d_event_create(&ev_stop));
@@ -128,6 +158,21 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     flow_w.ZeroData();
     finish();
     return;
+  }
+
+  if (blur) {
+    const auto t0 = std::chrono::steady_clock::now();
+    Data3D* from[2] = {&frame_0, &frame_1};
+    Data3D* to[2] = {&blur_0, &blur_1};
+    for (int i = 0; i < 2; ++i) {
+      OperationParameters bag;
+      bag.PushValuePtr("input", from[i]);
+      bag.PushValuePtr("output", to[i]);
+      bag.PushValuePtr("data_size", &original_data_size);
+      bag.PushValuePtr("gaussian_sigma", &gaussian_sigma);
+      cuop_convolution_p_.Execute(bag);
+    }
+    op_seconds_[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 
   // ---- coarse levels that fit: on the device -------------------------------------------------------------------------
@@ -163,13 +208,15 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       DataSize4 carried = {0, 0, 0, 0};
       int next = current_warp_level;
       if (last_with <= next) {
-        ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, next, last_with, container_bytes(last_with), true, carried);
+        ok = RunResidentLevels(*src_0, *src_1, flow_u, flow_v, flow_w, params, next, last_with, container_bytes(last_with), true, carried,
+                               level_median);
         originals_on_device_ = true;
         carried = GetLevel(original_data_size, warp_scale_factor, last_with).size;
         next = last_with - 1;
       }
       if (ok && last <= next)
-        ok = RunResidentLevels(frame_0, frame_1, flow_u, flow_v, flow_w, params, next, last, container_bytes(last), false, carried);
+        ok = RunResidentLevels(*src_0, *src_1, flow_u, flow_v, flow_w, params, next, last, container_bytes(last), false, carried,
+                               level_median);
       op_seconds_[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (!ok) {
         std::printf("'%s': Error in the resident levels.\n", GetName());
@@ -202,8 +249,8 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     pin_volume(v);
   }
 
-  Data3D* p_frame_0 = &frame_0;
-  Data3D* p_frame_1 = &frame_1;
+  Data3D* p_frame_0 = src_0;
+  Data3D* p_frame_1 = src_1;
   Data3D* p_frame_0_res = &frame_0_res;
   Data3D* p_frame_1_res_br = &frame_1_res_br;
 
@@ -326,7 +373,19 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 
     // At level 0 the registration swapped the CALLER's frame_1 with temp_0; give the caller its storage (and its data,
     // which the warp only read) back.  The reference leaves the warped frame in the caller's volume.
-    if (current_warp_level == 0) frame_1.Swap(temp_0);
+    if (current_warp_level == 0) src_1->Swap(temp_0);
+
+    /* Flow field median filtering (full pipeline only; commented out in the reference, optical_flow_p.cpp:268-302) */
+    if (level_median != 1) {
+      for (Data3D* flow : {&flow_u, &flow_v, &flow_w}) {
+        op.Clear();
+        op.PushValuePtr("input", flow);
+        op.PushValuePtr("output", flow);
+        op.PushValuePtr("data_size", &current_data_size);
+        op.PushValuePtr("radius", &level_median);
+        timed(4, cuop_median_p_, op);
+      }
+    }
 
     prev_data_size = current_data_size;
     --current_warp_level;
@@ -337,7 +396,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 
 bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w,
                                      OperationParameters& params, int first_level, int last_level, size_t container_bytes,
-                                     bool originals_on_device, const DataSize4& carried_flow_size)
+                                     bool originals_on_device, const DataSize4& carried_flow_size, size_t median_radius)
 {
   size_t outer_iterations_count, inner_iterations_count;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data;
@@ -393,7 +452,8 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
   OperationParameters init;
   init.PushValuePtr("container_size", &container);
   for (CudaOperationBase* cuop : {static_cast<CudaOperationBase*>(&cuop_resample_e_), static_cast<CudaOperationBase*>(&cuop_register_e_),
-                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_)})
+                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_),
+                                  static_cast<CudaOperationBase*>(&cuop_median_e_)})
     ok = cuop->Initialize(&init) && ok;
 
   OperationParameters op;
@@ -500,6 +560,17 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
       op.PushValuePtr("data_size", &current);
       cuop_add_e_.Execute(op);
     }
+    if (median_radius != 1) {
+      for (int i = 0; i < 3; ++i) {
+        op.Clear();
+        op.PushValuePtr("dev_input", &buf[FU + i]);
+        op.PushValuePtr("dev_output", &buf[TMP]);
+        op.PushValuePtr("data_size", &current);
+        op.PushValuePtr("radius", &median_radius);
+        cuop_median_e_.Execute(op);
+        std::swap(buf[FU + i], buf[TMP]);
+      }
+    }
     prev = current;
   }
 
@@ -512,7 +583,8 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
     ok = !CheckDeviceError(f3d_stream_sync()) && ok;
   }
   for (CudaOperationBase* cuop : {static_cast<CudaOperationBase*>(&cuop_resample_e_), static_cast<CudaOperationBase*>(&cuop_register_e_),
-                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_)})
+                                  static_cast<CudaOperationBase*>(&cuop_solve_e_), static_cast<CudaOperationBase*>(&cuop_add_e_),
+                                  static_cast<CudaOperationBase*>(&cuop_median_e_)})
     cuop->Destroy();
   release();
   return ok;

@@ -42,6 +42,10 @@ class OpticalFlowP : public OpticalFlowBase {
   // (they are resampled straight into device containers).  The flow goes to the host once, when the first level that does
   // not fit is reached.  Same kernels, same result; F3D_P_RESIDENT=0 or this flag sends every level through the host.
   bool resident_coarse_levels = true;
+  // Beyond the reference's piecemeal driver: also apply the Gaussian pre-blur and the per-level median of the flow, i.e.
+  // reproduce OpticalFlowE's whole pipeline (bit for bit) on volumes that do not fit the device.  Off by default, which is
+  // the reference's behaviour; F3D_P_FULL=1 turns it on as well.  Costs two more host volumes (the blurred frames).
+  bool full_pipeline = false;
 
  private:
   DataSize4 data_size_ = {0, 0, 0, 0};
@@ -49,7 +53,7 @@ class OpticalFlowP : public OpticalFlowBase {
   // levels first_level .. last_level (descending) on the device; false on a device error
   bool RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u, Data3D& flow_v, Data3D& flow_w, OperationParameters& params,
                          int first_level, int last_level, size_t container_bytes, bool originals_on_device,
-                         const DataSize4& carried_flow_size);
+                         const DataSize4& carried_flow_size, size_t median_radius);
 
   size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0;
   bool originals_on_device_ = false;
@@ -61,12 +65,15 @@ class OpticalFlowP : public OpticalFlowBase {
   CudaOperationRegistration cuop_register_e_;
   CudaOperationSolve cuop_solve_e_;
   CudaOperationAdd cuop_add_e_;
+  CudaOperationMedian cuop_median_e_;
 
   CudaOperationRegistrationP cuop_register_p_;
   CudaOperationResampleP cuop_resample_p_;
   CudaOperationSolveP cuop_solve_p_;
   CudaOperationStatP cuop_stat_p_;
   CudaOperationAddP cuop_add_p_;
+  CudaOperationConvolution3DP cuop_convolution_p_;  // full_pipeline only
+  CudaOperationMedianP cuop_median_p_;
   std::vector<CudaOperationBase*> cuda_operations_;
 };
 

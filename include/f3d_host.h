@@ -93,6 +93,10 @@ int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1
 int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels, size_t* resident_levels);
 /* whether the resident levels of the last compute resampled their frames from device copies of the two originals */
 int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes);
+/* also apply the Gaussian pre-blur and the per-level median, i.e. OpticalFlowE's whole pipeline on host volumes (off by
+ * default like the reference's piecemeal driver; F3D_P_FULL=1 also turns it on).  The two extra operators are
+ * "convolution_p" (keys input, output, data_size, gaussian_sigma) and "median_p" (input, output, data_size, radius). */
+int f3d_pflow_set_full_pipeline(f3d_pflow flow, int enabled);
 /* coarse levels whose working set fits the budget stay on the device (default on; F3D_P_RESIDENT=0 also turns it off) */
 int f3d_pflow_set_resident(f3d_pflow flow, int enabled);
 /* wall seconds of the last compute in {frame resample, flow resample, registration, solve, add} of the levels that went

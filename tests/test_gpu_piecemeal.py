@@ -210,11 +210,12 @@ def test_solve_reports_low_memory(f3d, capfd):
         x.destroy()
 
 
-def run_p(f3d, f0, f1, resident=True, **kw):
+def run_p(f3d, f0, f1, resident=True, full=False, **kw):
     d, h, w = f0.shape
     flow = f3d.PiecemealOpticalFlow()
     flow.initialize(w, h, d)
     flow.set_resident(resident)
+    flow.set_full_pipeline(full)
     try:
         out = flow.compute(f0, f1, silent=True, **kw)
         run_p.originals_on_device = flow.originals_on_device()
@@ -349,3 +350,80 @@ def test_cli_partial_mode(f3d, tmp_path):
         got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}-partial.raw", np.float32).reshape(D, H, W) for c in "uvw"]
         for g, e in zip(got, exp):
             assert same(g, e)
+
+
+@pytest.mark.parametrize("sigma,planes", [(2.0, 3 * 20), (1.0, 3 * 9), (3.5, 3 * 40)])
+def test_gaussian_in_chunks(f3d, oracle, sigma, planes):
+    """convolution_p: rows and columns on the chunk widened by the tap radius, slices on the chunk; zero padding at the ends
+    of the volume only.  Height a multiple of 4 and equal to the host volume's (the reference's precondition)."""
+    rng = np.random.default_rng(int(sigma * 10))
+    W, H, D = 41, 24, 37
+    src = rng.uniform(0, 255, size=(D, H, W)).astype(np.float32)
+    expect = oracle.gaussian(src, (W, H, D), sigma)
+    set_budget(budget_for(planes, W, H, 3))
+    vin, vout = f3d.HostVolume(src.copy()), f3d.HostVolume(np.full(src.shape, np.nan, np.float32))
+    op = make_op(f3d, "convolution_p")
+    assert op.name == "CUDA Convolution 3D Piecemeal"
+    op.execute(input=vin, output=vout, data_size=(W, H, D), gaussian_sigma=sigma)
+    assert same(vout.array, expect), f"max diff {np.nanmax(np.abs(vout.array - expect))}"
+    assert same(vin.array, src)
+    op.destroy()
+    vin.destroy()
+    vout.destroy()
+
+
+@pytest.mark.parametrize("radius,planes", [(5, 2 * 9), (3, 2 * 5), (7, 2 * 12), (5, 2 * 100), (4, 2 * 8), (1, 2 * 8)])
+def test_median_in_chunks_and_in_place(f3d, oracle, radius, planes):
+    """median_p on a sub-box of a larger host volume: separate output, and in place (the planes a later chunk needs of what
+    an earlier chunk replaced are carried over on the device)."""
+    rng = np.random.default_rng(radius)
+    W, H, D = 37, 21, 26
+    cd = (48, 24, 30)
+    src = box_in_container(rng, (W, H, D), cd, -3, 3)
+    eff = radius - 1 if radius % 2 == 0 else radius
+    expect = src if eff == 1 else oracle.median(src, (W, H, D), eff)
+    set_budget(budget_for(planes, W, H, 2))
+    op = make_op(f3d, "median_p")
+    assert op.name == "CUDA Median Piecemeal"
+    vin, vout = f3d.HostVolume(src.copy()), f3d.HostVolume(np.full(src.shape, np.nan, np.float32))
+    op.execute(input=vin, output=vout, data_size=(W, H, D), radius=radius)
+    assert same(vout.array[:D, :H, :W], expect[:D, :H, :W])
+    vio = f3d.HostVolume(src.copy())
+    op.execute(input=vio, output=vio, data_size=(W, H, D), radius=radius)
+    assert same(vio.array[:D, :H, :W], expect[:D, :H, :W])
+    op.destroy()
+    for v in (vin, vout, vio):
+        v.destroy()
+
+
+def test_full_pipeline_equals_the_resident_driver_and_the_golden_crop(f3d):
+    """full_pipeline: pre-blur and per-level median on host volumes as well -- OpticalFlowE's whole pipeline.  Against the
+    committed default-pipeline fixture (48x40x24 crop of the reference's 128^3 pair) and against OpticalFlowE on a 120^3
+    synthetic pair, with budgets that stream the finest levels; with and without the resident coarse levels."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    e = np.load(os.path.join(gold, "expected_oracle.npz"))
+    i128 = np.load(os.path.join(gold, "inputs_128.npz"))
+    crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+    f0 = i128["frame_0"].astype(np.float32)[crop].copy()
+    f1 = i128["frame_1"].astype(np.float32)[crop].copy()
+    for resident in (True, False):
+        set_budget(budget_for(13 * 20, 48, 40, 13))
+        got, (passes, streamed, on_device) = run_p(f3d, f0, f1, resident=resident, full=True)
+        assert streamed >= 1
+        for g, x, n in zip(got, e["crop128_flow"], "uvw"):
+            assert same(g, x), f"crop128 resident={resident} {n}: max diff {np.abs(g - x).max()}"
+    n = 120
+    a, b = f3d.synth_pair(n, n, n)
+    keep = a.copy(), b.copy()
+    flow = f3d.OpticalFlow()
+    flow.initialize(n, n, n)
+    try:
+        exp = flow.compute(a, b, silent=True, outer_iterations_count=5)
+    finally:
+        flow.destroy()
+    set_budget(budget_for(13 * 52, n, n, 13))
+    got, (passes, streamed, on_device) = run_p(f3d, a, b, full=True, outer_iterations_count=5)
+    assert streamed >= 3 and on_device >= 20
+    for g, x, c in zip(got, exp, "uvw"):
+        assert same(g, x), f"{c}: max diff {np.abs(g - x).max()}"
+    assert same(a, keep[0]) and same(b, keep[1])

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--all-through-host", action="store_true", help="no resident coarse levels in the piecemeal driver")
     ap.add_argument("--check", action="store_true", help="compare the two results bit for bit")
     ap.add_argument("--verbose", action="store_true", help="the driver's own log (levels, chunk plans)")
+    ap.add_argument("--full", action="store_true", help="full pipeline on both sides: pre-blur and median included")
     a = ap.parse_args()
     pkg = importlib.import_module("cuda-flow3d_amd")
     n = a.size
@@ -39,7 +40,7 @@ def main():
         flow = pkg.OpticalFlow()
         flow.initialize(W, H, D)
         flow.upload(f0, f1)
-        secs = flow.compute_resident(silent=True, gaussian_sigma=0.0, median_radius=1, **kw)
+        secs = flow.compute_resident(silent=True, **(kw if a.full else dict(kw, gaussian_sigma=0.0, median_radius=1)))
         print(f"resident : {secs:8.3f} s on the device  {W * H * D / secs / 1e6:7.2f} Mvoxels/s", flush=True)
         if a.check:
             exp = flow.download()
@@ -51,6 +52,7 @@ def main():
     flow = pkg.PiecemealOpticalFlow()
     flow.initialize(W, H, D)
     flow.set_resident(not a.all_through_host)
+    flow.set_full_pipeline(a.full)
     t0 = time.time()
     got = flow.compute(f0, f1, silent=not a.verbose, **kw)
     wall = time.time() - t0
