@@ -350,6 +350,15 @@ def test_cli_partial_mode(f3d, tmp_path):
         got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}-partial.raw", np.float32).reshape(D, H, W) for c in "uvw"]
         for g, e in zip(got, exp):
             assert same(g, e)
+    # --partial --full writes what the resident mode writes
+    common = [exe, "--dims", str(W), str(H), str(D), "--frames", paths[0], paths[1], "--levels", "6", "--outer", "3", "--silent"]
+    for extra, tag in ((["--partial", "--full", "--budget-mb", repr(mb)], "pf"), ([], "res")):
+        run = subprocess.run(common + ["--out", str(tmp_path / tag)] + extra, capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stdout + run.stderr
+    for c in "uvw":
+        a = np.fromfile(tmp_path / f"pf_flow-{c}-{W}-{H}-{D}-partial.raw", np.float32)
+        b = np.fromfile(tmp_path / f"res_flow-{c}-{W}-{H}-{D}.raw", np.float32)
+        assert same(a, b), c
 
 
 @pytest.mark.parametrize("sigma,planes", [(2.0, 3 * 20), (1.0, 3 * 9), (3.5, 3 * 40)])
