@@ -29,6 +29,7 @@ struct ProfRec {
 };
 struct Prof {
   bool enabled = false;
+  unsigned mask = ~0u;  // kernels that get events while enabled (bit = kernel id)
   std::vector<ProfRec> pending;
   std::vector<hipEvent_t> pool;
   double ms[F3D_K_COUNT][2] = {};  // [kernel][0 = all, 1 = filtered] is rebuilt on read
@@ -112,7 +113,7 @@ bool make_geo(F3dGeo* g, size_t w, size_t h, size_t d, const f3d_slab* slab, con
 
 void prof_begin(int kernel, size_t voxels)
 {
-  if (!P.enabled) return;
+  if (!P.enabled || !((P.mask >> kernel) & 1u)) return;
   hipEvent_t e = take_event();
   if (!e) return;
   (void)hipEventRecord(e, S.stream);
@@ -556,6 +557,12 @@ int f3d_stream_sync(void)
 int f3d_prof_enable(int enable)
 {
   P.enabled = enable != 0;
+  return 0;
+}
+
+int f3d_prof_select(unsigned kernel_mask)
+{
+  P.mask = kernel_mask;
   return 0;
 }
 
