@@ -852,23 +852,26 @@ void CudaOperationMedianP::Execute(OperationParameters& params)
   int chunk = D;
   if (total < 2 * static_cast<size_t>(D)) chunk = static_cast<int>((total - std::min<size_t>(total, 2 * static_cast<size_t>(half))) / 2);
   if (chunk < 2 * half + 1 && chunk < D) return LowMemory(GetName());
-  const int in_planes = std::min(D, chunk + 2 * half);
+  const int in_planes = chunk >= D ? D : chunk + 2 * half;  // plane 0 of the buffer is global plane z0 - half, also below plane 0
   Carver buf(box);
   buf.Add(in_planes);
   buf.Add(chunk);
   if (!buf.Commit()) return;
   ContainerScope scope(box, in_planes);
   if (!scope.ok()) return;
+  int have_hi = 0;  // one past the last input plane the buffer holds from the previous chunk
   for (int z0 = 0; z0 < D; z0 += chunk) {
     const int z1 = std::min(D, z0 + chunk);
     const int lo = std::max(0, z0 - half), hi = std::min(D, z1 + half);
     const int base = chunk == D ? 0 : z0 - half;
     int fresh_lo = lo;
     if (z0 > 0) {
-      // planes [z0 - half, z0 + half) sit at the tail of the buffer from the previous chunk (its planes chunk .. chunk + 2 half)
-      if (CheckDeviceError(f3d_copy_planes(buf[0], 0, buf[0], chunk, 2 * half, W, H))) return;
-      fresh_lo = std::min(hi, z0 + half);
+      // planes [z0 - half, have_hi) sit at the tail of the buffer from the previous chunk (from its plane `chunk` on)
+      const int carried = std::min(have_hi, z0 + half) - (z0 - half);
+      if (CheckDeviceError(f3d_copy_planes(buf[0], 0, buf[0], chunk, carried, W, H))) return;
+      fresh_lo = z0 - half + carried;
     }
+    have_hi = hi;
     if (hi > fresh_lo && !Upload(buf[0], box, fresh_lo - base, *p_input, W, H, fresh_lo, hi - fresh_lo)) return;
     const f3d_slab own = {base, z0, z1};
     if (CheckDeviceError(f3d_median(buf[0], W, H, D, radius, Rebase(buf[1], box, z0, base), &own))) return;

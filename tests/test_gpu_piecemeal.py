@@ -381,7 +381,8 @@ def test_gaussian_in_chunks(f3d, oracle, sigma, planes):
     vout.destroy()
 
 
-@pytest.mark.parametrize("radius,planes", [(5, 2 * 9), (3, 2 * 5), (7, 2 * 12), (5, 2 * 100), (4, 2 * 8), (1, 2 * 8)])
+# 51 planes in total for a depth of 26: the volume ALMOST fits (23-plane chunk + a 3-plane one whose halo ends at the volume)
+@pytest.mark.parametrize("radius,planes", [(5, 2 * 9), (3, 2 * 5), (7, 2 * 12), (5, 2 * 100), (4, 2 * 8), (1, 2 * 8), (5, 51), (7, 50)])
 def test_median_in_chunks_and_in_place(f3d, oracle, radius, planes):
     """median_p on a sub-box of a larger host volume: separate output, and in place (the planes a later chunk needs of what
     an earlier chunk replaced are carried over on the device)."""
