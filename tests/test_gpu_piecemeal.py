@@ -152,6 +152,7 @@ def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, e
     (26, 3, 3, 2, 0, 27),     # three per residency with pairs only
     (13, 1, 4, 5, 1, 27),     # two chunk sets of 13 planes: one-plane chunks, 27 of them through the pipeline per pass
     (28, 2, 5, 5, 1, 61),     # overlapped, two outer iterations per residency, odd number of chunks per pass
+    (26, 0, 3, 5, 0, 27),     # 26 of 27 planes: almost fits
     (1000, 0, 3, 5, 1, 27),   # overlap asked for but the level fits: still one residency
     (13, 1, 4, 5, 2, 27),     # overlap asked for on pageable volumes: the solver keeps the serial schedule
 ])
@@ -361,7 +362,7 @@ def test_cli_partial_mode(f3d, tmp_path):
         assert same(a, b), c
 
 
-@pytest.mark.parametrize("sigma,planes", [(2.0, 3 * 20), (1.0, 3 * 9), (3.5, 3 * 40)])
+@pytest.mark.parametrize("sigma,planes", [(2.0, 3 * 20), (1.0, 3 * 9), (3.5, 3 * 40), (2.0, 3 * 36), (2.0, 3 * 13)])  # 36 of 37 planes: almost fits
 def test_gaussian_in_chunks(f3d, oracle, sigma, planes):
     """convolution_p: rows and columns on the chunk widened by the tap radius, slices on the chunk; zero padding at the ends
     of the volume only.  Height a multiple of 4 and equal to the host volume's (the reference's precondition)."""
