@@ -2,19 +2,32 @@
 """bench.py -- headline benchmark of the MI355X-native 3-D optical-flow solver.
 
 Metric (BASELINE.json): Mvoxels/s of a FULL coarse-to-fine pyramid solve (default parameters of the reference,
-src/main.cpp:77-85) of a 512^3 float32 pair, frames already resident in HBM when the timed region starts.
-A "step" is one ComputeFlow over the whole pyramid (40 levels x (40 x (phi/ksi + 5 sweeps)) + warp, resample,
-add, median).  One JSON line on stdout carries the metric plus
-  roofline     : the dominant kernel (the solver sweep, 52 algorithmic B/voxel) timed live with HIP events on the
-                 library stream over the timed region, against the 8 TB/s HBM peak,
-  cpu_baseline : the same numerics (the oracle, a scalar-per-voxel C port with OpenMP over planes) run on the
-                 box's own host cores on a bounded sample (a smaller volume of the same synthetic family).
+src/main.cpp:77-85) of a 512^3 float32 pair (BASELINE config 4, the config the metric is quoted on).  A "step" is one
+ComputeFlow over the whole pyramid (40 levels x (40 x (phi/ksi + 5 sweeps)) + warp, resample, add, median).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu]
-For N > 1 launch through torch.distributed.run (one rank per GPU); the volume is z-slab partitioned.
+`value` is the DEVICE-RESIDENT rate: both frames are already in HBM when the timed region starts and the flow stays there.
+The reference's own timer sits before the upload and after the download (optical_flow_e.cpp:169,579); that rate is
+reported beside it as `host_inclusive` (page-locked host volumes -> H2D -> solve -> D2H) and is never `value`.
+
+One JSON line on stdout carries the metric plus
+  roofline     : the dominant kernel (the fused pair of solver sweeps, 2 x 52 algorithmic B/voxel) timed live with HIP
+                 events on the library stream over the timed region, against the 8 TB/s HBM peak; `traffic` is the HBM
+                 byte count of one finest-level launch from the committed PMC passes (omitted when they were collected on
+                 different kernel sources), `hbm_frac` the same launch priced with those measured bytes;
+  fixed_sample : SURVEY.md 8(d)'s like-for-like sample -- phi/ksi + 5 sweeps on the finest level -- on the GPU and on the
+                 box's host cores, in Mvoxel-updates/s;
+  configs      : BASELINE configs 2 and 3 (the shipped 128^3 pair and the 584x388x5 thin slab, full defaults) with their own
+                 roofline fractions;
+  cpu_baseline : the same numerics (the oracle, a scalar-per-voxel C port with OpenMP over planes) run on the box's own
+                 host cores on BASELINE config 2 (128^3, full default pyramid), timed fully.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu] [--no-extra]
+For N > 1 launch through torch.distributed.run (one rank per GPU); the volume is z-slab partitioned and the default size
+is BASELINE config 5 (1024^3).
 """
 import argparse
 import ctypes as C
+import hashlib
 import importlib
 import json
 import os
@@ -27,45 +40,183 @@ sys.path.insert(0, ROOT)
 SWEEP_BYTES_PER_VOXEL = 52.0    # 10 reads + 3 writes of float32
 PHI_KSI_BYTES_PER_VOXEL = 40.0  # 8 reads + 2 writes
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes of a whole default solve per config
+TOTAL_BYTES = {"c2": 0.183e12, "c3": 0.0845e12, 512: 11.58e12, 1024: 92.4e12}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def solver_source_stamp():
+    """sha256 (16 hex digits) of the solver kernel source: the PMC record is only valid for the kernels it was taken on"""
+    with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", "f3d_solve.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def measured_traffic(kernel):
-    """HBM bytes per 512^3 launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE in separate runs, tools/profile_round.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  bench.py cannot collect counters itself; the numbers are read from profiles/*_pmc_traffic.json."""
+    """HBM bytes per finest-level launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE in separate runs, tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  bench.py cannot collect counters itself; the record carries the stamp of the kernel source it was measured
+    on and is dropped when that is not the source of the library being timed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        rec = json.load(open(files[-1])).get(kernel)
+        doc = json.load(open(files[-1]))
     except (OSError, ValueError):
         return None
+    rec = doc.get(kernel)
     if not rec:
         return None
+    if doc.get("_solver_source_sha16") != solver_source_stamp():
+        return {"traffic": None, "traffic_scope": f"{os.path.basename(files[-1])} was collected on other kernel sources "
+                                                  f"({doc.get('_solver_source_sha16')}); not used"}
     return {"traffic": rec["hbm_bytes_per_launch"],
-            "traffic_scope": f"one 512^3 launch of {kernel}; algorithmic bytes of that launch: {rec['algorithmic_bytes_per_launch']}; "
-                             f"source {os.path.basename(files[-1])}"}
+            "traffic_scope": f"one {doc.get('_size', 512)}^3 launch of {kernel}; algorithmic bytes of that launch: "
+                             f"{rec['algorithmic_bytes_per_launch']}; source {os.path.basename(files[-1])}",
+            "_size": doc.get("_size", 512)}
 
 
-def cpu_baseline(size):
-    """Oracle (CPU port of the same numerics) on a size^3 pair of the same synthetic family, all host cores."""
-    import numpy as np  # noqa: F401
-    pkg = importlib.import_module("cuda-flow3d_amd")
+def golden_pairs():
+    """BASELINE configs 2 and 3: the reference's shipped volumes (uint8 fixtures under tests/golden/), as float32"""
+    import numpy as np
+    g = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    try:
+        a = np.load(os.path.join(g, "inputs_128.npz"))
+        out["c2"] = (a["frame_0"].astype(np.float32), a["frame_1"].astype(np.float32))
+        r = np.load(os.path.join(g, "inputs_rub.npz"))
+        rep = lambda k: np.ascontiguousarray(np.repeat(r[k][None], int(r["depth"]), axis=0).astype(np.float32))
+        out["c3"] = (rep("slice_0"), rep("slice_1"))
+    except (OSError, KeyError) as e:
+        log(f"[bench] golden inputs unavailable: {e}")
+    return out
+
+
+def cpu_baseline(pairs):
+    """BASELINE config 2 timed fully on the host: the oracle (CPU port of the same numerics) on the shipped 128^3 pair, full
+    default pyramid, every core of the box's share."""
     from oracle import oracle as orc  # cpu_baseline leg only
-    f0, f1 = pkg.synth_pair(size, size, size)
+    if "c2" not in pairs:
+        return None
+    f0, f1 = pairs["c2"]
     t0 = time.perf_counter()
     orc.compute_flow(f0, f1)
     dt = time.perf_counter() - t0
     return {
-        "value": round(size ** 3 / dt / 1e6, 5), "unit": "Mvoxels/s", "cores": orc.num_threads(), "kind": "port",
-        "sample": f"{size}^3 synthetic translated-Gaussian pair, full default pyramid, oracle/f3d_oracle.c with "
-                  f"OpenMP over planes ({dt:.1f} s)",
+        "value": round(f0.size / dt / 1e6, 5), "unit": "Mvoxels/s", "cores": orc.num_threads(), "kind": "port",
+        "sample": f"BASELINE config 2 in full: the shipped 128^3 pair, default pyramid (40 levels x 40 x 5), "
+                  f"oracle/f3d_oracle.c with OpenMP over planes ({dt:.1f} s)",
     }
+
+
+def fixed_sample_cpu(S):
+    """phi/ksi + 5 sweeps on the finest level of the bench volume, on the host (oracle), in Mvoxel-updates/s
+    (one update = one voxel through one of the six kernel passes)."""
+    import numpy as np
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    from oracle import oracle as orc  # cpu_baseline leg only
+    f0, f1 = pkg.synth_pair(S, S, S)
+    z = lambda: np.zeros((S, S, S), np.float32)
+    u, v, w, du, dv, dw = z(), z(), z(), z(), z(), z()
+    dims, h = (S, S, S), (1.0, 1.0, 1.0)
+    t0 = time.perf_counter()
+    phi, ksi = orc.phi_ksi(f0, f1, u, v, w, du, dv, dw, dims, h, 0.001, 0.001)
+    for _ in range(5):
+        du, dv, dw = orc.solve_sweep(f0, f1, u, v, w, du, dv, dw, phi, ksi, dims, h, 7.5)
+    dt = time.perf_counter() - t0
+    return {"value": round(6 * S ** 3 / dt / 1e6, 2), "unit": "Mvoxel-updates/s", "cores": orc.num_threads(),
+            "seconds": round(dt, 2)}
+
+
+def fixed_sample_gpu(pkg, S, reps=5):
+    """the same six passes through the solve operator (outer 1 x inner 5: du, dv, dw cleared, phi/ksi, five sweeps)"""
+    import numpy as np
+    f0, f1 = pkg.synth_pair(S, S, S)
+    cont = pkg.Containers(S, S, S)
+    ptr = {k: cont.new(fill=0) for k in ("f0", "f1", "u", "v", "w", "du", "dv", "dw", "phi", "ksi", "tdu", "tdv", "tdw")}
+    cont.upload(ptr["f0"], f0)
+    cont.upload(ptr["f1"], f1)
+    del f0, f1
+    op = pkg.Operation("solve")
+    op.initialize(cont)
+    kw = dict(dev_frame_0=ptr["f0"], dev_frame_1=ptr["f1"], dev_flow_u=ptr["u"], dev_flow_v=ptr["v"], dev_flow_w=ptr["w"],
+              dev_flow_du=ptr["du"], dev_flow_dv=ptr["dv"], dev_flow_dw=ptr["dw"], dev_phi=ptr["phi"], dev_ksi=ptr["ksi"],
+              dev_temp_du=ptr["tdu"], dev_temp_dv=ptr["tdv"], dev_temp_dw=ptr["tdw"], outer_iterations_count=1,
+              inner_iterations_count=5, equation_alpha=7.5, equation_smoothness=0.001, equation_data=0.001, hx=1.0, hy=1.0,
+              hz=1.0, data_size=(S, S, S))
+    op.execute(**kw)
+    pkg.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        op.execute(**kw)
+    pkg.sync()
+    dt = (time.perf_counter() - t0) / reps
+    op.destroy()
+    cont.free()
+    return {"value": round(6 * S ** 3 / dt / 1e6, 1), "unit": "Mvoxel-updates/s", "ms": round(dt * 1e3, 3)}
+
+
+def small_configs(pkg, pairs, reps=5):
+    """BASELINE configs 2 and 3 on the GPU, full defaults: ms per solve, Mvoxels/s and the fraction of the HBM roofline
+    their algorithmic bytes amount to"""
+    names = {"c2": "128^3 shipped pair, full default pyramid (BASELINE config 2)",
+             "c3": "584x388x5 thin-slab pair, full default pyramid (BASELINE config 3)"}
+    out = []
+    for key in ("c2", "c3"):
+        if key not in pairs:
+            continue
+        f0, f1 = pairs[key]
+        d, h, w = f0.shape
+        flow = pkg.OpticalFlow()
+        flow.initialize(w, h, d)
+        flow.upload(f0, f1)
+        flow.compute_resident(silent=True)
+        pkg.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            flow.compute_resident(silent=True)
+        pkg.sync()
+        dt = (time.perf_counter() - t0) / reps
+        flow.destroy()
+        gbs = TOTAL_BYTES[key] / dt / 1e9
+        out.append({"workload": names[key], "ms_per_step": round(dt * 1e3, 3), "value": round(f0.size / dt / 1e6, 3),
+                    "unit": "Mvoxels/s", "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "achieved_GBs": round(gbs, 1)})
+    return out
+
+
+def host_inclusive(pkg, flow, S, reps=2):
+    """the reference's timer placement (optical_flow_e.cpp:169,579): upload of both frames, the solve, download of u, v, w --
+    from page-locked host volumes (the reference's ALLOCATE_PINNED_MEMORY switch, data3d.cpp:30,57-61)"""
+    import numpy as np
+    hip = pkg.hip()
+    f0, f1 = pkg.synth_pair(S, S, S)
+    pinned = []
+    for a in (f0, f1):
+        if hip.f3d_host_register(C.c_void_p(a.ctypes.data), a.nbytes) == 0:
+            pinned.append(a)
+    try:
+        flow.compute(f0, f1, silent=True)   # first touch of the output pages
+        pkg.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            flow.compute(f0, f1, silent=True)
+        pkg.sync()
+        dt = (time.perf_counter() - t0) / reps
+    finally:
+        for a in pinned:
+            hip.f3d_host_unregister(C.c_void_p(a.ctypes.data))
+    return {"ms_per_step": round(dt * 1e3, 3), "value": round(S ** 3 / dt / 1e6, 4), "unit": "Mvoxels/s",
+            "note": "timer before H2D, after D2H (the reference's placement); frames page-locked, flow into fresh numpy arrays"}
+
+
+def profiler_attached():
+    """rocprofv3 preloads its tool library: the f3d_prof_* event bracket is switched off under it (the trace gives the kernel
+    times, and counter collection serialises every dispatch anyway)"""
+    blob = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    return "rocprof" in blob and os.environ.get("F3D_BENCH_FORCE_EVENTS") != "1"
 
 
 def run_single(args):
@@ -78,6 +229,7 @@ def run_single(args):
     flow.upload(f0, f1)
     del f0, f1
     hip = pkg.hip()
+    events = not profiler_attached()
 
     for i in range(args.warmup):
         t = flow.compute_resident(silent=True)
@@ -89,7 +241,7 @@ def run_single(args):
     dominant = 2 if os.environ.get("F3D_FUSED_SWEEPS", "1") != "0" else 1
     hip.f3d_prof_reset()
     hip.f3d_prof_select(1 << dominant)
-    hip.f3d_prof_enable(1)
+    hip.f3d_prof_enable(1 if events else 0)
     pkg.sync()
     t0 = time.perf_counter()
     dev_s = 0.0
@@ -98,11 +250,12 @@ def run_single(args):
     pkg.sync()
     wall = time.perf_counter() - t0
     hip.f3d_prof_enable(0)
-    hip.f3d_prof_select(0x7 & ~(1 << dominant))
-    hip.f3d_prof_enable(1)
-    flow.compute_resident(silent=True)      # untimed: phi/ksi and the other sweep kernel
-    pkg.sync()
-    hip.f3d_prof_enable(0)
+    if events and not args.no_extra:
+        hip.f3d_prof_select(0x7 & ~(1 << dominant))
+        hip.f3d_prof_enable(1)
+        flow.compute_resident(silent=True)      # untimed: phi/ksi and the other sweep kernel
+        pkg.sync()
+        hip.f3d_prof_enable(0)
     hip.f3d_prof_select(0x7)
     extra = args.steps                      # their totals cover one step, the dominant kernel's cover `steps`
 
@@ -122,6 +275,11 @@ def run_single(args):
         s1_ms, s1_n, s1_vox = s1_ms * extra, s1_n * extra, s1_vox * extra
         f1_ms, f1_n, f1_vox = f1_ms * extra, f1_n * extra, f1_vox * extra
     hip.f3d_prof_reset()
+
+    inclusive = None
+    if not args.no_extra:
+        log("[bench] host-inclusive step (H2D + solve + D2H) ...")
+        inclusive = host_inclusive(pkg, flow, S)
     flow.destroy()
 
     def gbs(bytes_per_voxel, vox, ms):
@@ -138,15 +296,20 @@ def run_single(args):
     finest = gbs(dom_b, fin_vox, fin_ms)
     all_sweeps = gbs(SWEEP_BYTES_PER_VOXEL, s1_vox + 2 * s2_vox, s1_ms + s2_ms)
     ms_per_step = wall / args.steps * 1e3
+    whole = TOTAL_BYTES.get(S)
     out = {
         "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
         "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair, full coarse-to-fine pyramid "
+        "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair (BASELINE config "
+                               f"{4 if S == 512 else 5 if S == 1024 else 'size ' + str(S)}), full coarse-to-fine pyramid "
                                "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
-                               "frames resident in HBM", "parallelism": "1 GPU"},
+                               "frames resident in HBM (value = device-resident rate; host_inclusive beside it)",
+                   "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
+        "host_inclusive": inclusive,
+        "whole_run_roofline_frac": round(whole / (wall / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if whole else None,
         "roofline": {
             "bound": "hbm", "kernel": dom_name,
             "algorithmic_bytes_per_voxel_per_launch": dom_b,
@@ -163,12 +326,31 @@ def run_single(args):
                         "frac": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms) / HBM_PEAK_GBS, 4), "launches": pk_n},
         },
     }
+    if not events:
+        out["roofline"]["note"] = "a profiler is attached: no HIP-event bracket in this run, kernel times come from its trace"
     traffic = measured_traffic(dom_name.split()[0])
     if traffic:
+        tsize = traffic.pop("_size", 512)
         out["roofline"].update(traffic)
-    if not args.no_cpu:
-        log("[bench] timing the CPU baseline (oracle) ...")
-        out["cpu_baseline"] = cpu_baseline(args.cpu_size)
+        # the same finest-level launch priced with the bytes the memory system really moved (fused sweeps move the bytes of
+        # one sweep for the algorithmic work of two, so `frac` above may exceed what a streaming kernel could reach)
+        if traffic.get("traffic") and fin_n and tsize == S:
+            real = traffic["traffic"] / (fin_ms / fin_n * 1e-3) / 1e9
+            out["roofline"]["hbm_frac"] = round(real / HBM_PEAK_GBS, 4)
+            out["roofline"]["hbm_GBs"] = round(real, 1)
+    if not args.no_extra:
+        log("[bench] fixed sample on the GPU (phi/ksi + 5 sweeps, finest level) ...")
+        out["fixed_sample"] = {"what": f"phi/ksi + 5 sweeps on the {S}^3 level (SURVEY.md 8d): six kernel passes per voxel",
+                               "gpu": fixed_sample_gpu(pkg, S)}
+        pairs = golden_pairs()
+        log("[bench] BASELINE configs 2 and 3 ...")
+        out["configs"] = small_configs(pkg, pairs)
+        if not args.no_cpu:
+            log("[bench] fixed sample and BASELINE config 2 on the host cores (oracle) ...")
+            out["fixed_sample"]["cpu"] = fixed_sample_cpu(S)
+            cb = cpu_baseline(pairs)
+            if cb:
+                out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
 
 
@@ -257,7 +439,9 @@ def run_multi(args):
             "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair, full coarse-to-fine pyramid "
+            "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair"
+                                   + (" (BASELINE config 5, the multi-GPU scaling workload)" if S == 1024 else "")
+                                   + ", full coarse-to-fine pyramid "
                                    "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
                                    "frames resident in HBM",
                        "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
@@ -284,10 +468,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--cpu-size", type=int, default=96)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--size", type=int, default=0, help="volume edge; default 512 on one GPU (BASELINE config 4), "
+                                                      "1024 on several (BASELINE config 5)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU legs (cpu_baseline, fixed_sample.cpu)")
+    ap.add_argument("--no-extra", action="store_true", help="only the timed steps: no host-inclusive step, fixed sample, "
+                                                           "configs 2/3 or CPU legs (profiling runs)")
     args = ap.parse_args()
+    multi = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.size <= 0:
+        args.size = 1024 if multi else 512
     force_multi = os.environ.get("F3D_BENCH_FORCE_SLAB") == "1"  # rehearse the multi-GPU code path with one rank
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not force_multi:
         run_single(args)

@@ -8,8 +8,10 @@ There is no Python or CPU implementation of any kernel here: if the libraries ar
 native handles raises -- build them with `python -c "import __graft_entry__ as g; g.build()"` or
 `make -C cuda-flow3d_amd`.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -67,7 +69,7 @@ def hip():
     L = _load("libf3d_hip.so")
     L.f3d_last_error.restype = C.c_char_p
     sig = {
-        "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_device_count": [C.POINTER(C.c_int)],
+        "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_is_initialized": [], "f3d_device_count": [C.POINTER(C.c_int)],
         "f3d_device_name": [C.c_char_p, _sz], "f3d_mem_info": [C.POINTER(_sz), C.POINTER(_sz)],
         "f3d_lds_per_workgroup": [C.POINTER(C.c_int)],
         "f3d_alloc_pitched": [C.POINTER(_dp), C.POINTER(_sz), _sz, _sz], "f3d_free": [_dp],
@@ -169,6 +171,7 @@ def host():
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
         "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_set_full_pipeline": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
+        "f3d_host_shutdown": [],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -188,6 +191,22 @@ def host():
     L.f3d_piecemeal_budget_bytes.restype = _sz
     _host = L
     return L
+
+
+def shutdown():
+    """Orderly end of device use: host volumes that are still page-locked are released, then f3d_host_shutdown() drops the
+    out-of-core arena, the copy queues, the RCCL communicator, the timing events and the library stream.  Registered with
+    atexit on import, so it runs while the interpreter, numpy's heap and the HIP runtime are all still alive -- nothing is
+    left to the order in which the process unloads libraries.  Idempotent."""
+    HostVolume.release_all()
+    if _host is not None:
+        _host.f3d_host_shutdown()
+    elif _hip is not None and _hip.f3d_is_initialized():
+        _hip.f3d_comm_destroy()
+        _hip.f3d_shutdown()
+
+
+atexit.register(shutdown)
 
 
 def check(status, what="f3d call"):
@@ -361,24 +380,52 @@ class Stat3(C.Structure):
 
 class HostVolume:
     """Dense host volume [z, y, x] float32 handed to the piecemeal operators as a Data3D* (f3d_volume_wrap).  Like the
-    reference's Data3D::Swap, registration_p / solve_p exchange STORAGE between the volumes of one call, so .array looks
-    the current storage up among all wrapped arrays."""
-    _storage = {}
+    reference's Data3D::Swap, registration_p / solve_p exchange STORAGE between the volumes of one call, so a volume may
+    end up holding the array another one was created with.  The class therefore keeps every wrapped array alive in a
+    table keyed by its address, together with whether it is page-locked, and a volume that goes away releases the storage
+    it holds AT THAT MOMENT (f3d_volume_data), never the one it started with: the survivor of a swapped pair keeps its
+    memory, its page-lock and its .array.  A finalizer does the same for volumes that are dropped without destroy()."""
+    _storage = {}   # address -> [array, page-locked]
 
     def __init__(self, array, pin=False):
         a = np.ascontiguousarray(array, dtype=np.float32)
         if a.ndim != 3:
             raise ValueError("volume must be [z, y, x]")
+        if a.ctypes.data in HostVolume._storage:
+            raise ValueError("this array is already wrapped by another HostVolume")
         self._h = C.c_void_p()
         d, h, w = a.shape
         check(host().f3d_volume_wrap(C.byref(self._h), a.ctypes.data_as(_fp), w, h, d), "f3d_volume_wrap")
-        HostVolume._storage[a.ctypes.data] = a
-        self._first = a.ctypes.data
-        self._pinned = False
+        entry = [a, False]
+        HostVolume._storage[a.ctypes.data] = entry
         if pin:  # page-locked: full link rate, and a precondition of the solver's overlapped schedule
-            check(hip().f3d_init(-1), "f3d_init")
-            check(hip().f3d_host_register(C.c_void_p(self._first), a.nbytes), "f3d_host_register")
-            self._pinned = True
+            try:
+                check(hip().f3d_init(-1), "f3d_init")
+                check(hip().f3d_host_register(C.c_void_p(a.ctypes.data), a.nbytes), "f3d_host_register")
+            except Exception:
+                self.destroy()
+                raise
+            entry[1] = True
+        self._finalizer = weakref.finalize(self, HostVolume._release, self._h.value)
+
+    @staticmethod
+    def _release(handle):
+        """drop the Data3D and whatever storage it holds now"""
+        if not handle or _host is None:
+            return
+        cur = _host.f3d_volume_data(C.c_void_p(handle))
+        _host.f3d_volume_destroy(C.c_void_p(handle))
+        entry = HostVolume._storage.pop(cur, None)
+        if entry is not None and entry[1] and _hip is not None and _hip.f3d_is_initialized():
+            _hip.f3d_host_unregister(C.c_void_p(cur))
+
+    @classmethod
+    def release_all(cls):
+        """exit hook: remove every page-lock that is still in place (the arrays themselves are numpy's to free)"""
+        for addr, entry in list(cls._storage.items()):
+            if entry[1] and _hip is not None and _hip.f3d_is_initialized():
+                _hip.f3d_host_unregister(C.c_void_p(addr))
+            entry[1] = False
 
     @property
     def object(self):
@@ -386,16 +433,15 @@ class HostVolume:
 
     @property
     def array(self):
-        return HostVolume._storage[host().f3d_volume_data(self._h)]
+        return HostVolume._storage[host().f3d_volume_data(self._h)][0]
 
     def destroy(self):
         if self._h:
-            host().f3d_volume_destroy(self._h)
+            fin = getattr(self, "_finalizer", None)
+            if fin is not None:
+                fin.detach()
+            HostVolume._release(self._h.value)
             self._h = C.c_void_p()
-            if self._pinned:
-                hip().f3d_host_unregister(C.c_void_p(self._first))
-                self._pinned = False
-            HostVolume._storage.pop(self._first, None)
 
 
 def plan_solve_piecemeal(budget_bytes, width, height, depth, inner_iterations, outer_iterations, forced_outer_per_pass=0,

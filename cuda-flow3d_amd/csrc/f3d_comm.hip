@@ -30,6 +30,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: older libraries may lack it
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -75,6 +76,7 @@ int load_rccl()
   F3D_SYM(AllReduce, "ncclAllReduce");
   F3D_SYM(GetErrorString, "ncclGetErrorString");
 #undef F3D_SYM
+  R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(dlsym(R.handle, "ncclCommAbort"));
   return 0;
 }
 
@@ -308,6 +310,40 @@ bool want_shm()
 
 }  // namespace
 
+namespace {
+
+// One grouped exchange.  Peers are validated BEFORE the group is opened, and once it is open ncclGroupEnd is always
+// called: a Send/Recv that fails is remembered, the group is closed, then the error is returned -- a communicator is
+// never left with an open group.  A rank that cannot post its part aborts the communicator (ncclCommAbort) so that the
+// peers already blocked in their grouped recv fail instead of waiting for ever.
+int grouped_sendrecv(const float* send_buf, const size_t* send_offset, const size_t* send_count, float* recv_buf,
+                     const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers, hipStream_t on,
+                     const char* who)
+{
+  for (int i = 0; i < n_peers; ++i)
+    if (peers[i] < 0 || peers[i] >= R.n_ranks)  // the own rank is a legal peer: RCCL pairs the send with the recv locally
+      return f3d::fail("%s: bad peer %d", who, peers[i]);
+  F3D_NCCL(R.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  for (int i = 0; i < n_peers && first == ncclSuccess; ++i) {
+    if (send_count[i]) first = R.Send(send_buf + send_offset[i], send_count[i], ncclFloat, peers[i], R.comm, on);
+    if (first == ncclSuccess && recv_count[i]) first = R.Recv(recv_buf + recv_offset[i], recv_count[i], ncclFloat, peers[i], R.comm, on);
+  }
+  const ncclResult_t end = R.GroupEnd();
+  if (first != ncclSuccess || end != ncclSuccess) {
+    const ncclResult_t e = first != ncclSuccess ? first : end;
+    if (R.CommAbort && R.comm) {
+      (void)R.CommAbort(R.comm);
+      R.comm = nullptr;
+    }
+    return f3d::fail("%s: RCCL error %d (%s); the communicator was aborted", who, static_cast<int>(e), R.GetErrorString ? R.GetErrorString(e) : "?");
+  }
+  return 0;
+}
+
+}  // namespace
+
+
 extern "C" {
 
 int f3d_comm_unique_id(void* id128)
@@ -475,19 +511,8 @@ int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size
     return shm_sendrecv(f3d_ptr<const float>(send_buf), send_offset, send_count, f3d_ptr<float>(recv_buf), recv_offset, recv_count,
                         peers, n_peers);
   if (!R.comm) return f3d::fail("f3d_comm_sendrecv: f3d_comm_init() has not been called");
-  F3D_NCCL(R.GroupStart());
-  for (int i = 0; i < n_peers; ++i) {
-    if (peers[i] < 0 || peers[i] >= R.n_ranks) {  // the own rank is a legal peer: RCCL pairs the send with the recv locally
-      (void)R.GroupEnd();
-      return f3d::fail("f3d_comm_sendrecv: bad peer %d", peers[i]);
-    }
-    if (send_count[i])
-      F3D_NCCL(R.Send(f3d_ptr<const float>(send_buf) + send_offset[i], send_count[i], ncclFloat, peers[i], R.comm, f3d::stream()));
-    if (recv_count[i])
-      F3D_NCCL(R.Recv(f3d_ptr<float>(recv_buf) + recv_offset[i], recv_count[i], ncclFloat, peers[i], R.comm, f3d::stream()));
-  }
-  F3D_NCCL(R.GroupEnd());
-  return 0;
+  return grouped_sendrecv(f3d_ptr<const float>(send_buf), send_offset, send_count, f3d_ptr<float>(recv_buf), recv_offset, recv_count,
+                          peers, n_peers, f3d::stream(), "f3d_comm_sendrecv");
 }
 
 int f3d_comm_sendrecv_begin(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
@@ -516,18 +541,9 @@ int f3d_comm_sendrecv_begin(f3d_devptr send_buf, const size_t* send_offset, cons
   }
   F3D_HIP(hipEventRecord(R.packed, f3d::stream()));
   F3D_HIP(hipStreamWaitEvent(R.side, R.packed, 0));
-  F3D_NCCL(R.GroupStart());
-  for (int i = 0; i < n_peers; ++i) {
-    if (peers[i] < 0 || peers[i] >= R.n_ranks) {
-      (void)R.GroupEnd();
-      return f3d::fail("f3d_comm_sendrecv_begin: bad peer %d", peers[i]);
-    }
-    if (send_count[i])
-      F3D_NCCL(R.Send(f3d_ptr<const float>(send_buf) + send_offset[i], send_count[i], ncclFloat, peers[i], R.comm, R.side));
-    if (recv_count[i])
-      F3D_NCCL(R.Recv(f3d_ptr<float>(recv_buf) + recv_offset[i], recv_count[i], ncclFloat, peers[i], R.comm, R.side));
-  }
-  F3D_NCCL(R.GroupEnd());
+  if (grouped_sendrecv(f3d_ptr<const float>(send_buf), send_offset, send_count, f3d_ptr<float>(recv_buf), recv_offset, recv_count, peers,
+                       n_peers, R.side, "f3d_comm_sendrecv_begin"))
+    return 1;
   F3D_HIP(hipEventRecord(R.arrived, R.side));
   R.open = true;
   return 0;

@@ -195,6 +195,8 @@ int f3d_shutdown(void)
   return 0;
 }
 
+int f3d_is_initialized(void) { return S.ready ? 1 : 0; }
+
 int f3d_device_name(char* name, size_t capacity)
 {
   F3D_REQUIRE_READY("f3d_device_name");

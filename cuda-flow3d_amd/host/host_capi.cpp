@@ -537,4 +537,12 @@ int f3d_plan_resample_source(int in_depth, int out_depth, int out_lo, int out_hi
   return 0;
 }
 
+int f3d_host_shutdown(void)
+{
+  if (!f3d_is_initialized()) return 0;
+  PiecemealReleaseArena();
+  f3d_comm_destroy();
+  return f3d_shutdown();
+}
+
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "f3d_host.h"
 #include "hip_utils.h"
 #include "optical_flow.h"
 #include "optical_flow_p.h"
@@ -151,7 +152,7 @@ int main(int argc, char** argv)
       if (pairs > 1) frame_0.Swap(frame_1);
     }
     optical_flow_p.Destroy();
-    f3d_shutdown();
+    f3d_host_shutdown();
     return 0;
   }
 
@@ -186,6 +187,6 @@ int main(int argc, char** argv)
   }
 
   optical_flow_e.Destroy();
-  f3d_shutdown();
+  f3d_host_shutdown();
   return 0;
 }

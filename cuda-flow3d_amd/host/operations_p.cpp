@@ -74,11 +74,16 @@ void ArenaFree()
   g_arena.bytes = 0;
 }
 
-// The arena, the copy queues and their events are released before the process tears the HIP runtime down (an exit handler
-// registered at first use runs before the destructors of libraries loaded earlier), not left to whatever order that takes.
+// The arena, the copy queues and their events are released by f3d_host_shutdown() (the language bindings call it from
+// their own exit hook, bin/flow3d at the end of main) or when the last piecemeal operator is destroyed.  The process exit
+// handler below is only the last resort for callers that do neither, and it touches the device only while the library is
+// still initialised: after f3d_shutdown() -- or once the HIP runtime may be tearing down -- it drops the handles unfreed.
 void ReleaseAtExit()
 {
-  static const bool registered = (std::atexit([] { PiecemealReleaseArena(); }), true);
+  static const bool registered = (std::atexit([] {
+                                    if (f3d_is_initialized()) PiecemealReleaseArena();
+                                  }),
+                                  true);
   (void)registered;
 }
 

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <utility>
 
 #include "common_utils.h"
@@ -37,6 +38,13 @@ bool OpticalFlowSlab::Initialize(const DataSize4& data_size)
     std::printf("'%s': a process computes either one rank (RCCL) or all of them (one-GPU rehearsal).\n", GetName());
     return false;
   }
+  // the in-process exchange looks a peer up by its rank number: the list must be exactly 0, 1, ..., n_ranks - 1
+  if (local_ranks_.size() > 1)
+    for (size_t i = 0; i < local_ranks_.size(); ++i)
+      if (local_ranks_[i] != static_cast<int>(i)) {
+        std::printf("'%s': with every rank in one process the rank list must be 0 .. %d in order.\n", GetName(), n_ranks_ - 1);
+        return false;
+      }
   full_size_ = data_size;
   full_size_.pitch = 0;
   const size_t max_planes = (data_size.depth + n_ranks_ - 1) / n_ranks_ + 1;
@@ -461,9 +469,18 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       const f3d_slab own = Window(D, l.rank, 0, 0);
       float m = 0.f;
       if (!Check(f3d_abs_max(l.buf[FW], W, H, D, &own, &m))) return false;
-      max_w = std::max(max_w, m);
+      // NaN does not survive every max reduction; +Inf does, so every rank sees a broken flow and fails together
+      max_w = std::isfinite(m) ? std::max(max_w, m) : std::numeric_limits<float>::infinity();
     }
     if (locals_.size() == 1 && n_ranks_ > 1 && !Check(f3d_comm_allreduce_max_f32(&max_w))) return false;
+    // a NaN or infinite flow would make the float -> int conversion below undefined and feed the halo sizing of every
+    // rank; f3d_abs_max ignores nothing, so a non-finite value here means the flow itself is broken
+    if (!std::isfinite(max_w) || !(hz > 0.f) || max_w / hz > 1.0e6f) {
+      std::printf("'%s': the flow is not finite at this level (max |w| = %g); cannot size the warp halo.\n", GetName(),
+                  static_cast<double>(max_w));
+      failed_ = true;
+      return false;
+    }
     const int reach = static_cast<int>(std::ceil(max_w / hz)) + 1;
     // Outer iterations per exchange of the increments.  Thick slabs exchange after every outer iteration (K + 1 planes, hidden
     // behind the interior where possible).  Thin slabs of a small level are latency-bound -- a launch costs the same with a

@@ -54,8 +54,11 @@ typedef struct f3d_queue_s* f3d_queue; /* a side stream for copies; NULL always 
 
 /* cuInit + cuDeviceGet + cuCtxCreate: src/utils/cuda_utils.cpp:21-57.  device < 0 picks LOCAL_RANK or 0. */
 int f3d_init(int device);
-/* cuCtxDestroy: src/main.cpp:236 */
+/* cuCtxDestroy: src/main.cpp:236.  Idempotent: drains the library stream, destroys the timing events and the stream.
+ * Memory is the owners' to free first (f3d_free, the operators' and drivers' Destroy). */
 int f3d_shutdown(void);
+/* 1 between a successful f3d_init() and f3d_shutdown(), else 0 (exit-time code asks before it touches the device) */
+int f3d_is_initialized(void);
 /* cuDeviceGetCount / cuDeviceGetName: src/utils/cuda_utils.cpp:27,44 */
 int f3d_device_count(int* count);
 int f3d_device_name(char* name, size_t capacity);

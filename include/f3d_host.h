@@ -39,6 +39,14 @@ typedef struct f3d_op_s* f3d_op;
 /* defaults of src/main.cpp:77-85 */
 void f3d_flow_default_params(f3d_flow_params* p);
 
+/* Orderly end of device use (the reference's cuCtxDestroy at src/main.cpp:236 with what this library adds around it):
+ * releases the out-of-core path's device arena, copy queues and events, destroys the RCCL communicator if one exists,
+ * then f3d_shutdown().  Idempotent; every step is a no-op when there is nothing to release.  Drivers and operators that
+ * are still alive must be destroyed BEFORE this call -- their containers are theirs to free.  Bindings call it from their
+ * own exit hook (the Python package registers it with atexit at import) so that nothing depends on the order in which
+ * the process tears libraries down. */
+int f3d_host_shutdown(void);
+
 int f3d_flow_create(f3d_flow* flow);
 /* OpticalFlowE::Initialize: allocates the 15 containers and initialises the six operators */
 int f3d_flow_initialize(f3d_flow flow, size_t width, size_t height, size_t depth);

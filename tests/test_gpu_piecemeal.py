@@ -2,6 +2,7 @@
 budget forced small (F3D_P_BUDGET_MB) so that every operator really cuts its level into several z-chunks.  Every result
 must equal the oracle's whole-volume result bit for bit (sign of zero aside): chunking, halos, the in-place resample
 order and the number of outer iterations per residency must not be visible in the output."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -133,6 +134,40 @@ def test_registration_matches_oracle(f3d, oracle, w_amp, planes):
     op.destroy()
     for x in vols + [temp]:
         x.destroy()
+
+
+def test_swapped_pair_survives_the_destruction_of_one_volume(f3d):
+    """registration_p swaps the storage of frame_1 and temp (Data3D::Swap).  Destroying one of the two afterwards must
+    release the array THAT volume holds now, not the one it was created with: the survivor keeps its memory, its
+    page-lock and its .array; and the storage table does not leak when both are gone."""
+    rng = np.random.default_rng(5)
+    W, H, D = 24, 12, 10
+    mk = lambda lo, hi: rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32)
+    f0, f1, u, v, w = mk(0, 255), mk(0, 255), mk(-1, 1), mk(-1, 1), mk(-1, 1)
+    set_budget(budget_for(1000, W, H, 6))
+    before = len(f3d.HostVolume._storage)
+    vols = [f3d.HostVolume(x.copy(), pin=(i == 1)) for i, x in enumerate((f0, f1, u, v, w))]   # frame_1 page-locked
+    temp = f3d.HostVolume(np.full(f0.shape, np.nan, np.float32))
+    f1_addr = vols[1].array.ctypes.data
+    op = make_op(f3d, "registration_p")
+    op.execute(frame_0=vols[0], frame_1=vols[1], flow_u=vols[2], flow_v=vols[3], flow_w=vols[4], temp=temp,
+               hx=1.0, hy=1.0, hz=1.0, data_size=(W, H, D), max_mag=0)
+    assert temp.array.ctypes.data == f1_addr          # temp now holds frame_1's original (page-locked) array
+    warped = vols[1].array.copy()
+    vols[1].destroy()                                  # drops the array it holds NOW (temp's original)
+    assert same(temp.array, f1)                        # the survivor still reads its data ...
+    yes = C.c_int()
+    f3d.check(f3d.hip().f3d_host_is_pinned(C.c_void_p(f1_addr), C.byref(yes)))
+    assert yes.value == 1                              # ... and keeps its page-lock
+    temp.array[0, 0, 0] = 7.0                          # the memory is alive and writable
+    assert np.isfinite(warped).all()
+    op.destroy()
+    for x in [vols[0]] + vols[2:] + [temp]:
+        x.destroy()
+    f3d.check(f3d.hip().f3d_host_is_pinned(C.c_void_p(f1_addr), C.byref(yes)))
+    assert yes.value == 0
+    assert len(f3d.HostVolume._storage) == before
+    vols[1].destroy()                                  # idempotent
 
 
 def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, eps_d):
