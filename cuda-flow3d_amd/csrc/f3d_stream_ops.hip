@@ -124,21 +124,28 @@ __global__ __launch_bounds__(kBX* kBY) void k_conv(float* __restrict__ dst, cons
 // ---- max |field| over a slab (feeds the warp halo depth of the z-slab decomposition) ---------------------------
 __global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ f, F3dGeo g, unsigned* result)
 {
-  // the maximum is taken over the BIT PATTERNS of |x|: non-negative floats order like unsigned integers, Inf sits above
-  // every finite value and NaN above Inf, so a broken flow shows up in the result instead of being skipped by fmaxf
+  // Largest FINITE |x|.  The result sizes the z reach of the warp, and the warp sends a voxel whose flow is NaN or infinite
+  // to frame_0 without looking anywhere (registration_3d.cu:60-64): such voxels need no reach, and leaving them out keeps
+  // the result finite whatever the field holds (the callers convert it to a plane count).
   const int z = g.z_lo + blockIdx.z;
-  unsigned m = 0u;
+  float m = 0.f;
   for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
     const size_t r = f3d_row(g, y, z);
-    for (int x = threadIdx.x; x < g.W; x += blockDim.x) m = max(m, __float_as_uint(fabsf(f[r + x])));
+    for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
+      const float v = fabsf(f[r + x]);
+      if (v < __builtin_inff()) m = fmaxf(m, v);  // false for NaN and for Inf
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<unsigned>(__shfl_down(static_cast<int>(m), off)));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
   // one atomic per workgroup, not per wave: thousands of atomics on one address serialise in the L2 (85 us per call on a
   // 512 x 512 x 74 slab before)
-  __shared__ unsigned wave_max[4];
+  __shared__ float wave_max[4];
   if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(result, max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3])));
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    atomicMax(result, __float_as_uint(m));  // non-negative finite floats order like uints
+  }
 }
 
 // ---- flow statistics: min / max / sum of |(u, v, w)| over a slab -------------------------------------------------------

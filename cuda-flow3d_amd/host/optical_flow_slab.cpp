@@ -469,14 +469,13 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       const f3d_slab own = Window(D, l.rank, 0, 0);
       float m = 0.f;
       if (!Check(f3d_abs_max(l.buf[FW], W, H, D, &own, &m))) return false;
-      // NaN does not survive every max reduction; +Inf does, so every rank sees a broken flow and fails together
-      max_w = std::isfinite(m) ? std::max(max_w, m) : std::numeric_limits<float>::infinity();
+      max_w = std::max(max_w, m);  // f3d_abs_max returns the largest FINITE |w|: NaN / Inf flows are warped to frame_0
     }
     if (locals_.size() == 1 && n_ranks_ > 1 && !Check(f3d_comm_allreduce_max_f32(&max_w))) return false;
-    // a NaN or infinite flow would make the float -> int conversion below undefined and feed the halo sizing of every
-    // rank; f3d_abs_max ignores nothing, so a non-finite value here means the flow itself is broken
+    // the float -> int conversion below is only defined for a finite, moderate quotient; every rank holds the same max_w here
+    // (the all-reduce above), so they fail together
     if (!std::isfinite(max_w) || !(hz > 0.f) || max_w / hz > 1.0e6f) {
-      std::printf("'%s': the flow is not finite at this level (max |w| = %g); cannot size the warp halo.\n", GetName(),
+      std::printf("'%s': the flow is out of range at this level (max |w| = %g); cannot size the warp halo.\n", GetName(),
                   static_cast<double>(max_w));
       failed_ = true;
       return false;
