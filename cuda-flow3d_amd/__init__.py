@@ -92,6 +92,7 @@ def hip():
         "f3d_phi_ksi": [_dp] * 8 + [_sz] * 3 + [C.c_float] * 5 + [_dp, _dp, _slabp],
         "f3d_solve_sweep": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
         "f3d_solve_sweep2": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
+        "f3d_solve_sweep_phi_ksi": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 6 + [_dp] * 5 + [_slabp],
         "f3d_warp": [_dp] * 5 + [_sz] * 3 + [C.c_float] * 3 + [_dp, _slabp],
         "f3d_resample_x": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
         "f3d_resample_y": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
 // HBM traffic for two sweeps: 10 reads + 3 writes per voxel instead of 20 + 6.
 struct Carry {
   float J12, J13, J23, J14, J24, J34, d1, d2, d3, ksi, pw[6], U, V, W;
+  float fx, fy, fz, ft;  // handed on to a phi/ksi second stage (k_pair8, PAIR_SP); dead code elsewhere
 };
 struct S3 {
   float u, v, w;
@@ -772,6 +773,7 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
   f_derivatives(fq, fd);
   const float fx = fq[0], fy = fq[1], fz = fq[2];
   const float ft = c[LF1] - c[LF0];
+  k.fx = fx; k.fy = fy; k.fz = fz; k.ft = ft;
 
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
   k.J12 = fx * fy; k.J13 = fx * fz; k.J23 = fy * fz;
@@ -1192,6 +1194,8 @@ inline int max_planes_per_chunk(const F3dGeo& g)
   return planes < 1 ? 1 : (planes > 0x3fffffff ? 0x3fffffff : static_cast<int>(planes));
 }
 
+#include "f3d_solve_pair8.h"
+
 // k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
 template <bool SWEEP>
 void launch_solver(const SolveArgs& a, const F3dGeo& g)
@@ -1319,9 +1323,31 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
   go(k_sweep7<TY, 0>);
 }
 
+// 0 = k_sweep7 (every row wave loads its own row), 1 = k_pair8 (DMA loader wave); F3D_PAIR8 overrides
+int pair8_enabled()
+{
+  static const int v = std::getenv("F3D_PAIR8") ? std::atoi(std::getenv("F3D_PAIR8")) : 1;
+  return v;
+}
+
+PairArgs pair_args(const SolveArgs& a)
+{
+  PairArgs p = {};
+  for (int i = 0; i < 10; ++i) p.in[i] = a.in[i];
+  for (int i = 0; i < 3; ++i) p.out[i] = a.out[i];
+  p.hx = a.hx; p.hy = a.hy; p.hz = a.hz;
+  p.alpha = a.p0;
+  p.plain_division = a.plain_division;
+  return p;
+}
+
 void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
+  if (pair8_enabled() && g.pitch % kLanes == 0) {  // the loader fetches whole 64-float row segments in 16-byte pieces
+    launch_pair8<PAIR_SS, 8>(pair_args(a), g, t.zchunk, t.xcd_remap);
+    return;
+  }
   static const int ty = std::getenv("F3D_SWEEP2_TY") ? std::atoi(std::getenv("F3D_SWEEP2_TY")) : 9;
   static const long want = std::getenv("F3D_SWEEP2_WG") ? std::atol(std::getenv("F3D_SWEEP2_WG")) : 0;
   if (ty == 8) launch_sweep2_ty<8>(a, g, want, t.zchunk, t.xcd_remap);
@@ -1417,6 +1443,43 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
   f3d::prof_begin(F3D_K_SWEEP2, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
   launch_sweep2(a, g);
   f3d::prof_end(F3D_K_SWEEP2);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                            f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                            size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                            float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                            f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep_phi_ksi");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep_phi_ksi")) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep_phi_ksi: every dimension must be at least 2");
+  if (phi_next == phi || ksi_next == ksi || phi_next == ksi || ksi_next == phi)
+    return f3d::fail("f3d_solve_sweep_phi_ksi: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)");
+  if (g.pitch % kLanes != 0)
+    return f3d::fail("f3d_solve_sweep_phi_ksi: the container pitch must be a multiple of 256 bytes (f3d_alloc_pitched gives that)");
+  if (g.z_lo == g.z_hi) return 0;
+  if (!slab_reach_ok(g, 2, "f3d_solve_sweep_phi_ksi")) return 1;
+  PairArgs a = {};
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
+  const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
+  for (int i = 0; i < 10; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
+  a.out[0] = f3d_ptr<float>(temp_du);
+  a.out[1] = f3d_ptr<float>(temp_dv);
+  a.out[2] = f3d_ptr<float>(temp_dw);
+  a.out[3] = f3d_ptr<float>(phi_next);
+  a.out[4] = f3d_ptr<float>(ksi_next);
+  a.hx = hx; a.hy = hy; a.hz = hz;
+  a.alpha = equation_alpha;
+  a.eps_s = equation_smoothness;
+  a.eps_d = equation_data;
+  f3d::prof_begin(F3D_K_SWEEP_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
+  launch_pair8<PAIR_SP, 8>(a, g, tuning().zchunk, tuning().xcd_remap);
+  f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
   F3D_HIP(hipGetLastError());
   return 0;
 }

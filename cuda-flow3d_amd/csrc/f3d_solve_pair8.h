@@ -1,0 +1,519 @@
+// Two solver stages per launch, fed by a DMA loader wave: k_pair8.
+//
+// This header is part of f3d_solve.hip (included inside its anonymous namespace, after the per-voxel arithmetic and
+// k_sweep7): it uses sweep_stage1 / sweep_stage2 / PlaneRegs / Face6 / the uniform-divisor helpers defined there.
+//
+// Why.  k_sweep7 (two fused sweeps, every row wave loads its own row with `global_load_dword`) moves the bytes of one
+// sweep for the work of two but runs at 45 % of the HBM peak in real bytes: a CU accepts ~128 vector-memory
+// instructions, a dword-per-lane load carries 256 B, so a CU never has more than ~32 KB on its way, and each of the twelve
+// waves spends ~800 cycles of every step in the issue stage while the vector unit idles (profiles/r01_summary.md,
+// tools/lab/issue_lab).  Here NO compute wave issues a load:
+//
+//   * one LOADER wave per workgroup fetches every input plane with `global_load_lds_dwordx4` -- 16 B per lane, 1 KiB per
+//     instruction, four 64-float row segments at a time, straight into an LDS ring of four raw planes (34 instructions per
+//     plane instead of ~150) -- and keeps TWO planes (68 KB per CU) in flight behind a counted `s_waitcnt vmcnt`;
+//   * the row waves read their operands from the ring with ds_read: their own row of plane q+1 (kept in registers for the
+//     three steps it serves as z+1, centre and z-1), the rows above and below of plane q, and the x-halo columns; nothing is
+//     re-published, so the 40 KB face image and the halo rings of k_sweep7 are gone and the plane-in-flight registers with them;
+//   * stage 2 works exactly like k_sweep7's: stage-1 results of the neighbours come from an LDS image (rows), DPP (lanes), the
+//     column wave (tile edges) and registers (planes).
+//
+// Two flavours of the second stage:
+//   PAIR_SS  stage 1 = sweep, stage 2 = sweep              -- f3d_solve_sweep2 (two iterations of cuda_operation_solve.cpp:222-255)
+//   PAIR_SP  stage 1 = sweep, stage 2 = phi/ksi of the NEXT outer iteration from the increments stage 1 just produced
+//                                                          -- f3d_solve_sweep_phi_ksi (last solve_3d launch of outer iteration i
+//                                                             and compute_phi_ksi_3d of iteration i+1, cuda_operation_solve.cpp:215-252)
+// Both keep the reference's expression trees operation for operation; what is shared between
+// the stages are values the reference computes twice from the same operands (fx, fy, fz, ft, the J products, U[x+1] - U[x-1]).
+//
+// Tile: TY core rows x 64 columns, marching along z.  Waves: TY + 2 row waves (rows y0-1 .. y0+TY), one column wave
+// (stage 1 of the 2 x TY voxels left and right of the tile), one loader wave.  TY = 8 -> 12 waves, three per SIMD.
+//
+// x faces.  A 16-byte DMA piece cannot mirror inside itself, so lanes beyond the volume (x >= W) hold whatever the padded
+// row holds and the reference's mirror rule is applied where it matters: at x = 0 the left neighbour IS the right one
+// (index -1 -> 1) and at x = W-1 the right one is the left one, so stage 1 substitutes the whole neighbour there (rows and
+// planes are mirrored by address, as before).  Halo pieces of tiles at an x face are fetched from columns inside the row
+// (their values are never used) so that no address leaves the container.
+
+enum { PAIR_SS = 0, PAIR_SP = 1 };
+
+struct PairArgs {
+  const float* in[10];  // f0, f1(warped), u, v, w, du, dv, dw, phi, ksi
+  float* out[5];        // temp_du, temp_dv, temp_dw; PAIR_SP: new phi, new ksi
+  float hx, hy, hz, alpha;
+  float eps_s, eps_d;   // PAIR_SP
+  int plain_division;   // timing experiments (F3D_UDIV=0)
+};
+
+template <int TY>
+struct Pair8Lds {
+  static constexpr int NR = TY + 2;                   // row waves
+  static constexpr int NJ = TY + 4;                   // ring rows: y0-2 .. y0+TY+1
+  static constexpr int NK = (NJ + 3) / 4;             // row pieces (4 rows x 64 floats = 1 KiB) per array and plane
+  static constexpr int NJP = NK * 4;                  // rows per array in the ring (padded to whole pieces)
+  static constexpr int kHaloLanes = 10 * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
+  static constexpr int NH = (kHaloLanes + 63) / 64;   // halo instructions per plane
+  static constexpr int kRowFloats = 10 * NJP * 64;
+  static constexpr int kHaloOff = kRowFloats;         // float offset of the halo area inside a slot
+  static constexpr int kSlotFloats = kRowFloats + NH * 256;
+  static constexpr int kSlots = 4;
+  static constexpr int kPerPlane = 10 * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
+};
+
+// one 1-KiB piece: lane L's 16 bytes land at lds_dst + 16 L
+__device__ __forceinline__ void dma16(const float* base, unsigned byte_off, float* lds_dst)
+{
+  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
+  asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(byte_off), "s"(base), "{m0}"(m0v) : "memory");
+}
+__device__ __forceinline__ void dma16_lane(const float* lane_addr, float* lds_dst)
+{
+  const unsigned m0v = static_cast<unsigned>(reinterpret_cast<unsigned long>((LdsFloat*)lds_dst));
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lane_addr), "{m0}"(m0v) : "memory");
+}
+
+struct CarryP {  // PAIR_SP: what phi/ksi of a voxel reuses from its sweep
+  float fx, fy, fz, ft;
+  float D[9];  // U[x+1]-U[x-1], U[y+1]-U[y-1], U[z+1]-U[z-1], then V, W: the first operation of the nine flow derivatives
+};
+
+// A.3 for one voxel from the increments after the sweep: n?.{u,v,w} = dU, dV, dW of the six neighbours
+__device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, const S3& xp, const S3& ym, const S3& yp,
+                                               const S3& zm, const S3& zp, float du, float dv_c, float dw,
+                                               const SolveDivs& dv, float eps_s, float eps_d, float& phi, float& ksi)
+{
+  float q[9] = {k.D[0] + xp.u - xm.u, k.D[1] + yp.u - ym.u, k.D[2] + zp.u - zm.u,
+                k.D[3] + xp.v - xm.v, k.D[4] + yp.v - ym.v, k.D[5] + zp.v - zm.v,
+                k.D[6] + xp.w - xm.w, k.D[7] + yp.w - ym.w, k.D[8] + zp.w - zm.w};
+  if (dv.ok && udiv_all_safe(q)) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q[3 * c + 0] = udiv(q[3 * c + 0], dv.x2);
+      q[3 * c + 1] = udiv(q[3 * c + 1], dv.y2);
+      q[3 * c + 2] = udiv(q[3 * c + 2], dv.z2);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      q[3 * c + 0] = q[3 * c + 0] / dv.x2.d;
+      q[3 * c + 1] = q[3 * c + 1] / dv.y2.d;
+      q[3 * c + 2] = q[3 * c + 2] / dv.z2.d;
+    }
+  }
+  const float dux = q[0], duy = q[1], duz = q[2], dvx = q[3], dvy = q[4], dvz = q[5], dwx = q[6], dwy = q[7], dwz = q[8];
+  phi = 1.f / (2.f * sqrtf(dux * dux + duy * duy + duz * duz + dvx * dvx + dvy * dvy + dvz * dvz + dwx * dwx +
+                           dwy * dwy + dwz * dwz + eps_s * eps_s));
+  const float fx = k.fx, fy = k.fy, fz = k.fz, ft = k.ft;
+  const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
+  const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
+  const float J14 = fx * ft, J24 = fy * ft, J34 = fz * ft, J44 = ft * ft;
+  float s = (J11 * du + J12 * dv_c + J13 * dw + J14) * du + (J12 * du + J22 * dv_c + J23 * dw + J24) * dv_c +
+            (J13 * du + J23 * dv_c + J33 * dw + J34) * dw + (J14 * du + J24 * dv_c + J34 * dw + J44);
+  s = static_cast<float>(s > 0) * s;
+  ksi = 1.f / (2.f * sqrtf(s + eps_d * eps_d));
+}
+
+template <int MODE, int TY>
+__global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                           int xcd_remap)
+{
+  using L = Pair8Lds<TY>;
+  constexpr int NR = L::NR, NJ = L::NJ, NK = L::NK, NJP = L::NJP, NH = L::NH;
+  static_assert(TY <= 32, "the column wave holds one halo voxel per lane: 2 x TY <= 64");
+  __shared__ __attribute__((aligned(16))) float ring[L::kSlots][L::kSlotFloats];
+  __shared__ float img1[2][3][NR][kLanes];  // stage-1 results of the row waves: S = U + dU' (SS) or dU' (SP)
+  __shared__ float hc1[2][3][2][32];        // the same for the two halo columns: [component][side][core row]
+
+  int tile = static_cast<int>(blockIdx.x);
+  if (xcd_remap) {
+    const int per_xcd = (n_tiles + 7) / 8;
+    tile = (tile % 8) * per_xcd + tile / 8;
+  }
+  if (tile >= n_tiles) return;
+  const int tx = tile % ntx;
+  const int ty = (tile / ntx) % nty;
+  const int tz = tile / (ntx * nty);
+
+  const int lane = threadIdx.x;
+  const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const bool colw = r == NR;
+  const bool loader = r == NR + 1;
+  const int z0 = g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int qs = z0 > 0 ? z0 - 1 : 0;        // first and last plane of stage 1
+  const int qe = z1 < g.D ? z1 : g.D - 1;
+  const int q_end = z1 < g.D ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
+  const int p_last = qe + 1;                 // last plane the ring ever holds (mirrored when it is D)
+  const int x0 = tx * kLanes;
+  const int y0 = ty * TY;
+  const bool left_face = tx == 0;
+  const bool right_face = x0 + kLanes >= g.W;
+  const bool tile_at_x_face = __builtin_amdgcn_readfirstlane(static_cast<int>(left_face || right_face)) != 0;
+
+  const int zb = qs > 0 ? qs - 1 : 0;  // lowest plane touched: byte offsets inside the chunk stay small and positive
+  const size_t base_off = f3d_row(g, 0, zb);
+  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+
+  // ================================================== loader wave ==================================================
+  if (loader) {
+    const float* base[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) base[i] = a.in[i] + base_off;
+    // row pieces: lane -> (row 4k + lane/16, floats 4 (lane%16) ..)
+    unsigned rowb[NK];
+    bool rowv[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int j = 4 * k + (lane >> 4);
+      rowv[k] = j < NJ;
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + (rowv[k] ? j : 0), g.H), 0, g.H - 1);
+      rowb[k] = static_cast<unsigned>(yrow) * row_b + static_cast<unsigned>(x0 + 4 * (lane & 15)) * 4u;
+    }
+    // halo pieces: lane' = 64 h + lane -> [array][side][row]; four floats left of the tile (x0-4 ..) or right of it (x0+64 ..)
+    const float* hptr[NH];
+    bool hv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int lp = 64 * h + lane;
+      hv[h] = lp < L::kHaloLanes;
+      const int lq = hv[h] ? lp : 0;
+      const int arr = lq / (2 * NJ);
+      const int s = (lq / NJ) & 1;
+      const int j = lq % NJ;
+      const float* b = base[0];
+#pragma unroll
+      for (int i = 1; i < 10; ++i)
+        if (arr == i) b = base[i];
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, g.H), 0, g.H - 1);
+      // tiles at an x face fetch a piece from inside the row instead (never used: the mirror rule substitutes there)
+      const int xc = s == 0 ? (left_face ? 0 : x0 - 4) : (right_face ? x0 + kLanes - 4 : x0 + kLanes);
+      hptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(g.pitch) + xc;
+    }
+    auto issue = [&](int p) {  // plane p (mirrored for the address) into slot p mod 4
+      float* slot = &ring[p & (L::kSlots - 1)][0];
+      const int zz = f3d_mir(p, g.D);
+      const unsigned poff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b)));
+      unsigned off[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) off[k] = rowb[k] + poff;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (NJ % 4 == 0 || rowv[k]) dma16(base[i], off[k], slot + (i * NJP + 4 * k) * kLanes);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        if (hv[h]) dma16_lane(hptr[h] + (poff >> 2), slot + L::kHaloOff + h * 256);
+    };
+    // prologue: planes qs-1 .. qs+2; the first three must have landed before anybody reads
+    issue(qs - 1);
+    issue(qs);
+    issue(qs + 1);
+    if (qs + 2 <= p_last) {
+      issue(qs + 2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int q = qs; q <= q_end; ++q) {
+      __syncthreads();  // B_q: slot (q-1) mod 4 was last read during step q-1
+      if (q + 3 <= p_last) {
+        issue(q + 3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");  // plane q+2 has landed, q+3 stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    return;
+  }
+
+  // ================================================= compute waves =================================================
+  FDivs fdivs = make_f_divs(a.hx, a.hy, a.hz);
+  fdivs.ok = fdivs.ok && !a.plain_division;
+  SolveDivs sdivs = {};
+  if (MODE == PAIR_SP) {
+    sdivs = make_solve_divs(a.hx, a.hy, a.hz);
+    sdivs.ok = sdivs.ok && !a.plain_division;
+  }
+
+  // row waves
+  const int y = y0 - 1 + r;
+  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int x = x0 + lane;
+  const bool core = r >= 1 && r <= TY;
+  const bool owner = core && x < g.W && y < g.H;
+  const int side = lane < 32 ? 0 : 1;
+  const int jr = r + 1;  // ring row of this wave's row
+  const unsigned xb = static_cast<unsigned>(x) * 4u;
+  // column wave: lane = side * 32 + core row (lanes beyond TY rows repeat the last row and publish nothing)
+  const bool cactive = (lane & 31) < TY;
+  const int crow = cactive ? (lane & 31) : TY - 1;
+  const int cy = y0 + crow;
+  const int cx = side == 0 ? x0 - 1 : x0 + kLanes;
+  const int jc = crow + 2;  // ring row of the column wave's voxel
+  const int e_near = side == 0 ? 3 : 0;  // element of the 4-float halo piece next to the tile, and the one beyond it
+  const int e_far = side == 0 ? 2 : 1;
+
+  float* obase[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) obase[i] = (i < 3 || MODE == PAIR_SP) ? a.out[i] + base_off : nullptr;
+  auto rowoff = [&](int yrow, int zz) {
+    return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
+  };
+
+  // raw values of one ring row (own lane) / of one halo piece element
+  auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi) {
+    const float* d = slot + j * kLanes + lane;
+    constexpr int st = NJP * kLanes;
+    p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
+    p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
+    if (with_ksi) p.ksi = d[9 * st];
+  };
+  auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi) {
+    const float* d = slot + L::kHaloOff + (s * NJ + j) * 4 + e;
+    constexpr int st = 2 * NJ * 4;
+    p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
+    p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
+    if (with_ksi) p.ksi = d[9 * st];
+  };
+
+  S3 hM = {0.f, 0.f, 0.f}, hC = {0.f, 0.f, 0.f};  // stage-1 result of planes q-2 and q-1 (SS: S = U + dU'; SP: dU')
+  float hC_dv = 0.f, hC_dw = 0.f;                 // SS: dV', dW' of plane q-1
+  Carry kC = {};
+  CarryP pC = {};
+
+  // M, C, P: finished planes q-1, q, q+1; P is read from the ring at the start of the step
+  auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) {
+    __syncthreads();  // B_q: planes q and q+1 are in the ring, img1 / hc1 of plane q-1 are complete
+    const float* Sq = &ring[q & (L::kSlots - 1)][0];
+    const float* Sp = &ring[(q + 1) & (L::kSlots - 1)][0];
+    const bool do1 = q <= qe;
+    const int b = q & 1;
+
+    float r_du = 0.f, r_dv = 0.f, r_dw = 0.f;
+    Carry kN = kC;
+    CarryP pN = pC;
+    if (do1) {
+      Face6 ym, yp, xm, xp;
+      S3 rxm = {}, rxp = {}, rym = {}, ryp = {};  // PAIR_SP: raw u, v, w of the x and y neighbours
+      int vx, vy;
+      if (colw) {
+        halo_raw(P, Sp, side, jc, e_near, true);
+        plane_finish(P);
+        PlaneRegs T;
+        halo_raw(T, Sq, side, jc - 1, e_near, false);
+        rym = {T.u, T.v, T.w};
+        plane_finish(T);
+        ym = plane_face(T);
+        halo_raw(T, Sq, side, jc + 1, e_near, false);
+        ryp = {T.u, T.v, T.w};
+        plane_finish(T);
+        yp = plane_face(T);
+        halo_raw(T, Sq, side, jc, e_far, false);
+        const S3 router = {T.u, T.v, T.w};
+        plane_finish(T);
+        const Face6 outer = plane_face(T);
+        {  // the tile's own edge column
+          const float* d = Sq + jc * kLanes + (side ? kLanes - 1 : 0);
+          constexpr int st = NJP * kLanes;
+          T.f0 = d[F0 * st]; T.f1 = d[F1 * st]; T.u = d[U * st]; T.v = d[V * st]; T.w = d[Wf * st];
+          T.su = d[DU * st]; T.dv = d[DV * st]; T.dw = d[DW * st]; T.phi = d[PHI * st];
+        }
+        const S3 rinner = {T.u, T.v, T.w};
+        plane_finish(T);
+        const Face6 inner = plane_face(T);
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) {
+          xm.v[i] = side ? inner.v[i] : outer.v[i];
+          xp.v[i] = side ? outer.v[i] : inner.v[i];
+        }
+        rxm = side ? rinner : router;
+        rxp = side ? router : rinner;
+        vx = cx;
+        vy = cy;
+      } else {
+        row_raw(P, Sp, jr, true);
+        PlaneRegs T;
+        row_raw(T, Sq, jr - 1, false);
+        rym = {T.u, T.v, T.w};
+        plane_finish(T);
+        ym = plane_face(T);
+        row_raw(T, Sq, jr + 1, false);
+        ryp = {T.u, T.v, T.w};
+        plane_finish(T);
+        yp = plane_face(T);
+        PlaneRegs X;
+        halo_raw(X, Sq, side, jr, e_near, false);
+        plane_finish(P);
+        const S3 rx = {X.u, X.v, X.w};
+        plane_finish(X);
+        const Face6 xf = plane_face(X);
+        const Face6 cf = plane_face(C);
+#pragma unroll
+        for (int i = 0; i < kNL; ++i) {
+          xm.v[i] = lane_left_or(cf.v[i], xf.v[i]);
+          xp.v[i] = lane_right_or(cf.v[i], xf.v[i]);
+        }
+        if (MODE == PAIR_SP) {
+          rxm = {lane_left_or(C.u, rx.u), lane_left_or(C.v, rx.v), lane_left_or(C.w, rx.w)};
+          rxp = {lane_right_or(C.u, rx.u), lane_right_or(C.v, rx.v), lane_right_or(C.w, rx.w)};
+        }
+        vx = x;
+        vy = y;
+        // mirror rule at the x faces of the volume (index -1 -> 1, W -> W-2): the missing neighbour is the opposite one
+        if (tile_at_x_face) {
+          if (x == 0) {
+            xm = xp;
+            rxm = rxp;
+          }
+          if (x == g.W - 1) {
+            xp = xm;
+            rxp = rxm;
+          }
+        }
+      }
+      const Face6 cfc = plane_face(C);
+      sweep_stage1(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                   fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
+      if (MODE == PAIR_SP) {
+        pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
+        pN.D[0] = rxp.u - rxm.u; pN.D[1] = ryp.u - rym.u; pN.D[2] = P.u - M.u;
+        pN.D[3] = rxp.v - rxm.v; pN.D[4] = ryp.v - rym.v; pN.D[5] = P.v - M.v;
+        pN.D[6] = rxp.w - rxm.w; pN.D[7] = ryp.w - rym.w; pN.D[8] = P.w - M.w;
+      }
+    }
+    // what a neighbour reads of this voxel in stage 2: SS U + dU', SP dU'
+    const S3 sN = MODE == PAIR_SS ? S3{C.u + r_du, C.v + r_dv, C.w + r_dw} : S3{r_du, r_dv, r_dw};
+    if (do1) {
+      if (colw) {
+        if (cactive) {
+          hc1[b][0][side][crow] = sN.u;
+          hc1[b][1][side][crow] = sN.v;
+          hc1[b][2][side][crow] = sN.w;
+        }
+      } else {
+        img1[b][0][r][lane] = sN.u;
+        img1[b][1][r][lane] = sN.v;
+        img1[b][2][r][lane] = sN.w;
+      }
+    }
+    // PAIR_SP: the sweep's result is final -- store it for the planes this chunk owns
+    if (MODE == PAIR_SP && do1 && owner && q >= z0 && q < z1) {
+      const unsigned off = xb + rowoff(yy, q);
+      gst(obase[0], off, r_du);
+      gst(obase[1], off, r_dv);
+      gst(obase[2], off, r_dw);
+    }
+
+    // stage 2 of plane t = q - 1
+    const int t = q - 1;
+    const bool do2 = core && t >= z0;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (do2) {
+      const int pb = t & 1;
+      S3 ym, yp, xm, xp, zm, zp;
+      ym.u = img1[pb][0][r - 1][lane]; ym.v = img1[pb][1][r - 1][lane]; ym.w = img1[pb][2][r - 1][lane];
+      yp.u = img1[pb][0][r + 1][lane]; yp.v = img1[pb][1][r + 1][lane]; yp.w = img1[pb][2][r + 1][lane];
+      const float eu = hc1[pb][0][side][r - 1], ev = hc1[pb][1][side][r - 1], ew = hc1[pb][2][side][r - 1];
+      xm.u = lane_left_or(hC.u, eu); xm.v = lane_left_or(hC.v, ev); xm.w = lane_left_or(hC.w, ew);
+      xp.u = lane_right_or(hC.u, eu); xp.v = lane_right_or(hC.v, ev); xp.w = lane_right_or(hC.w, ew);
+      zm = hM;
+      zp = sN;
+      // mirror rule at the faces of the volume: the missing neighbour is the opposite one (stage-1 values of voxels outside
+      // the volume are never looked at)
+      if (tile_at_x_face) {
+        if (x == 0) xm = xp;
+        if (x == g.W - 1) xp = xm;
+      }
+      if (y == 0) ym = yp;
+      if (y == g.H - 1) yp = ym;
+      if (t == 0) zm = zp;
+      if (t == g.D - 1) zp = zm;
+      if (MODE == PAIR_SS)
+        sweep_stage2(kC, xm, xp, ym, yp, zm, zp, hC_dv, hC_dw, o0, o1, o2);
+      else
+        phi_ksi_stage2(pC, xm, xp, ym, yp, zm, zp, hC.u, hC.v, hC.w, sdivs, a.eps_s, a.eps_d, o0, o1);
+    }
+    asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(sN.u), "v"(sN.v), "v"(sN.w));
+    hM = hC;
+    hC = sN;
+    hC_dv = r_dv;
+    hC_dw = r_dw;
+    kC = kN;
+    pC = pN;
+    if (do2 && owner) {
+      const unsigned off = xb + rowoff(yy, t);
+      if (MODE == PAIR_SS) {
+        gst(obase[0], off, o0);
+        gst(obase[1], off, o1);
+        gst(obase[2], off, o2);
+      } else {
+        gst(obase[3], off, o0);
+        gst(obase[4], off, o1);
+      }
+    }
+  };
+
+  __syncthreads();  // prologue barrier: planes qs-1, qs, qs+1 are in the ring
+  PlaneRegs A = {}, B = {}, Cc = {};
+  {
+    const float* Sm = &ring[(qs - 1) & (L::kSlots - 1)][0];
+    const float* S0 = &ring[qs & (L::kSlots - 1)][0];
+    if (colw) {
+      halo_raw(A, Sm, side, jc, e_near, false);
+      halo_raw(B, S0, side, jc, e_near, true);
+    } else {
+      row_raw(A, Sm, jr, false);
+      row_raw(B, S0, jr, true);
+    }
+    plane_finish(A);
+    plane_finish(B);
+  }
+  int q = qs;
+  for (; q + 2 <= q_end; q += 3) {
+    step(A, B, Cc, q);
+    step(B, Cc, A, q + 1);
+    step(Cc, A, B, q + 2);
+  }
+  if (q <= q_end) step(A, B, Cc, q);
+  if (q + 1 <= q_end) step(B, Cc, A, q + 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
+}
+
+template <int MODE, int TY>
+void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
+{
+  const int planes = g.z_hi - g.z_lo;
+  const int ntx = (g.W + kLanes - 1) / kLanes;
+  const int nty = (g.H + TY - 1) / TY;
+  // one workgroup per CU at a time: z-chunks by the round model of k_sweep7 (a chunk costs its planes plus ~7 steps of
+  // prologue and repeated stage-1 planes, 256 workgroups run per round), at least two planes per chunk
+  const long tiles = static_cast<long>(ntx) * nty;
+  const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
+  const int zc_limit = max_planes_per_chunk(g);
+  int zchunk = std::min(planes, zc_limit);
+  long best = -1;
+  for (int nzc = 1; nzc <= max_chunks; ++nzc) {
+    const int zc = (planes + nzc - 1) / nzc;
+    if (zc > zc_limit) continue;
+    const long wgs = tiles * ((planes + zc - 1) / zc);
+    const long cost = ((wgs + 255) / 256) * (zc + 7);
+    if (best < 0 || cost < best) {
+      best = cost;
+      zchunk = zc;
+    }
+  }
+  if (force_zchunk > 0) zchunk = force_zchunk;
+  zchunk = std::min(zchunk, zc_limit);
+  const int nz = (planes + zchunk - 1) / zchunk;
+  const int n_tiles = ntx * nty * nz;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
+  const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
+  hipLaunchKernelGGL((k_pair8<MODE, TY>), grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap);
+}

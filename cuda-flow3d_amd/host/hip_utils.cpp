@@ -37,3 +37,12 @@ bool FusedSweepsEnabled()
   }();
   return on;
 }
+
+bool FusedPhiKsiEnabled()
+{
+  static const bool on = [] {
+    const char* e = std::getenv("F3D_FUSED_PHI_KSI");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}

@@ -26,5 +26,7 @@ void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_heig
 void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_height, size_t device_pitch);
 // Inner sweeps are launched in fused pairs unless F3D_FUSED_SWEEPS=0 (A/B timing; the results are bit-identical).
 bool FusedSweepsEnabled();
+// The last sweep of an outer iteration and the phi/ksi of the next one are one launch unless F3D_FUSED_PHI_KSI=0.
+bool FusedPhiKsiEnabled();
 
 #endif

@@ -248,6 +248,30 @@ void CudaOperationResample::ResampleZ(DevicePtr input, DevicePtr output, DataSiz
 
 // ---- solve (cuda_operation_solve.cpp:75-281) ------------------------------------------------------------------
 
+bool CudaOperationSolve::EnsureWeightScratch()
+{
+  if (phi_alt_ && ksi_alt_) return true;
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  for (DevicePtr* p : {&phi_alt_, &ksi_alt_}) {
+    if (*p) continue;
+    size_t pitch = 0;
+    if (f3d_alloc_pitched(p, &pitch, dev_container_size_.width * sizeof(float), rows) != 0 || pitch != dev_container_size_.pitch) {
+      if (*p) f3d_free(*p);
+      *p = 0;
+      return false;  // no room (or another pitch): the unfused schedule needs no scratch
+    }
+  }
+  return true;
+}
+
+void CudaOperationSolve::Destroy()
+{
+  if (phi_alt_) f3d_free(phi_alt_);
+  if (ksi_alt_) f3d_free(ksi_alt_);
+  phi_alt_ = ksi_alt_ = 0;
+  CudaOperationBase::Destroy();
+}
+
 void CudaOperationSolve::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
@@ -300,24 +324,44 @@ void CudaOperationSolve::Execute(OperationParameters& params)
   CheckDeviceError(f3d_memset2d(*dw_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
 
   const size_t w = data_size.width, h = data_size.height, d = data_size.depth;
+  // Launch schedule of one outer iteration (the same bit pattern whichever way it is cut):
+  //   phi/ksi, then the sweeps in fused pairs (f3d_solve_sweep2: the intermediate increment stays on chip, one buffer swap per
+  //   pair); an odd count ends with a single sweep, and when another outer iteration follows that sweep and the phi/ksi of the
+  //   NEXT iteration are one launch (f3d_solve_sweep_phi_ksi) writing into the second weight pair.  Defaults (5 sweeps): 3
+  //   launches per outer iteration instead of the reference's 6.
+  const bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && inner_iterations_count % 2 == 1 &&
+                            outer_iterations_count > 1 && dev_container_size_.pitch % 256 == 0 && EnsureWeightScratch();
+  DevicePtr phi_cur = dev_phi, ksi_cur = dev_ksi, phi_nxt = phi_alt_, ksi_nxt = ksi_alt_;
+  bool weights_ready = false;
   for (size_t i = 0; i < outer_iterations_count; ++i) {
-    if (CheckDeviceError(f3d_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr,
-                                     *dw_ptr, w, h, d, hx, hy, hz, equation_smoothness, equation_data, dev_phi,
-                                     dev_ksi, slab_)))
+    if (!weights_ready &&
+        CheckDeviceError(f3d_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, w, h, d,
+                                     hx, hy, hz, equation_smoothness, equation_data, phi_cur, ksi_cur, slab_)))
       return;
-    // Sweeps go in fused pairs (f3d_solve_sweep2: the intermediate increment stays on chip, one buffer swap per pair);
-    // an odd count ends with a single sweep.  The result is the same bit pattern either way.
+    weights_ready = false;
     for (size_t j = 0; j < inner_iterations_count;) {
       const bool pair = FusedSweepsEnabled() && j + 2 <= inner_iterations_count;
-      const int status =
-          pair ? f3d_solve_sweep2(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
-                                  dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_)
-               : f3d_solve_sweep(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
-                                 dev_phi, dev_ksi, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      const bool with_weights = !pair && fuse_weights && j + 1 == inner_iterations_count && i + 1 < outer_iterations_count;
+      int status;
+      if (pair)
+        status = f3d_solve_sweep2(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur,
+                                  ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      else if (with_weights)
+        status = f3d_solve_sweep_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
+                                         phi_cur, ksi_cur, w, h, d, hx, hy, hz, equation_alpha, equation_smoothness, equation_data,
+                                         *tdu_ptr, *tdv_ptr, *tdw_ptr, phi_nxt, ksi_nxt, slab_);
+      else
+        status = f3d_solve_sweep(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur,
+                                 ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
       if (CheckDeviceError(status)) return;
       std::swap(*du_ptr, *tdu_ptr);
       std::swap(*dv_ptr, *tdv_ptr);
       std::swap(*dw_ptr, *tdw_ptr);
+      if (with_weights) {
+        std::swap(phi_cur, phi_nxt);
+        std::swap(ksi_cur, ksi_nxt);
+        weights_ready = true;
+      }
       j += pair ? 2 : 1;
     }
     if (!silent) {

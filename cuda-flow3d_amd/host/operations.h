@@ -109,8 +109,15 @@ class CudaOperationSolve : public CudaOperationBase {
   CudaOperationSolve() : CudaOperationBase("CUDA Solve") {}
   bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
   void Execute(OperationParameters& params) override;
+  void Destroy() override;
 
   bool silent = false;
+
+ private:
+  // second phi / ksi pair for the fused "last sweep + next phi/ksi" launch (f3d_solve_sweep_phi_ksi writes the weights of the
+  // next outer iteration while other tiles still read the current ones); container sized, allocated on first use
+  bool EnsureWeightScratch();
+  DevicePtr phi_alt_ = 0, ksi_alt_ = 0;
 };
 
 #endif

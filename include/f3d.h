@@ -153,6 +153,18 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
                      size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
                      f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
 
+/* The last solve_3d sweep of an outer iteration AND compute_phi_ksi_3d of the next one in one launch: temp_d* receive the
+ * sweep (what f3d_solve_sweep would write), phi_next / ksi_next what f3d_phi_ksi would then compute from temp_d* -- bit for
+ * bit; the kernel reads frame_0 .. ksi once for both.  Replaces the launch pair cuda_operation_solve.cpp:246-252 (last j) +
+ * :215-221 (next i).  phi_next / ksi_next must be buffers of their own: other tiles are still reading phi / ksi while this
+ * launch writes (the operator ping-pongs two pairs).  A slab window [z_lo, z_hi) needs planes z_lo-2 .. z_hi+1 of every input
+ * inside the container; the container pitch must be a multiple of 256 bytes. */
+int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                            f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                            size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                            float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                            f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
+
 /* registration_3d, 12 args: cuda_operation_registration.cpp:110-122; kernel src/kernels/registration_3d.cu:28-82 */
 int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
              size_t width, size_t height, size_t depth, float hx, float hy, float hz, f3d_devptr output,
@@ -189,7 +201,7 @@ int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height,
 
 /* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
 
-enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_COUNT = 3 };
+enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_SWEEP_PHI_KSI = 3, F3D_K_COUNT = 4 };
 /* enable = 1 brackets every launch of the solver kernels (phi/ksi, one sweep, two fused sweeps) with events on the library stream */
 int f3d_prof_enable(int enable);
 int f3d_prof_reset(void);

@@ -327,6 +327,62 @@ def test_two_fused_sweeps_slab_window(f3d, oracle, dims, cdims):
         dev.close()
 
 
+@pytest.mark.parametrize("dims,cdims", CASES + BIG_CASES)
+@pytest.mark.parametrize("h", SPACINGS)
+def test_sweep_and_next_phi_ksi_fused(f3d, oracle, dims, cdims, h):
+    """f3d_solve_sweep_phi_ksi = f3d_solve_sweep followed by f3d_phi_ksi on its result, bit for bit (and equal to the oracle's
+    sweep + phi/ksi): the increments reach the weights of the next outer iteration without a trip through HBM."""
+    rng = np.random.default_rng(hash((dims, h, 3)) % 2**32)
+    W, H, D = dims
+    arrs = solver_inputs(rng, dims, cdims)
+    alpha, eps_s, eps_d = 7.5, 0.001, 0.002
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, eps_s, eps_d)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(f3d.hip().f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs, None))
+        for name, g, e in zip(("du", "dv", "dw", "phi", "ksi"), outs, list(s1) + [phi_n, ksi_n]):
+            got = dev.get(g)[:D, :H, :W]
+            assert bit_same(got, e[:D, :H, :W]), \
+                f"{name}: {np.count_nonzero(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))} voxels differ"
+        # the weights must go to buffers of their own
+        assert f3d.hip().f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs[:3], phi, outs[4], None) != 0
+        assert b"alias" in f3d.hip().f3d_last_error()
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:5] + BIG_CASES[:1])
+def test_sweep_and_next_phi_ksi_slab_window(f3d, oracle, dims, cdims):
+    """Slab launch of the fused sweep + phi/ksi: window [z_lo, z_hi) with two halo planes on either side inside the container."""
+    rng = np.random.default_rng(12)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, 0.001, 0.001)
+    z_lo, z_hi = (1, D - 1) if D < 10 else (3, D - 2)
+    z_base = max(0, z_lo - 2)
+    top = min(D, z_hi + 2)
+    planes = top - z_base
+    sub = lambda a: np.ascontiguousarray(a[z_base:top])
+    dev = Dev(f3d, (cdims[0], cdims[1], planes))
+    try:
+        ptr = [dev.put(sub(a)) for a in arrs] + [dev.put(sub(phi_o)), dev.put(sub(ksi_o))]
+        outs = [dev.out() for _ in range(5)]
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        f3d.check(f3d.hip().f3d_solve_sweep_phi_ksi(*ptr, W, H, D, *h, 7.5, 0.001, 0.001, *outs, C.byref(slab)))
+        for g, e in zip(outs, list(s1) + [phi_n, ksi_n]):
+            assert bit_same(dev.get(g)[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("value", [0, 0xFF, 0x3C])
 def test_memset2d_sub_box(f3d, value):
     """f3d_memset2d (cuMemsetD2D8 of optical_flow_e.cpp:305-310): width_bytes of every row set, the rest of the pitch and

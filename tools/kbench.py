@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
 (f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
-   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|phi|both]
+   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|phi|both]
 """
 import argparse
 import ctypes as C
@@ -38,6 +38,7 @@ def main():
     cont.set_current()
     phi, ksi = cont.alloc(fill=0), cont.alloc(fill=0)
     out = [cont.alloc(fill=0) for _ in range(3)]
+    phi2, ksi2 = cont.alloc(fill=0), cont.alloc(fill=0)
     h = (1.0, 1.0, 1.0)
     pkg.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
     pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
@@ -51,9 +52,12 @@ def main():
             pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
         if a.kernel in ("sweep2", "both"):
             pkg.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+        if a.kernel in ("sweeppk", "both"):
+            pkg.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
     pkg.sync()
     # sweep2: two sweeps of algorithmic work (2 x 52 B per voxel) per launch
-    for kid, name, bpv in ((0, "phi_ksi", 40.0), (1, "sweep", 52.0), (2, "sweep2", 104.0)):
+    # sweeppk: one sweep + the next phi/ksi (52 + 40 B per voxel) per launch
+    for kid, name, bpv in ((0, "phi_ksi", 40.0), (1, "sweep", 52.0), (2, "sweep2", 104.0), (3, "sweeppk", 92.0)):
         ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
         hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox))
         if n.value:
