@@ -113,7 +113,9 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
   ksi = 1.f / (2.f * sqrtf(s + eps_d * eps_d));
 }
 
-template <int MODE, int TY>
+// ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
+// arithmetic (LDS traffic, barriers and stores stay), bit 2 = the compute waves only keep the barriers
+template <int MODE, int TY, int ABL = 0>
 __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                            int xcd_remap)
 {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     __syncthreads();
     for (int q = qs; q <= q_end; ++q) {
       __syncthreads();  // B_q: slot (q-1) mod 4 was last read during step q-1
-      if (q + 3 <= p_last) {
+      if (q + 3 <= p_last && !(ABL & 1)) {
         issue(q + 3);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");  // plane q+2 has landed, q+3 stays in flight
       } else {
@@ -287,37 +289,64 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   Carry kC = {};
   CarryP pC = {};
 
-  // M, C, P: finished planes q-1, q, q+1; P is read from the ring at the start of the step
+  // Raw neighbours of a plane for stage 1 -- the rows above and below and the x-halo column (column wave: its two y
+  // neighbours and the column beyond).  They are fetched at the END of the step before the one that uses them: the plane
+  // has been in the ring since the barrier before last, so the reads need no barrier of their own, and issued there they
+  // run in the shadow of the other waves' arithmetic instead of in a burst of all twelve waves right after the barrier
+  // (with every wave in the same phase the LDS pipe -- 128 B per clock for 4-byte reads -- was a phase of its own, a third
+  // of the step, during which the vector unit idled).
+  // They are finished (S = U + dU) right there, so six values per neighbour cross the barrier, not nine; PAIR_SP also keeps
+  // U[y+1] - U[y-1] (the first operation of its y derivatives) and the raw U, V, W of the halo column.
+  Face6 nYm = {}, nYp = {}, nX = {};
+  S3 nDy = {0.f, 0.f, 0.f}, nXr = {0.f, 0.f, 0.f};
+  auto fetch_neighbours = [&](const float* S) {
+    PlaneRegs T0, T1, T2;
+    if (colw) {
+      halo_raw(T0, S, side, jc - 1, e_near, false);
+      halo_raw(T1, S, side, jc + 1, e_near, false);
+      halo_raw(T2, S, side, jc, e_far, false);
+    } else {
+      row_raw(T0, S, jr - 1, false);
+      row_raw(T1, S, jr + 1, false);
+      halo_raw(T2, S, side, jr, e_near, false);
+    }
+    if (MODE == PAIR_SP) {
+      nDy = {T1.u - T0.u, T1.v - T0.v, T1.w - T0.w};
+      nXr = {T2.u, T2.v, T2.w};
+    }
+    plane_finish(T0);
+    plane_finish(T1);
+    plane_finish(T2);
+    nYm = plane_face(T0);
+    nYp = plane_face(T1);
+    nX = plane_face(T2);
+  };
+
+  // M, C, P: finished planes q-1, q, q+1; P is read from the ring at the start of the step.  Stage 1 is computed in every
+  // step, also in the one extra step of the top chunk (q = D, from whatever the ring holds): its results are neither stored
+  // nor looked at there, and an unconditional body spares the carried values a copy per step.
   auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) {
-    __syncthreads();  // B_q: planes q and q+1 are in the ring, img1 / hc1 of plane q-1 are complete
+    __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
+    if (ABL & 4) return;
     const float* Sq = &ring[q & (L::kSlots - 1)][0];
     const float* Sp = &ring[(q + 1) & (L::kSlots - 1)][0];
     const bool do1 = q <= qe;
     const int b = q & 1;
 
     float r_du = 0.f, r_dv = 0.f, r_dw = 0.f;
-    Carry kN = kC;
-    CarryP pN = pC;
-    if (do1) {
-      Face6 ym, yp, xm, xp;
-      S3 rxm = {}, rxp = {}, rym = {}, ryp = {};  // PAIR_SP: raw u, v, w of the x and y neighbours
+    Carry kN;
+    CarryP pN;
+    {
+      Face6 xm, xp;
+      const Face6 ym = nYm, yp = nYp;
+      S3 rxm = {}, rxp = {};  // PAIR_SP: raw u, v, w of the x neighbours
       int vx, vy;
       if (colw) {
         halo_raw(P, Sp, side, jc, e_near, true);
         plane_finish(P);
+        const S3 router = nXr;
+        const Face6 outer = nX;
         PlaneRegs T;
-        halo_raw(T, Sq, side, jc - 1, e_near, false);
-        rym = {T.u, T.v, T.w};
-        plane_finish(T);
-        ym = plane_face(T);
-        halo_raw(T, Sq, side, jc + 1, e_near, false);
-        ryp = {T.u, T.v, T.w};
-        plane_finish(T);
-        yp = plane_face(T);
-        halo_raw(T, Sq, side, jc, e_far, false);
-        const S3 router = {T.u, T.v, T.w};
-        plane_finish(T);
-        const Face6 outer = plane_face(T);
         {  // the tile's own edge column
           const float* d = Sq + jc * kLanes + (side ? kLanes - 1 : 0);
           constexpr int st = NJP * kLanes;
@@ -338,21 +367,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         vy = cy;
       } else {
         row_raw(P, Sp, jr, true);
-        PlaneRegs T;
-        row_raw(T, Sq, jr - 1, false);
-        rym = {T.u, T.v, T.w};
-        plane_finish(T);
-        ym = plane_face(T);
-        row_raw(T, Sq, jr + 1, false);
-        ryp = {T.u, T.v, T.w};
-        plane_finish(T);
-        yp = plane_face(T);
-        PlaneRegs X;
-        halo_raw(X, Sq, side, jr, e_near, false);
         plane_finish(P);
-        const S3 rx = {X.u, X.v, X.w};
-        plane_finish(X);
-        const Face6 xf = plane_face(X);
+        const S3 rx = nXr;
+        const Face6 xf = nX;
         const Face6 cf = plane_face(C);
 #pragma unroll
         for (int i = 0; i < kNL; ++i) {
@@ -378,14 +395,19 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         }
       }
       const Face6 cfc = plane_face(C);
+      if (ABL & 2) {
+        kN = Carry{};
+        r_du = xm.v[0] + xp.v[1] + ym.v[2] + yp.v[3] + M.su + P.sv + C.ksi + rxm.u + nDy.v;
+        r_dv = xm.v[4] + xp.v[5] + ym.v[0] + yp.v[1] + M.f0 + P.f1 + C.u + rxp.w + nDy.u;
+        r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
+        kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
+      } else
       sweep_stage1(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
                    fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
-      if (MODE == PAIR_SP) {
-        pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
-        pN.D[0] = rxp.u - rxm.u; pN.D[1] = ryp.u - rym.u; pN.D[2] = P.u - M.u;
-        pN.D[3] = rxp.v - rxm.v; pN.D[4] = ryp.v - rym.v; pN.D[5] = P.v - M.v;
-        pN.D[6] = rxp.w - rxm.w; pN.D[7] = ryp.w - rym.w; pN.D[8] = P.w - M.w;
-      }
+      pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
+      pN.D[0] = rxp.u - rxm.u; pN.D[1] = nDy.u; pN.D[2] = P.u - M.u;
+      pN.D[3] = rxp.v - rxm.v; pN.D[4] = nDy.v; pN.D[5] = P.v - M.v;
+      pN.D[6] = rxp.w - rxm.w; pN.D[7] = nDy.w; pN.D[8] = P.w - M.w;
     }
     // what a neighbour reads of this voxel in stage 2: SS U + dU', SP dU'
     const S3 sN = MODE == PAIR_SS ? S3{C.u + r_du, C.v + r_dv, C.w + r_dw} : S3{r_du, r_dv, r_dw};
@@ -434,7 +456,11 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       if (y == g.H - 1) yp = ym;
       if (t == 0) zm = zp;
       if (t == g.D - 1) zp = zm;
-      if (MODE == PAIR_SS)
+      if (ABL & 2) {
+        o0 = xm.u + xp.v + ym.w + kC.J12;
+        o1 = yp.u + zm.v + zp.w + kC.d1;
+        o2 = xm.w + yp.v + zp.u + kC.pw[0] + hC_dv + hC_dw;
+      } else if (MODE == PAIR_SS)
         sweep_stage2(kC, xm, xp, ym, yp, zm, zp, hC_dv, hC_dw, o0, o1, o2);
       else
         phi_ksi_stage2(pC, xm, xp, ym, yp, zm, zp, hC.u, hC.v, hC.w, sdivs, a.eps_s, a.eps_d, o0, o1);
@@ -457,6 +483,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         gst(obase[4], off, o1);
       }
     }
+    fetch_neighbours(Sp);  // for step q+1
   };
 
   __syncthreads();  // prologue barrier: planes qs-1, qs, qs+1 are in the ring
@@ -473,6 +500,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     }
     plane_finish(A);
     plane_finish(B);
+    fetch_neighbours(S0);
   }
   int q = qs;
   for (; q + 2 <= q_end; q += 3) {
@@ -515,5 +543,13 @@ void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
   const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
-  hipLaunchKernelGGL((k_pair8<MODE, TY>), grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap);
+  static const int abl = std::getenv("F3D_ABLATE8") ? std::atoi(std::getenv("F3D_ABLATE8")) : 0;
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
+  if constexpr (MODE == PAIR_SS) {
+    if (abl == 1) return go(k_pair8<MODE, TY, 1>);
+    if (abl == 2) return go(k_pair8<MODE, TY, 2>);
+    if (abl == 3) return go(k_pair8<MODE, TY, 3>);
+    if (abl == 4) return go(k_pair8<MODE, TY, 4>);
+  }
+  go(k_pair8<MODE, TY, 0>);
 }

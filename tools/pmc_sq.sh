@@ -20,7 +20,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("$O/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_sweep" in r["Kernel_Name"] or "k_phiksi" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("k_sweep", "k_phiksi", "k_pair8")):
             agg[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open("$O/summary.csv", "w") as out:
     out.write("kernel,counter,launches,avg\n")
