@@ -60,6 +60,18 @@ struct Pair8Lds {
   static constexpr int kPerPlane = 10 * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
 };
 
+// A wave-uniform pointer moved into scalar registers for good: the "s" operands of the hand-issued memory instructions need
+// one, and the compiler does not always insert the v_readfirstlane itself when it has formed the address with vector
+// 64-bit arithmetic (it then hands the assembler a VGPR pair: "invalid operand for instruction").
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // one 1-KiB piece: lane L's 16 bytes land at lds_dst + 16 L
 __device__ __forceinline__ void dma16(const float* base, unsigned byte_off, float* lds_dst)
 {
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   if (loader) {
     const float* base[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) base[i] = a.in[i] + base_off;
+    for (int i = 0; i < 10; ++i) base[i] = uniform_ptr(a.in[i] + base_off);
     // row pieces: lane -> (row 4k + lane/16, floats 4 (lane%16) ..)
     unsigned rowb[NK];
     bool rowv[NK];
@@ -262,21 +274,21 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 
   float* obase[5];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) obase[i] = (i < 3 || MODE == PAIR_SP) ? a.out[i] + base_off : nullptr;
-  auto rowoff = [&](int yrow, int zz) {
+  for (int i = 0; i < 5; ++i) obase[i] = (i < 3 || MODE == PAIR_SP) ? uniform_ptr(a.out[i] + base_off) : nullptr;
+  auto rowoff = [&](int yrow, int zz) __attribute__((always_inline)) {
     return static_cast<unsigned>(__builtin_amdgcn_readfirstlane(
         static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b + static_cast<unsigned>(yrow) * row_b)));
   };
 
   // raw values of one ring row (own lane) / of one halo piece element
-  auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi) {
+  auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi) __attribute__((always_inline)) {
     const float* d = slot + j * kLanes + lane;
     constexpr int st = NJP * kLanes;
     p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
     p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
     if (with_ksi) p.ksi = d[9 * st];
   };
-  auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi) {
+  auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi) __attribute__((always_inline)) {
     const float* d = slot + L::kHaloOff + (s * NJ + j) * 4 + e;
     constexpr int st = 2 * NJ * 4;
     p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
@@ -299,9 +311,10 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   // U[y+1] - U[y-1] (the first operation of its y derivatives) and the raw U, V, W of the halo column.
   Face6 nYm = {}, nYp = {}, nX = {};
   S3 nDy = {0.f, 0.f, 0.f}, nXr = {0.f, 0.f, 0.f};
-  auto fetch_neighbours = [&](const float* S) {
+  auto fetch_neighbours = [&](auto colw_c, const float* S) __attribute__((always_inline)) {
+    constexpr bool CW = decltype(colw_c)::value;
     PlaneRegs T0, T1, T2;
-    if (colw) {
+    if constexpr (CW) {
       halo_raw(T0, S, side, jc - 1, e_near, false);
       halo_raw(T1, S, side, jc + 1, e_near, false);
       halo_raw(T2, S, side, jc, e_far, false);
@@ -325,7 +338,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   // M, C, P: finished planes q-1, q, q+1; P is read from the ring at the start of the step.  Stage 1 is computed in every
   // step, also in the one extra step of the top chunk (q = D, from whatever the ring holds): its results are neither stored
   // nor looked at there, and an unconditional body spares the carried values a copy per step.
-  auto step = [&](PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) {
+  auto step = [&](auto colw_c, PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) __attribute__((always_inline)) {
+    constexpr bool CW = decltype(colw_c)::value;  // the column wave runs a loop of its own: no value merges with the row waves
     __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
     if (ABL & 4) return;
     const float* Sq = &ring[q & (L::kSlots - 1)][0];
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       const Face6 ym = nYm, yp = nYp;
       S3 rxm = {}, rxp = {};  // PAIR_SP: raw u, v, w of the x neighbours
       int vx, vy;
-      if (colw) {
+      if constexpr (CW) {
         halo_raw(P, Sp, side, jc, e_near, true);
         plane_finish(P);
         const S3 router = nXr;
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     // what a neighbour reads of this voxel in stage 2: SS U + dU', SP dU'
     const S3 sN = MODE == PAIR_SS ? S3{C.u + r_du, C.v + r_dv, C.w + r_dw} : S3{r_du, r_dv, r_dw};
     if (do1) {
-      if (colw) {
+      if constexpr (CW) {
         if (cactive) {
           hc1[b][0][side][crow] = sN.u;
           hc1[b][1][side][crow] = sN.v;
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 
     // stage 2 of plane t = q - 1
     const int t = q - 1;
-    const bool do2 = core && t >= z0;
+    const bool do2 = !CW && core && t >= z0;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (do2) {
       const int pb = t & 1;
@@ -483,15 +497,16 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         gst(obase[4], off, o1);
       }
     }
-    fetch_neighbours(Sp);  // for step q+1
+    fetch_neighbours(colw_c, Sp);  // for step q+1
   };
 
   __syncthreads();  // prologue barrier: planes qs-1, qs, qs+1 are in the ring
   PlaneRegs A = {}, B = {}, Cc = {};
-  {
-    const float* Sm = &ring[(qs - 1) & (L::kSlots - 1)][0];
-    const float* S0 = &ring[qs & (L::kSlots - 1)][0];
-    if (colw) {
+  const float* Sm = &ring[(qs - 1) & (L::kSlots - 1)][0];
+  const float* S0 = &ring[qs & (L::kSlots - 1)][0];
+  auto march = [&](auto colw_c) __attribute__((always_inline)) {
+    constexpr bool CW = decltype(colw_c)::value;
+    if constexpr (CW) {
       halo_raw(A, Sm, side, jc, e_near, false);
       halo_raw(B, S0, side, jc, e_near, true);
     } else {
@@ -500,16 +515,18 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     }
     plane_finish(A);
     plane_finish(B);
-    fetch_neighbours(S0);
-  }
-  int q = qs;
-  for (; q + 2 <= q_end; q += 3) {
-    step(A, B, Cc, q);
-    step(B, Cc, A, q + 1);
-    step(Cc, A, B, q + 2);
-  }
-  if (q <= q_end) step(A, B, Cc, q);
-  if (q + 1 <= q_end) step(B, Cc, A, q + 1);
+    fetch_neighbours(colw_c, S0);
+    int q = qs;
+    for (; q + 2 <= q_end; q += 3) {
+      step(colw_c, A, B, Cc, q);
+      step(colw_c, B, Cc, A, q + 1);
+      step(colw_c, Cc, A, B, q + 2);
+    }
+    if (q <= q_end) step(colw_c, A, B, Cc, q);
+    if (q + 1 <= q_end) step(colw_c, B, Cc, A, q + 1);
+  };
+  if (colw) march(std::true_type{});
+  else march(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
 }
 
