@@ -50,13 +50,16 @@ struct Pair8Lds {
   static constexpr int NR = TY + 2;                   // row waves
   static constexpr int NJ = TY + 4;                   // ring rows: y0-2 .. y0+TY+1
   static constexpr int NK = (NJ + 3) / 4;             // row pieces (4 rows x 64 floats = 1 KiB) per array and plane
-  static constexpr int NJP = NK * 4;                  // rows per array in the ring (padded to whole pieces)
+  static constexpr int NJP = NJ;                      // rows per array in the ring (a partial last piece masks its surplus lanes)
   static constexpr int kHaloLanes = 10 * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
   static constexpr int NH = (kHaloLanes + 63) / 64;   // halo instructions per plane
   static constexpr int kRowFloats = 10 * NJP * 64;
   static constexpr int kHaloOff = kRowFloats;         // float offset of the halo area inside a slot
   static constexpr int kSlotFloats = kRowFloats + NH * 256;
-  static constexpr int kSlots = 4;
+  // Three slots hold TWO planes in flight: everything a step reads of plane p (its rows as z+1 plane during step p-1, its
+  // neighbour rows and halo columns at the end of step p-1) has been read when barrier B_p falls, so at step q the loader
+  // refills the slot of plane q with plane q+3 while q+1 is being read and q+2 is landing.
+  static constexpr int kSlots = 3;
   static constexpr int kPerPlane = 10 * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
 };
 
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 
   // ================================================== loader wave ==================================================
   if (loader) {
+    // the youngest wave of its SIMD would otherwise get the issue slots the arithmetic of the older two leaves over
+    __builtin_amdgcn_s_setprio(3);
     const float* base[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) base[i] = uniform_ptr(a.in[i] + base_off);
@@ -204,8 +209,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       const int xc = s == 0 ? (left_face ? 0 : x0 - 4) : (right_face ? x0 + kLanes - 4 : x0 + kLanes);
       hptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(g.pitch) + xc;
     }
-    auto issue = [&](int p) {  // plane p (mirrored for the address) into slot p mod 4
-      float* slot = &ring[p & (L::kSlots - 1)][0];
+    auto issue = [&](int p) {  // plane p (mirrored for the address) into slot (p - (qs-1)) mod 3
+      float* slot = &ring[(p - qs + 1) % L::kSlots][0];
       const int zz = f3d_mir(p, g.D);
       const unsigned poff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b)));
       unsigned off[NK];
@@ -222,25 +227,23 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       for (int h = 0; h < NH; ++h)
         if (hv[h]) dma16_lane(hptr[h] + (poff >> 2), slot + L::kHaloOff + h * 256);
     };
-    // prologue: planes qs-1 .. qs+2; the first three must have landed before anybody reads
+    // prologue: planes qs-1, qs, qs+1 fill the three slots and must have landed before anybody reads
     issue(qs - 1);
     issue(qs);
     issue(qs + 1);
-    if (qs + 2 <= p_last) {
-      issue(qs + 2);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int q = qs; q <= q_end; ++q) {
-      __syncthreads();  // B_q: slot (q-1) mod 4 was last read during step q-1
-      if (q + 3 <= p_last && !(ABL & 1)) {
-        issue(q + 3);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");  // plane q+2 has landed, q+3 stays in flight
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // B_q: the slots of planes q-1 and q have been read for the last time
+      if (!(ABL & 1)) {
+        if (q == qs && q + 2 <= p_last) issue(q + 2);  // steady state: issued one step ago
+        if (q + 3 <= p_last) {
+          issue(q + 3);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");  // plane q+2 has landed, q+3 stays in flight
+          continue;
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     return;
   }
@@ -311,9 +314,21 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   // U[y+1] - U[y-1] (the first operation of its y derivatives) and the raw U, V, W of the halo column.
   Face6 nYm = {}, nYp = {}, nX = {};
   S3 nDy = {0.f, 0.f, 0.f}, nXr = {0.f, 0.f, 0.f};
+  Face6 nIn = {};                    // column wave: the tile's own edge column
+  S3 nInr = {0.f, 0.f, 0.f};
   auto fetch_neighbours = [&](auto colw_c, const float* S) __attribute__((always_inline)) {
     constexpr bool CW = decltype(colw_c)::value;
     PlaneRegs T0, T1, T2;
+    if constexpr (CW) {
+      PlaneRegs T;
+      const float* d = S + jc * kLanes + (side ? kLanes - 1 : 0);
+      constexpr int st = NJP * kLanes;
+      T.f0 = d[F0 * st]; T.f1 = d[F1 * st]; T.u = d[U * st]; T.v = d[V * st]; T.w = d[Wf * st];
+      T.su = d[DU * st]; T.dv = d[DV * st]; T.dw = d[DW * st]; T.phi = d[PHI * st];
+      nInr = {T.u, T.v, T.w};
+      plane_finish(T);
+      nIn = plane_face(T);
+    }
     if constexpr (CW) {
       halo_raw(T0, S, side, jc - 1, e_near, false);
       halo_raw(T1, S, side, jc + 1, e_near, false);
@@ -338,12 +353,14 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   // M, C, P: finished planes q-1, q, q+1; P is read from the ring at the start of the step.  Stage 1 is computed in every
   // step, also in the one extra step of the top chunk (q = D, from whatever the ring holds): its results are neither stored
   // nor looked at there, and an unconditional body spares the carried values a copy per step.
-  auto step = [&](auto colw_c, PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) __attribute__((always_inline)) {
+  // SLOT = ring slot of plane q+1, a compile-time constant: slots are numbered from plane qs-1 and the march is unrolled
+  // three steps deep, so every LDS address below is a lane offset plus an immediate
+  auto step = [&](auto colw_c, auto slot_c, PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) __attribute__((always_inline)) {
     constexpr bool CW = decltype(colw_c)::value;  // the column wave runs a loop of its own: no value merges with the row waves
+    constexpr int SLOT = decltype(slot_c)::value;
     __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
     if (ABL & 4) return;
-    const float* Sq = &ring[q & (L::kSlots - 1)][0];
-    const float* Sp = &ring[(q + 1) & (L::kSlots - 1)][0];
+    const float* Sp = &ring[SLOT][0];
     const bool do1 = q <= qe;
     const int b = q & 1;
 
@@ -360,16 +377,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         plane_finish(P);
         const S3 router = nXr;
         const Face6 outer = nX;
-        PlaneRegs T;
-        {  // the tile's own edge column
-          const float* d = Sq + jc * kLanes + (side ? kLanes - 1 : 0);
-          constexpr int st = NJP * kLanes;
-          T.f0 = d[F0 * st]; T.f1 = d[F1 * st]; T.u = d[U * st]; T.v = d[V * st]; T.w = d[Wf * st];
-          T.su = d[DU * st]; T.dv = d[DV * st]; T.dw = d[DW * st]; T.phi = d[PHI * st];
-        }
-        const S3 rinner = {T.u, T.v, T.w};
-        plane_finish(T);
-        const Face6 inner = plane_face(T);
+        const S3 rinner = nInr;
+        const Face6 inner = nIn;
 #pragma unroll
         for (int i = 0; i < kNL; ++i) {
           xm.v[i] = side ? inner.v[i] : outer.v[i];
@@ -502,8 +511,11 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 
   __syncthreads();  // prologue barrier: planes qs-1, qs, qs+1 are in the ring
   PlaneRegs A = {}, B = {}, Cc = {};
-  const float* Sm = &ring[(qs - 1) & (L::kSlots - 1)][0];
-  const float* S0 = &ring[qs & (L::kSlots - 1)][0];
+  const float* Sm = &ring[0][0];  // plane qs-1
+  const float* S0 = &ring[1][0];  // plane qs
+  using Slot0 = std::integral_constant<int, 0>;
+  using Slot1 = std::integral_constant<int, 1>;
+  using Slot2 = std::integral_constant<int, 2>;
   auto march = [&](auto colw_c) __attribute__((always_inline)) {
     constexpr bool CW = decltype(colw_c)::value;
     if constexpr (CW) {
@@ -517,13 +529,13 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     plane_finish(B);
     fetch_neighbours(colw_c, S0);
     int q = qs;
-    for (; q + 2 <= q_end; q += 3) {
-      step(colw_c, A, B, Cc, q);
-      step(colw_c, B, Cc, A, q + 1);
-      step(colw_c, Cc, A, B, q + 2);
+    for (; q + 2 <= q_end; q += 3) {  // step q reads plane q+1 from slot (q - qs + 2) mod 3
+      step(colw_c, Slot2{}, A, B, Cc, q);
+      step(colw_c, Slot0{}, B, Cc, A, q + 1);
+      step(colw_c, Slot1{}, Cc, A, B, q + 2);
     }
-    if (q <= q_end) step(colw_c, A, B, Cc, q);
-    if (q + 1 <= q_end) step(colw_c, B, Cc, A, q + 1);
+    if (q <= q_end) step(colw_c, Slot2{}, A, B, Cc, q);
+    if (q + 1 <= q_end) step(colw_c, Slot0{}, B, Cc, A, q + 1);
   };
   if (colw) march(std::true_type{});
   else march(std::false_type{});
