@@ -407,6 +407,12 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         rxp = side ? router : rinner;
         vx = cx;
         vy = cy;
+        // A halo column can be the LAST column of the volume (W = 64 k + 1): its right neighbour lies beyond the row, where
+        // the 16-byte piece holds padding instead of the mirrored column, so the mirror rule is applied here as well.
+        if (cx == g.W - 1) {
+          xp = xm;
+          rxp = rxm;
+        }
       } else {
         row_raw(P, Sp, jr, true);
         plane_finish(P);

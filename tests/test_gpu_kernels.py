@@ -22,6 +22,8 @@ CASES = [
     ((62, 4, 4), (62, 4, 4)),
     ((63, 5, 6), (63, 5, 6)),
     ((125, 9, 7), (125, 9, 7)),
+    ((129, 10, 9), (192, 12, 9)),   # W = 64 k + 1: the last column of the volume is a tile's halo column
+    ((65, 6, 5), (65, 6, 5)),
 ]
 SPACINGS = [(1.0, 1.0, 1.0), (7.1, 1.6, 1.25)]
 
