@@ -238,6 +238,7 @@ def run_single(args):
     # Timed region: HIP events around every launch of the DOMINANT kernel only (the fused pair, kernel id 2; the single
     # sweep when fusion is off).  Events on all 6400 solver launches of a solve cost ~2 % of it; the other two solver kernels
     # are timed in one extra, untimed step afterwards.
+    # kernel ids (include/f3d.h): 0 phi/ksi, 1 one sweep, 2 two fused sweeps, 3 sweep + next phi/ksi fused
     dominant = 2 if os.environ.get("F3D_FUSED_SWEEPS", "1") != "0" else 1
     hip.f3d_prof_reset()
     hip.f3d_prof_select(1 << dominant)
@@ -251,12 +252,12 @@ def run_single(args):
     wall = time.perf_counter() - t0
     hip.f3d_prof_enable(0)
     if events and not args.no_extra:
-        hip.f3d_prof_select(0x7 & ~(1 << dominant))
+        hip.f3d_prof_select(0xf & ~(1 << dominant))
         hip.f3d_prof_enable(1)
         flow.compute_resident(silent=True)      # untimed: phi/ksi and the other sweep kernel
         pkg.sync()
         hip.f3d_prof_enable(0)
-    hip.f3d_prof_select(0x7)
+    hip.f3d_prof_select(0xf)
     extra = args.steps                      # their totals cover one step, the dominant kernel's cover `steps`
 
     def prof(kernel, min_vox):
@@ -269,8 +270,10 @@ def run_single(args):
     f2_ms, f2_n, f2_vox = prof(2, S ** 3)
     f1_ms, f1_n, f1_vox = prof(1, S ** 3)
     pk_ms, pk_n, pk_vox = prof(0, 0)
+    sp_ms, sp_n, sp_vox = prof(3, 0)          # last sweep of an outer iteration fused with the next phi/ksi
     # the kernels of the extra step ran once, the dominant one `steps` times: put them on the same footing
     pk_ms, pk_n, pk_vox = pk_ms * extra, pk_n * extra, pk_vox * extra
+    sp_ms, sp_n, sp_vox = sp_ms * extra, sp_n * extra, sp_vox * extra
     if dominant == 2:
         s1_ms, s1_n, s1_vox = s1_ms * extra, s1_n * extra, s1_vox * extra
         f1_ms, f1_n, f1_vox = f1_ms * extra, f1_n * extra, f1_vox * extra
@@ -286,15 +289,18 @@ def run_single(args):
         return bytes_per_voxel * vox / (ms * 1e-3) / 1e9 if ms else 0.0
 
     fused = s2_n > 0
-    if fused:   # dominant kernel: k_sweep7
-        dom_name, dom_b, dom_ms, dom_n, dom_vox = "k_sweep7 (two fused solver sweeps, f3d_solve_sweep2)", 2 * SWEEP_BYTES_PER_VOXEL, s2_ms, s2_n, s2_vox
+    pair_kernel = "k_pair8" if os.environ.get("F3D_PAIR8", "1") != "0" else "k_sweep7"
+    if fused:   # dominant kernel: the fused pair
+        dom_name, dom_b, dom_ms, dom_n, dom_vox = f"{pair_kernel} (two fused solver sweeps, f3d_solve_sweep2)", 2 * SWEEP_BYTES_PER_VOXEL, s2_ms, s2_n, s2_vox
         fin_ms, fin_n, fin_vox = f2_ms, f2_n, f2_vox
     else:
         dom_name, dom_b, dom_ms, dom_n, dom_vox = "k_sweep6 (solver sweep, f3d_solve_sweep)", SWEEP_BYTES_PER_VOXEL, s1_ms, s1_n, s1_vox
         fin_ms, fin_n, fin_vox = f1_ms, f1_n, f1_vox
     achieved = gbs(dom_b, dom_vox, dom_ms)
     finest = gbs(dom_b, fin_vox, fin_ms)
-    all_sweeps = gbs(SWEEP_BYTES_PER_VOXEL, s1_vox + 2 * s2_vox, s1_ms + s2_ms)
+    # every solver launch priced at its algorithmic bytes: 52 B per voxel-sweep, 40 B per voxel of phi/ksi
+    all_sweeps = gbs(1.0, SWEEP_BYTES_PER_VOXEL * (s1_vox + 2 * s2_vox + sp_vox) + PHI_KSI_BYTES_PER_VOXEL * (sp_vox + pk_vox),
+                     s1_ms + s2_ms + sp_ms + pk_ms)
     ms_per_step = wall / args.steps * 1e3
     whole = TOTAL_BYTES.get(S)
     out = {
@@ -318,8 +324,12 @@ def run_single(args):
             "avg_voxels_per_launch": round(dom_vox / dom_n, 1) if dom_n else None,
             "finest_level": {"achieved": round(finest, 1), "frac": round(finest / HBM_PEAK_GBS, 4), "launches": fin_n,
                              "avg_launch_us": round(fin_ms / fin_n * 1e3, 3) if fin_n else None},
-            "all_sweeps": {"achieved": round(all_sweeps, 1), "frac": round(all_sweeps / HBM_PEAK_GBS, 4),
-                           "note": "52 B per voxel-sweep over every sweep launch, fused or single; the non-dominant kernels are timed in one extra untimed step"},
+            "all_solver_launches": {"achieved": round(all_sweeps, 1), "frac": round(all_sweeps / HBM_PEAK_GBS, 4),
+                                    "note": "every solver launch at its algorithmic bytes (52 B per voxel-sweep, 40 B per voxel of "
+                                            "phi/ksi), fused or not; the non-dominant kernels are timed in one extra untimed step"},
+            "sweep_phi_ksi": {"kernel": "k_pair8 (last sweep + next phi/ksi, f3d_solve_sweep_phi_ksi)",
+                              "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, sp_vox, sp_ms), 1),
+                              "launches": sp_n},
             "single_sweep": {"kernel": "k_sweep6", "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL, s1_vox, s1_ms), 1),
                              "launches": s1_n},
             "phi_ksi": {"kernel": "k_phiksi6", "achieved": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms), 1),

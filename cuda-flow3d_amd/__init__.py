@@ -36,6 +36,12 @@ class Slab(C.Structure):  # f3d_slab
     _fields_ = [("z_base", C.c_int), ("z_lo", C.c_int), ("z_hi", C.c_int)]
 
 
+class LevelStat(C.Structure):  # f3d_level_stat
+    _fields_ = [("level", C.c_int), ("width", C.c_size_t), ("height", C.c_size_t), ("depth", C.c_size_t),
+                ("residual_rms", C.c_double), ("residual_mean_abs", C.c_double), ("residual_max_abs", C.c_float),
+                ("flow_min", C.c_float), ("flow_max", C.c_float), ("flow_avg", C.c_float)]
+
+
 class FlowParams(C.Structure):  # f3d_flow_params
     _fields_ = [
         ("warp_levels_count", C.c_size_t), ("warp_scale_factor", C.c_float),
@@ -115,6 +121,7 @@ def hip():
         "f3d_unpack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
         "f3d_flow_stats": [_dp, _dp, _dp, _sz, _sz, _sz, _slabp, _fp, _fp, C.POINTER(C.c_double)],
+        "f3d_residual_stats": [_dp, _dp, _sz, _sz, _sz, _slabp, C.POINTER(C.c_double), C.POINTER(C.c_double), _fp],
         "f3d_comm_sendrecv_begin": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
         "f3d_comm_sendrecv_end": [],
         "f3d_comm_allreduce_max_f32": [_fp],
@@ -142,6 +149,9 @@ def host():
         "f3d_flow_compute_resident": [C.c_void_p, pp, C.c_int, _fp],
         "f3d_flow_download": [C.c_void_p, _fp, _fp, _fp],
         "f3d_flow_container": [C.c_void_p, C.POINTER(Size4)], "f3d_flow_destroy": [C.c_void_p],
+        "f3d_flow_set_level_stats": [C.c_void_p, C.c_int], "f3d_flow_level_stat_count": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_flow_level_stat": [C.c_void_p, _sz, C.POINTER(LevelStat)],
+        "f3d_flow_final_residual": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "f3d_op_create": [C.POINTER(C.c_void_p), C.c_char_p], "f3d_op_initialize": [C.c_void_p, C.POINTER(Size4)],
         "f3d_op_execute": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), _sz],
         "f3d_op_set_slab": [C.c_void_p, _slabp], "f3d_op_destroy": [C.c_void_p],
@@ -565,6 +575,27 @@ class OpticalFlow:
         u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
         check(host().f3d_flow_download(self._h, u.ctypes.data_as(_fp), v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)))
         return u, v, ww
+
+    def set_level_stats(self, enable=True):
+        """record, per pyramid level of every later compute, the residual before the solve and the flow statistics after it"""
+        check(host().f3d_flow_set_level_stats(self._h, int(bool(enable))))
+
+    def level_stats(self):
+        """list of dicts, coarsest level first"""
+        n = _sz()
+        check(host().f3d_flow_level_stat_count(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            st = LevelStat()
+            check(host().f3d_flow_level_stat(self._h, i, C.byref(st)))
+            out.append({k: getattr(st, k) for k, _ in LevelStat._fields_})
+        return out
+
+    def final_residual(self):
+        """((rms, mean |.|, max |.|) of frame_1 registered with the flow on the device against frame_0, the same unregistered)"""
+        a, b = (C.c_double * 3)(), (C.c_double * 3)()
+        check(host().f3d_flow_final_residual(self._h, a, b), "f3d_flow_final_residual")
+        return tuple(a), tuple(b)
 
     def destroy(self):
         if self._h:

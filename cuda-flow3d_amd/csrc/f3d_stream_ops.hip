@@ -184,6 +184,43 @@ __global__ __launch_bounds__(256) void k_flow_stats(const float* __restrict__ u,
   }
 }
 
+// ---- registration residual: how well frame_1 warped by the flow matches frame_0 -----------------------------------------
+// The reference's only diagnostic of a result is a disabled debug block that registers frame_1 with the final flow and dumps
+// the volume (optical_flow_e.cpp:536-571).  Here the comparison itself runs on the device: sum of squares, sum of absolute
+// values (both in double) and the maximum of |warped - frame_0| over a slab.
+struct ResidualStats {
+  double sum_sq, sum_abs;
+  unsigned max_bits;
+  unsigned pad;
+};
+__global__ __launch_bounds__(256) void k_residual_stats(const float* __restrict__ f0, const float* __restrict__ fw, F3dGeo g,
+                                                        ResidualStats* out)
+{
+  const int z = g.z_lo + blockIdx.z;
+  double ssq = 0.0, sab = 0.0;
+  float hi = 0.f;
+  for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
+    const size_t r = f3d_row(g, y, z);
+    for (int x = threadIdx.x; x < g.W; x += blockDim.x) {
+      const float d = fw[r + x] - f0[r + x];
+      const float a = fabsf(d);
+      hi = fmaxf(hi, a);
+      sab += static_cast<double>(a);
+      ssq += static_cast<double>(d) * static_cast<double>(d);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmaxf(hi, __shfl_down(hi, off));
+    ssq += __shfl_down(ssq, off);
+    sab += __shfl_down(sab, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out->max_bits, __float_as_uint(hi));
+    atomicAdd(&out->sum_sq, ssq);
+    atomicAdd(&out->sum_abs, sab);
+  }
+}
+
 bool same_buffer(f3d_devptr a, f3d_devptr b, const char* who)
 {
   if (a == b) {
@@ -372,6 +409,31 @@ int f3d_flow_stats(f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w, size
   std::memcpy(min_magnitude, &h.min_bits, sizeof(float));
   std::memcpy(max_magnitude, &h.max_bits, sizeof(float));
   *sum_magnitude = h.sum;
+  return 0;
+}
+
+int f3d_residual_stats(f3d_devptr frame_0, f3d_devptr frame_1_warped, size_t width, size_t height, size_t depth,
+                       const f3d_slab* slab, double* sum_squares, double* sum_abs, float* max_abs)
+{
+  F3D_REQUIRE_READY("f3d_residual_stats");
+  if (!sum_squares || !sum_abs || !max_abs) return f3d::fail("f3d_residual_stats: null argument");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_residual_stats")) return 1;
+  static ResidualStats* d_stats = nullptr;
+  if (!d_stats) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(ResidualStats)));
+  F3D_HIP(hipMemsetAsync(d_stats, 0, sizeof(ResidualStats), f3d::stream()));
+  if (g.z_hi > g.z_lo) {
+    const int gy = g.H < 64 ? g.H : 64;
+    hipLaunchKernelGGL(k_residual_stats, dim3(1, gy, g.z_hi - g.z_lo), dim3(256, 1, 1), 0, f3d::stream(),
+                       f3d_ptr<const float>(frame_0), f3d_ptr<const float>(frame_1_warped), g, d_stats);
+    F3D_HIP(hipGetLastError());
+  }
+  ResidualStats h;
+  F3D_HIP(hipMemcpyAsync(&h, d_stats, sizeof(h), hipMemcpyDeviceToHost, f3d::stream()));
+  F3D_HIP(hipStreamSynchronize(f3d::stream()));
+  *sum_squares = h.sum_sq;
+  *sum_abs = h.sum_abs;
+  std::memcpy(max_abs, &h.max_bits, sizeof(float));
   return 0;
 }
 

@@ -23,6 +23,8 @@ void Data3D::Release()
 
 bool Data3D::Allocate(size_t width, size_t height, size_t depth)
 {
+  // same extent, own storage: keep it (a frame sequence reads file after file into the same page-locked buffer)
+  if (data_ && owns_ && width == width_ && height == height_ && depth == depth_) return true;
   Release();
   data_ = new (std::nothrow) float[width * height * depth];
   if (!data_) {

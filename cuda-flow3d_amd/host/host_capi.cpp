@@ -142,6 +142,47 @@ int f3d_flow_container(f3d_flow flow, f3d_size4* container)
   return 0;
 }
 
+int f3d_flow_set_level_stats(f3d_flow flow, int enable)
+{
+  if (!flow) return 1;
+  flow->driver.collect_level_statistics = enable != 0;
+  return 0;
+}
+
+int f3d_flow_level_stat_count(f3d_flow flow, size_t* count)
+{
+  if (!flow || !count) return 1;
+  *count = flow->driver.LevelStats().size();
+  return 0;
+}
+
+int f3d_flow_level_stat(f3d_flow flow, size_t index, f3d_level_stat* out)
+{
+  if (!flow || !out || index >= flow->driver.LevelStats().size()) return 1;
+  const OpticalFlowE::LevelStatistics& st = flow->driver.LevelStats()[index];
+  out->level = st.level;
+  out->width = st.size.width;
+  out->height = st.size.height;
+  out->depth = st.size.depth;
+  out->residual_rms = st.before.rms;
+  out->residual_mean_abs = st.before.mean_abs;
+  out->residual_max_abs = st.before.max_abs;
+  out->flow_min = st.flow.min;
+  out->flow_max = st.flow.max;
+  out->flow_avg = st.flow.avg;
+  return 0;
+}
+
+int f3d_flow_final_residual(f3d_flow flow, double registered[3], double unregistered[3])
+{
+  if (!flow || !registered || !unregistered) return 1;
+  OpticalFlowE::Residual a, b;
+  if (!flow->driver.FinalResidual(a, b)) return 1;
+  registered[0] = a.rms; registered[1] = a.mean_abs; registered[2] = a.max_abs;
+  unregistered[0] = b.rms; unregistered[1] = b.mean_abs; unregistered[2] = b.max_abs;
+  return 0;
+}
+
 int f3d_flow_destroy(f3d_flow flow)
 {
   delete flow;

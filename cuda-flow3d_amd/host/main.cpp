@@ -165,25 +165,106 @@ int main(int argc, char** argv)
   if (!optical_flow_e.AllocateResidentFrames()) return 3;
   std::printf("Mode: Full GPU mode \n");
   optical_flow_e.silent = silent_mode;
-  for (size_t k = 0; k < pairs; ++k) {
-    if (!synthetic && !load(frame_1, files[k + 1])) return 2;
+  optical_flow_e.collect_level_statistics = print_stats;
+
+  auto report = [&]() {
+    Stat3 stat = {0.f, 0.f, 0.f};
+    if (optical_flow_e.ResultStatistics(stat))
+      std::printf("Flow magnitude  min: %8.4f  max: %8.4f  avg: %8.4f\n", stat.min, stat.max, stat.avg);
+    if (silent_mode)  // otherwise the driver has printed each level as it went
+      for (const OpticalFlowE::LevelStatistics& st : optical_flow_e.LevelStats())
+        std::printf("level %2d (%4zu x%4zu x%4zu)  residual before the solve: rms %.5f  mean |.| %.5f  max %.4f;  flow after it: "
+                    "min %.4f  max %.4f  avg %.4f\n", st.level, st.size.width, st.size.height, st.size.depth, st.before.rms,
+                    st.before.mean_abs, st.before.max_abs, st.flow.min, st.flow.max, st.flow.avg);
+    OpticalFlowE::Residual reg, unreg;
+    if (optical_flow_e.FinalResidual(reg, unreg))
+      std::printf("Registration residual (frame_1 warped by the flow vs frame_0)  rms: %.5f  mean |.|: %.5f  max: %.4f   "
+                  "(unregistered  rms: %.5f  mean |.|: %.5f  max: %.4f)\n", reg.rms, reg.mean_abs, reg.max_abs, unreg.rms,
+                  unreg.mean_abs, unreg.max_abs);
+  };
+  auto write_pair = [&](size_t k, Data3D& u, Data3D& v, Data3D& w) {
+    const std::string tag = pairs > 1 ? prefix + "_" + std::to_string(k) : prefix;
+    u.WriteRAWToFileF32((tag + "_flow-u" + suffix).c_str());
+    v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
+    w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
+    if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), u, v, w);
+  };
+
+  if (pairs == 1) {
+    if (!synthetic && !load(frame_1, files[1])) return 2;
     optical_flow_e.UploadResidentFrames(frame_0, frame_1);
     optical_flow_e.ComputeFlowResident(params);
-    if (print_stats) {
-      Stat3 stat = {0.f, 0.f, 0.f};
-      if (optical_flow_e.ResultStatistics(stat))
-        std::printf("Flow magnitude  min: %8.4f  max: %8.4f  avg: %8.4f\n", stat.min, stat.max, stat.avg);
-    }
+    if (print_stats) report();
     optical_flow_e.DownloadFlow(flow_u, flow_v, flow_w);
-    const std::string tag = pairs > 1 ? prefix + "_" + std::to_string(k) : prefix;
-    flow_u.WriteRAWToFileF32((tag + "_flow-u" + suffix).c_str());
-    flow_v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
-    flow_w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
-    if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), flow_u, flow_v, flow_w);
-    if (pairs > 1) {
+    write_pair(0, flow_u, flow_v, flow_w);
+  } else {
+    // Sequence: pair k solves on the device while the host reads frame k+2 and uploads it on one copy queue, and downloads and
+    // writes the flow of pair k-1 on another -- from and to page-locked buffers (the reference's ALLOCATE_PINNED_MEMORY switch,
+    // data3d.cpp:30,57-61), so the copies really run beside the kernels.  A frame crosses the link once although it serves two
+    // pairs.  With --stats or without --silent the driver reads results back per level, which serialises the solve with the
+    // host; the copies still overlap.
+    if (!optical_flow_e.AllocateSequenceFrames()) return 3;
+    const DataSize4& c = optical_flow_e.ContainerSize();
+    Data3D host_frame[3], host_flow[2][3];
+    std::vector<void*> pinned;
+    auto pin = [&](Data3D& v) {
+      if (f3d_host_register(v.DataPtr(), width * height * depth * sizeof(float)) == 0) pinned.push_back(v.DataPtr());
+    };
+    for (Data3D& f : host_frame)
+      if (!f.Allocate(width, height, depth)) return 2;
+    for (auto& set : host_flow)
+      for (Data3D& f : set)
+        if (!f.Allocate(width, height, depth)) return 2;
+    for (Data3D& f : host_frame) pin(f);
+    for (auto& set : host_flow)
+      for (Data3D& f : set) pin(f);
+    f3d_queue up = nullptr, down = nullptr;
+    f3d_event uploaded[3] = {nullptr, nullptr, nullptr};
+    if (CheckDeviceError(f3d_queue_create(&up)) || CheckDeviceError(f3d_queue_create(&down))) return 3;
+    for (f3d_event& e : uploaded)
+      if (CheckDeviceError(f3d_event_create(&e))) return 3;
+    auto upload = [&](size_t frame_index) {  // file -> page-locked buffer -> device container, slot = frame index mod 3
+      const int slot = static_cast<int>(frame_index % 3);
+      if (!load(host_frame[slot], files[frame_index])) return false;
+      CheckDeviceError(f3d_copy_planes_h2d_on(up, optical_flow_e.SequenceFrame(slot), c.pitch, c.height, 0, host_frame[slot].DataPtr(),
+                                              width, height, width, height, depth));
+      CheckDeviceError(f3d_event_record_on(uploaded[slot], up));
+      return true;
+    };
+    if (!upload(0) || !upload(1)) return 2;
+    DevicePtr taken[3] = {0, 0, 0};
+    bool pending_output = false;
+    for (size_t k = 0; k < pairs; ++k) {
+      // the solve of pair k waits (on the device) for the uploads of frames k and k+1
+      CheckDeviceError(f3d_queue_wait_event(nullptr, uploaded[k % 3]));
+      CheckDeviceError(f3d_queue_wait_event(nullptr, uploaded[(k + 1) % 3]));
+      optical_flow_e.SelectResidentPair(static_cast<int>(k % 3), static_cast<int>((k + 1) % 3));
+      optical_flow_e.BeginComputeFlowResident(params);
+      // beside it: frame k+2 into the container pair k-1 has released, and the previous pair's flow out to its files
+      if (k + 2 <= pairs && !upload(k + 2)) return 2;
+      if (pending_output) {
+        CheckDeviceError(f3d_queue_sync(down));
+        optical_flow_e.GiveResultBack(taken);
+        write_pair(k - 1, host_flow[(k - 1) & 1][0], host_flow[(k - 1) & 1][1], host_flow[(k - 1) & 1][2]);
+        pending_output = false;
+      }
+      optical_flow_e.EndComputeFlowResident();
+      if (print_stats) report();
       std::printf("pair %zu of %zu: %.3f s on the device\n", k + 1, pairs, optical_flow_e.LastDeviceSeconds());
-      frame_0.Swap(frame_1);   // the second frame of this pair is the first of the next
+      if (!optical_flow_e.TakeResult(taken)) return 3;
+      for (int i = 0; i < 3; ++i)
+        CheckDeviceError(f3d_copy_planes_d2h_on(down, host_flow[k & 1][i].DataPtr(), width, height, width, height, depth, taken[i],
+                                                c.pitch, c.height, 0));
+      pending_output = true;
     }
+    CheckDeviceError(f3d_queue_sync(down));
+    optical_flow_e.GiveResultBack(taken);
+    write_pair(pairs - 1, host_flow[(pairs - 1) & 1][0], host_flow[(pairs - 1) & 1][1], host_flow[(pairs - 1) & 1][2]);
+    CheckDeviceError(f3d_queue_sync(up));
+    for (f3d_event e : uploaded) f3d_event_destroy(e);
+    f3d_queue_destroy(up);
+    f3d_queue_destroy(down);
+    for (void* p : pinned) f3d_host_unregister(p);
   }
 
   optical_flow_e.Destroy();

@@ -231,6 +231,80 @@ void OpticalFlowE::ComputeFlowResident(OperationParameters& params)
   f3d_event_destroy(ev_stop);
 }
 
+bool OpticalFlowE::AllocateSequenceFrames()
+{
+  if (!AllocateResidentFrames()) return false;
+  if (sequence_frame_[2]) return true;
+  sequence_frame_[0] = resident_frame_[0];
+  sequence_frame_[1] = resident_frame_[1];
+  size_t pitch = 0;
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  if (CheckDeviceError(f3d_alloc_pitched(&sequence_frame_[2], &pitch, dev_container_size_.width * sizeof(float), rows)) ||
+      pitch != dev_container_size_.pitch) {
+    sequence_frame_[2] = 0;
+    return false;
+  }
+  return true;
+}
+
+void OpticalFlowE::SelectResidentPair(int slot_0, int slot_1)
+{
+  if (!sequence_frame_[2]) return;
+  resident_frame_[0] = sequence_frame_[slot_0 % 3];
+  resident_frame_[1] = sequence_frame_[slot_1 % 3];
+}
+
+void OpticalFlowE::BeginComputeFlowResident(OperationParameters& params)
+{
+  if (!IsInitialized() || !resident_frame_[0] || ev_begin_) return;
+  ReleaseResult();
+  CheckDeviceError(f3d_event_create(&ev_begin_));
+  CheckDeviceError(f3d_event_create(&ev_end_));
+  CheckDeviceError(f3d_event_record(ev_begin_));
+  RunPyramid(params, resident_frame_[0], resident_frame_[1], false);  // enqueues; nothing in it waits for the device when silent
+  CheckDeviceError(f3d_event_record(ev_end_));
+}
+
+void OpticalFlowE::EndComputeFlowResident()
+{
+  if (!ev_begin_) return;
+  float elapsed_ms = 0.f;
+  CheckDeviceError(f3d_event_sync(ev_end_));
+  CheckDeviceError(f3d_event_elapsed_ms(&elapsed_ms, ev_begin_, ev_end_));
+  last_device_seconds_ = elapsed_ms / 1000.f;
+  f3d_event_destroy(ev_begin_);
+  f3d_event_destroy(ev_end_);
+  ev_begin_ = ev_end_ = nullptr;
+}
+
+bool OpticalFlowE::TakeResult(DevicePtr (&flow)[3])
+{
+  if (!result_flow_[0]) return false;
+  // the pool keeps its fifteen: three spare containers replace the ones that leave (allocated once, recycled afterwards)
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  while (free_containers_.size() < kContainers) {
+    DevicePtr p = 0;
+    size_t pitch = 0;
+    if (CheckDeviceError(f3d_alloc_pitched(&p, &pitch, dev_container_size_.width * sizeof(float), rows)) || pitch != dev_container_size_.pitch)
+      return false;
+    free_containers_.push_back(p);
+    ++extra_containers_;
+  }
+  for (int i = 0; i < 3; ++i) {
+    flow[i] = result_flow_[i];
+    result_flow_[i] = 0;
+  }
+  return true;
+}
+
+void OpticalFlowE::GiveResultBack(DevicePtr (&flow)[3])
+{
+  for (DevicePtr& p : flow) {
+    if (p) free_containers_.push_back(p);
+    p = 0;
+  }
+}
+
 void OpticalFlowE::DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w)
 {
   if (!result_flow_[0]) return;
@@ -255,6 +329,42 @@ bool OpticalFlowE::ResultStatistics(Stat3& stat)
   cuop_stat_.silent = true;
   cuop_stat_.Execute(bag);
   return true;
+}
+
+bool OpticalFlowE::ResidualOf(DevicePtr frame_0, DevicePtr warped, const DataSize4& size, Residual& out)
+{
+  double ssq = 0.0, sab = 0.0;
+  float mx = 0.f;
+  if (CheckDeviceError(f3d_residual_stats(frame_0, warped, size.width, size.height, size.depth, nullptr, &ssq, &sab, &mx))) return false;
+  const double n = static_cast<double>(size.width) * static_cast<double>(size.height) * static_cast<double>(size.depth);
+  out.rms = std::sqrt(ssq / n);
+  out.mean_abs = sab / n;
+  out.max_abs = mx;
+  return true;
+}
+
+bool OpticalFlowE::FinalResidual(Residual& registered, Residual& unregistered)
+{
+  if (!IsInitialized() || !result_flow_[0] || !resident_frame_[0]) return false;
+  DataSize4 size = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
+  DevicePtr dev_temp = Borrow();
+  float h = 1.f;
+  OperationParameters op;
+  op.PushValuePtr("dev_frame_0", &resident_frame_[0]);
+  op.PushValuePtr("dev_frame_1", &resident_frame_[1]);
+  op.PushValuePtr("dev_flow_u", &result_flow_[0]);
+  op.PushValuePtr("dev_flow_v", &result_flow_[1]);
+  op.PushValuePtr("dev_flow_w", &result_flow_[2]);
+  op.PushValuePtr("dev_output", &dev_temp);
+  op.PushValuePtr("data_size", &size);
+  op.PushValuePtr("hx", &h);
+  op.PushValuePtr("hy", &h);
+  op.PushValuePtr("hz", &h);
+  cuop_register_.Execute(op);
+  const bool ok = ResidualOf(resident_frame_[0], dev_temp, size, registered) &&
+                  ResidualOf(resident_frame_[0], resident_frame_[1], size, unregistered);
+  GiveBack(dev_temp);
+  return ok;
 }
 
 bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, DevicePtr raw_1, bool raw_is_pooled)
@@ -316,6 +426,7 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
   DevicePtr dev_flow_u = Borrow(), dev_flow_v = Borrow(), dev_flow_w = Borrow();
   DevicePtr dev_flow_du = Borrow(), dev_flow_dv = Borrow(), dev_flow_dw = Borrow();
 
+  level_stats_.clear();
   DataSize4 prev_data_size = {0, 0, 0, 0};
   if (level < 0) {  // no level requested: the flow is identically zero
     const size_t rows = dev_container_size_.height * dev_container_size_.depth;
@@ -385,6 +496,13 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
       std::swap(dev_frame_1_res_br, dev_temp);
       GiveBack(dev_temp);
     }
+    if (collect_level_statistics) {
+      LevelStatistics st;
+      st.level = level;
+      st.size = current;
+      ResidualOf(dev_frame_0_res, dev_frame_1_res_br, current, st.before);
+      level_stats_.push_back(st);
+    }
 
     // difference problem: increments du, dv, dw (:372-417)
     {
@@ -446,6 +564,20 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
       GiveBack(dev_temp);
     }
 
+    if (collect_level_statistics) {
+      float mn = 0.f, mx = 0.f;
+      double sum = 0.0;
+      if (!CheckDeviceError(f3d_flow_stats(dev_flow_u, dev_flow_v, dev_flow_w, current.width, current.height, current.depth, nullptr,
+                                           &mn, &mx, &sum))) {
+        const double n = static_cast<double>(current.width) * static_cast<double>(current.height) * static_cast<double>(current.depth);
+        level_stats_.back().flow = {mn, mx, static_cast<float>(sum / n)};
+      }
+      if (!silent) {
+        const LevelStatistics& st = level_stats_.back();
+        std::printf("  residual before the solve: rms %.5f  mean |.| %.5f  max %.4f;  flow after it: min %.4f  max %.4f  avg %.4f\n",
+                    st.before.rms, st.before.mean_abs, st.before.max_abs, st.flow.min, st.flow.max, st.flow.avg);
+      }
+    }
     prev_data_size = current;
     --level;
   }
@@ -474,10 +606,18 @@ void OpticalFlowE::Destroy()
     free_containers_.pop_back();
     ++freed;
   }
+  if (sequence_frame_[2]) {  // sequence mode: the three frame containers, two of which resident_frame_ points at
+    for (DevicePtr& p : sequence_frame_) {
+      if (p) CheckDeviceError(f3d_free(p));
+      p = 0;
+    }
+    resident_frame_[0] = resident_frame_[1] = 0;
+  }
   for (DevicePtr& p : resident_frame_) {
     if (p) CheckDeviceError(f3d_free(p));
     p = 0;
   }
-  if (freed && freed != kContainers) std::printf("Warning. Not all device memory allocations were freed.\n");
+  if (freed && freed != kContainers + extra_containers_) std::printf("Warning. Not all device memory allocations were freed.\n");
+  extra_containers_ = 0;
   initialized_ = false;
 }

@@ -62,10 +62,43 @@ class OpticalFlowE : public OpticalFlowBase {
   const DataSize4& ContainerSize() const { return dev_container_size_; }
   void ComputeFlowResident(OperationParameters& params);
   void DownloadFlow(Data3D& flow_u, Data3D& flow_v, Data3D& flow_w);
+
+  // Frame sequences (bin/flow3d --frames f0 f1 f2 ...).  The reference sets the driver up, uploads both
+  // frames, solves, downloads and tears everything down for every pair (src/main.cpp:132-185).  Here the frames live in THREE
+  // rotating device containers, so a frame is uploaded once although it serves two pairs, and a solve is split into
+  // BeginComputeFlowResident (enqueues the whole pyramid on the library stream and returns) and EndComputeFlowResident (waits):
+  // in between the caller reads the next file and uploads it on a copy queue, and downloads / writes the previous pair's flow,
+  // which TakeResult() has moved out of the driver's way (three spare containers join the pool the first time).
+  bool AllocateSequenceFrames();                                    // the third frame container
+  DevicePtr SequenceFrame(int slot) const { return sequence_frame_[slot % 3]; }
+  void SelectResidentPair(int slot_0, int slot_1);                  // which two of the three are frame_0 / frame_1 of the next solve
+  void BeginComputeFlowResident(OperationParameters& params);
+  void EndComputeFlowResident();
+  bool TakeResult(DevicePtr (&flow)[3]);                            // the caller owns the three containers until GiveResultBack
+  void GiveResultBack(DevicePtr (&flow)[3]);
   // min / max / average magnitude of the flow ComputeFlowResident() left on the device (CudaOperationStat); false when there
   // is none
   bool ResultStatistics(Stat3& stat);
   float LastDeviceSeconds() const { return last_device_seconds_; }
+
+  // Diagnostics per pyramid level and for the result (the reference's counterpart is the disabled
+  // "apply the flow and dump the registered volume" block, optical_flow_e.cpp:536-571).  Collected only when asked for: every
+  // level costs two small reductions and a read-back.
+  struct Residual {
+    double rms = 0.0, mean_abs = 0.0;
+    float max_abs = 0.f;
+  };
+  struct LevelStatistics {
+    int level = 0;
+    DataSize4 size = {0, 0, 0, 0};
+    Residual before;  // frame_1 warped with the flow handed down from the coarser level, against frame_0, at this level's size
+    Stat3 flow = {0.f, 0.f, 0.f};  // min / max / average flow magnitude after this level's median
+  };
+  bool collect_level_statistics = false;
+  const std::vector<LevelStatistics>& LevelStats() const { return level_stats_; }
+  // The reference's debug block made measurable: the ORIGINAL frame_1 registered with the final flow (h = 1) against the
+  // original frame_0, and the same difference without any flow.  Needs the resident raw frames and a computed flow.
+  bool FinalResidual(Residual& registered, Residual& unregistered);
 
  private:
   static constexpr size_t kContainers = 15;  // optical_flow_e.h:40
@@ -80,8 +113,13 @@ class OpticalFlowE : public OpticalFlowBase {
   DataSize4 dev_container_size_ = {0, 0, 0, 0};
   std::vector<DevicePtr> free_containers_;  // LIFO like the reference's std::stack
   DevicePtr resident_frame_[2] = {0, 0};
+  DevicePtr sequence_frame_[3] = {0, 0, 0};  // sequence mode: resident_frame_ aliases two of these
+  size_t extra_containers_ = 0;               // spares allocated for TakeResult
+  f3d_event ev_begin_ = nullptr, ev_end_ = nullptr;
   DevicePtr result_flow_[3] = {0, 0, 0};
   float last_device_seconds_ = 0.f;
+  std::vector<LevelStatistics> level_stats_;
+  bool ResidualOf(DevicePtr frame_0, DevicePtr warped, const DataSize4& size, Residual& out);
 
   CudaOperationAdd cuop_add_;
   CudaOperationMedian cuop_median_;

@@ -256,6 +256,13 @@ int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, con
 int f3d_flow_stats(f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w, size_t width, size_t height, size_t depth,
                    const f3d_slab* slab, float* min_magnitude, float* max_magnitude, double* sum_magnitude);
 
+/* Registration residual on the device: sum of (warped - frame_0)^2, sum of |warped - frame_0| (both accumulated in double)
+ * and max |warped - frame_0| over the slab's planes (host out).  The reference's counterpart is the disabled debug block of
+ * src/optical_flow/optical_flow_e.cpp:536-571, which registers frame_1 with the final flow (cuop_register_, h = 1) and dumps
+ * the volume for inspection; here the comparison with frame_0 is a reduction and nothing is written to disk. */
+int f3d_residual_stats(f3d_devptr frame_0, f3d_devptr frame_1_warped, size_t width, size_t height, size_t depth,
+                       const f3d_slab* slab, double* sum_squares, double* sum_abs, float* max_abs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,23 @@ int f3d_flow_upload(f3d_flow flow, const float* frame_0, const float* frame_1);
 int f3d_flow_compute_resident(f3d_flow flow, const f3d_flow_params* params, int silent, float* device_seconds);
 int f3d_flow_download(f3d_flow flow, float* u, float* v, float* w);
 int f3d_flow_container(f3d_flow flow, f3d_size4* container);
+/* Diagnostics (the reference's counterpart is the disabled block optical_flow_e.cpp:536-571 that registers
+ * frame_1 with the final flow and dumps the volume).  With level statistics enabled every later compute records, per pyramid
+ * level, the residual of frame_1 warped by the flow handed down from the coarser level against frame_0 (before the solve) and the
+ * min / max / average flow magnitude after the level's median. */
+typedef struct f3d_level_stat {
+  int level;
+  size_t width, height, depth;
+  double residual_rms, residual_mean_abs;
+  float residual_max_abs;
+  float flow_min, flow_max, flow_avg;
+} f3d_level_stat;
+int f3d_flow_set_level_stats(f3d_flow flow, int enable);
+int f3d_flow_level_stat_count(f3d_flow flow, size_t* count);
+int f3d_flow_level_stat(f3d_flow flow, size_t index, f3d_level_stat* out);  /* index 0 = coarsest level of the last compute */
+/* residual of the ORIGINAL frame_1 registered with the flow on the device (h = 1) against the original frame_0, and of the pair
+ * as it stands; values: rms, mean |.|, max |.| each.  Needs f3d_flow_upload + f3d_flow_compute_resident. */
+int f3d_flow_final_residual(f3d_flow flow, double registered[3], double unregistered[3]);
 int f3d_flow_destroy(f3d_flow flow);
 
 /* name: "add" | "convolution" | "median" | "registration" | "resample" | "solve" */

@@ -318,6 +318,29 @@ void orc_add(float* a, const float* b, int W, int H, int D, const orc_geom* g)
       }
 }
 
+/* What one reads off the volume the reference's debug block dumps (optical_flow_e.cpp:536-571: frame_1 registered with the
+ * final flow): sum of squares, sum of absolute values (double, scan order) and maximum of |warped - frame_0|. */
+void orc_residual_stats(const float* f0, const float* fw, int W, int H, int D, const orc_geom* g, double* sum_sq,
+                        double* sum_abs, float* max_abs)
+{
+  (void)D;
+  double ssq = 0.0, sab = 0.0;
+  float mx = 0.f;
+  for (int z = g->z_lo; z < g->z_hi; z++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        size_t c = IDX(g, x, y, z);
+        float d = fw[c] - f0[c];
+        float a = fabsf(d);
+        mx = fmaxf(mx, a);
+        sab += (double)a;
+        ssq += (double)d * (double)d;
+      }
+  *sum_sq = ssq;
+  *sum_abs = sab;
+  *max_abs = mx;
+}
+
 /* cuda_operation_stat_p.cpp:85-104 (serial on purpose: the reference's float sum depends on the scan order) */
 void orc_flow_stats(const float* u, const float* v, const float* w, int W, int H, int D, const orc_geom* g,
                     float* min_mag, float* max_mag, float* avg_float, double* sum_double)

@@ -92,6 +92,11 @@ void orc_add(float* a, const float* b, int W, int H, int D, const orc_geom* g);
 void orc_flow_stats(const float* u, const float* v, const float* w, int W, int H, int D, const orc_geom* g,
                     float* min_mag, float* max_mag, float* avg_float, double* sum_double);
 
+/* residual of a registration: sums of (warped - frame_0)^2 and |warped - frame_0| in double, maximum of the latter
+ * (diagnostic of src/optical_flow/optical_flow_e.cpp:536-571, which only dumps the registered volume) */
+void orc_residual_stats(const float* f0, const float* fw, int W, int H, int D, const orc_geom* g, double* sum_sq,
+                        double* sum_abs, float* max_abs);
+
 /* A.5 median, window diameter r in {3,5,7} */
 void orc_median(const float* in, float* out, int W, int H, int D, int r, const orc_geom* g);
 

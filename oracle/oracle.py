@@ -78,6 +78,9 @@ def lib():
         L.orc_flow_stats.restype = None
         L.orc_flow_stats.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, gp, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.orc_residual_stats.restype = None
+        L.orc_residual_stats.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, gp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_float)]
         L.orc_add.restype = None
         L.orc_add.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, gp]
         L.orc_median.restype = None
@@ -254,6 +257,14 @@ def flow_stats(u, v, w, dims, g=None):
     mn, mx, avg, s = C.c_float(), C.c_float(), C.c_float(), C.c_double()
     lib().orc_flow_stats(_p(u), _p(v), _p(w), W, H, D, g or geom(u, z_hi=D), C.byref(mn), C.byref(mx), C.byref(avg), C.byref(s))
     return mn.value, mx.value, avg.value, s.value
+
+
+def residual_stats(f0, fw, dims, g=None):
+    """(sum of squares, sum of absolute values, max) of warped - frame_0"""
+    W, H, D = dims
+    ssq, sab, mx = C.c_double(), C.c_double(), C.c_float()
+    lib().orc_residual_stats(_p(f0), _p(fw), W, H, D, g or geom(f0, z_hi=D), C.byref(ssq), C.byref(sab), C.byref(mx))
+    return ssq.value, sab.value, mx.value
 
 
 def median(inp, dims, r, g=None):

@@ -442,6 +442,30 @@ def test_flow_stats(f3d, oracle, dims, cdims):
         dev.close()
 
 
+@pytest.mark.parametrize("dims,cdims", CASES[:4])
+def test_residual_stats(f3d, oracle, dims, cdims):
+    """f3d_residual_stats (sum of squares, sum of absolute values, maximum of warped - frame_0) against the oracle's scan:
+    the maximum exactly, the double sums to 1e-12 (the order of a parallel reduction differs from the scan's)."""
+    rng = np.random.default_rng(6)
+    W, H, D = dims
+    f0 = box_in_container(rng, dims, cdims, 0, 255)
+    fw = box_in_container(rng, dims, cdims, 0, 255)
+    ssq_o, sab_o, mx_o = oracle.residual_stats(f0, fw, dims)
+    dev = Dev(f3d, cdims)
+    try:
+        p0, pw = dev.put(f0), dev.put(fw)
+        ssq, sab, mx = C.c_double(), C.c_double(), C.c_float()
+        f3d.check(f3d.hip().f3d_residual_stats(p0, pw, W, H, D, None, C.byref(ssq), C.byref(sab), C.byref(mx)))
+        assert mx.value == mx_o
+        assert abs(ssq.value - ssq_o) <= 1e-12 * ssq_o and abs(sab.value - sab_o) <= 1e-12 * sab_o
+        slab = f3d.Slab(0, 1, D - 1)
+        f3d.check(f3d.hip().f3d_residual_stats(p0, pw, W, H, D, C.byref(slab), C.byref(ssq), C.byref(sab), C.byref(mx)))
+        ssq2, sab2, mx2 = oracle.residual_stats(f0, fw, dims, g=oracle.geom(f0, z_base=0, z_lo=1, z_hi=D - 1))
+        assert mx.value == mx2 and abs(ssq.value - ssq2) <= 1e-12 * ssq2 and abs(sab.value - sab2) <= 1e-12 * sab2
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("scale", [1e-33, 1e-38, 3e-42])
 def test_phi_ksi_and_fused_sweeps_tiny_numerators(f3d, oracle, scale):
     """Derivative numerators below 2^-100 (down to subnormal data): the exact-division shortcut by the uniform divisors 2h

@@ -171,13 +171,16 @@ def test_missing_key_is_reported_not_fatal(f3d, capfd):
 
 
 def test_cli_frame_sequence_and_stats(f3d, tmp_path):
-    """bin/flow3d on three frames: one Initialize, the flow of every consecutive pair written, --stats printing what
-    the device statistics operator returns; each pair equals a fresh OpticalFlow.compute of the same two frames."""
+    """bin/flow3d on four frames: one Initialize, three rotating frame containers (every frame uploaded once, the next one
+    while the current pair solves, the previous flow downloaded and written beside the next solve), the flow of every
+    consecutive pair written, --stats printing what the device statistics return; each pair equals a fresh
+    OpticalFlow.compute of the same two frames."""
     import re
     import subprocess
     W, H, D = 48, 40, 24
     f0, f1 = f3d.synth_pair(W, H, D)
-    frames = [np.round(np.clip(f0, 0, 255)), np.round(np.clip(f1, 0, 255)), np.round(np.clip(0.5 * (f0 + f1), 0, 255))]
+    frames = [np.round(np.clip(f0, 0, 255)), np.round(np.clip(f1, 0, 255)), np.round(np.clip(0.5 * (f0 + f1), 0, 255)),
+              np.round(np.clip(0.25 * f0 + 0.75 * f1, 0, 255))]
     paths = []
     for k, fr in enumerate(frames):
         p = tmp_path / f"frame{k}.raw"
@@ -190,8 +193,12 @@ def test_cli_frame_sequence_and_stats(f3d, tmp_path):
                           "--stats", "--silent"], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     stats = re.findall(r"Flow magnitude\s+min:\s*([\d.]+)\s+max:\s*([\d.]+)\s+avg:\s*([\d.]+)", run.stdout)
-    assert len(stats) == 2, run.stdout
-    for k in range(2):
+    assert len(stats) == 3, run.stdout
+    residual = re.findall(r"Registration residual .*?rms:\s*([\d.]+).*?unregistered\s+rms:\s*([\d.]+)", run.stdout)
+    assert len(residual) == 3 and all(float(a) < float(b) for a, b in residual), run.stdout
+    assert len(re.findall(r"^level\s+\d+ \(", run.stdout, flags=re.M)) == 3 * 5, run.stdout   # five levels per pair
+    assert len(re.findall(r"^pair \d of 3:", run.stdout, flags=re.M)) == 3, run.stdout
+    for k in range(3):
         a = frames[k].astype(np.uint8).astype(np.float32)
         b = frames[k + 1].astype(np.uint8).astype(np.float32)
         flow = f3d.OpticalFlow()
@@ -204,6 +211,47 @@ def test_cli_frame_sequence_and_stats(f3d, tmp_path):
         mag = np.sqrt(exp[0] * exp[0] + exp[1] * exp[1] + exp[2] * exp[2])
         mn, mx, avg = (float(v) for v in stats[k])
         assert abs(mn - mag.min()) < 1e-3 and abs(mx - mag.max()) < 1e-3 and abs(avg - mag.mean()) < 1e-3
+
+
+def test_level_statistics_and_final_residual(f3d, oracle):
+    """The driver's diagnostics: one record per pyramid level with the level geometry of the schedule, a
+    residual that the registration brings down, flow statistics equal to the statistics operator's; and the final residual --
+    frame_1 registered with the computed flow against frame_0 -- equal to the oracle's warp + scan of the same volumes."""
+    W, H, D = 48, 40, 36
+    f0, f1 = f3d.synth_pair(W, H, D)
+    kw = dict(warp_levels_count=12, outer_iterations_count=6)
+    flow = f3d.OpticalFlow()
+    flow.initialize(W, H, D)
+    try:
+        flow.upload(f0, f1)
+        flow.set_level_stats(True)
+        flow.compute_resident(silent=True, **kw)
+        u, v, w = flow.download()
+        levels = flow.level_stats()
+        reg, unreg = flow.final_residual()
+        flow.set_level_stats(False)
+        flow.compute_resident(silent=True, **kw)
+        assert flow.level_stats() == []                      # nothing is collected unless asked for
+        for a, b in zip(flow.download(), (u, v, w)):
+            assert same(a, b)                                # ... and collecting changes nothing
+    finally:
+        flow.destroy()
+    assert [st["level"] for st in levels] == list(range(11, -1, -1))
+    for st in levels:
+        (cw, ch, cd), _ = oracle.level_geometry(W, H, D, 0.95, st["level"])
+        assert (st["width"], st["height"], st["depth"]) == (cw, ch, cd)
+        assert st["residual_rms"] >= 0 and st["residual_max_abs"] >= st["residual_mean_abs"] >= 0
+        assert 0 <= st["flow_min"] <= st["flow_avg"] <= st["flow_max"]
+    assert levels[0]["residual_rms"] > 2 * levels[-1]["residual_rms"]      # the flow handed down registers better and better
+    mag = np.sqrt(u.astype(np.float64) ** 2 + v.astype(np.float64) ** 2 + w.astype(np.float64) ** 2)
+    assert abs(levels[-1]["flow_avg"] - mag.mean()) < 1e-5 * mag.mean()
+    assert levels[-1]["flow_max"] == np.float32(np.sqrt(u * u + v * v + w * w).max())
+    # final residual: oracle warp (pinned to the reference's host warp) + oracle scan
+    warped = oracle.warp(f0, f1, u, v, w, (W, H, D), (1.0, 1.0, 1.0))
+    n = W * H * D
+    for got, (ssq, sab, mx) in ((reg, oracle.residual_stats(f0, warped, (W, H, D))), (unreg, oracle.residual_stats(f0, f1, (W, H, D)))):
+        assert abs(got[0] - np.sqrt(ssq / n)) <= 1e-10 * got[0] and abs(got[1] - sab / n) <= 1e-10 * got[1] and got[2] == mx
+    assert reg[0] < 0.5 * unreg[0]
 
 
 def test_fused_pairs_equal_single_sweeps_end_to_end(tmp_path):

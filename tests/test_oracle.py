@@ -184,3 +184,16 @@ def test_flow_stats_equal_the_reference(oracle):
         u, v, w = (rng.uniform(-4, 4, (D, H, W)).astype(np.float32) for _ in range(3))
         mn, mx, avg, _ = oracle.flow_stats(u, v, w, dims)
         assert (mn, mx, avg) == oracle.ref_flow_stats(u, v, w)
+
+
+def test_residual_stats_match_numpy(oracle):
+    """orc_residual_stats (the checker of f3d_residual_stats): double sums and the float maximum of warped - frame_0"""
+    rng = np.random.default_rng(8)
+    for dims in [(37, 21, 9), (64, 8, 5)]:
+        W, H, D = dims
+        a, b = (rng.uniform(0, 255, (D, H, W)).astype(np.float32) for _ in range(2))
+        ssq, sab, mx = oracle.residual_stats(a, b, dims)
+        d = (b - a)
+        assert mx == np.abs(d).max()
+        assert abs(ssq - (d.astype(np.float64) ** 2).sum()) <= 1e-12 * ssq
+        assert abs(sab - np.abs(d).astype(np.float64).sum()) <= 1e-12 * sab
