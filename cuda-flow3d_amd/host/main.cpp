@@ -234,12 +234,14 @@ int main(int argc, char** argv)
     if (!upload(0) || !upload(1)) return 2;
     DevicePtr taken[3] = {0, 0, 0};
     bool pending_output = false;
+    const bool serial_sequence = std::getenv("F3D_SEQ_SERIAL") && std::atoi(std::getenv("F3D_SEQ_SERIAL")) != 0;
     for (size_t k = 0; k < pairs; ++k) {
       // the solve of pair k waits (on the device) for the uploads of frames k and k+1
       CheckDeviceError(f3d_queue_wait_event(nullptr, uploaded[k % 3]));
       CheckDeviceError(f3d_queue_wait_event(nullptr, uploaded[(k + 1) % 3]));
       optical_flow_e.SelectResidentPair(static_cast<int>(k % 3), static_cast<int>((k + 1) % 3));
       optical_flow_e.BeginComputeFlowResident(params);
+      if (serial_sequence) optical_flow_e.EndComputeFlowResident();  // A/B timing: nothing runs beside the solve
       // beside it: frame k+2 into the container pair k-1 has released, and the previous pair's flow out to its files
       if (k + 2 <= pairs && !upload(k + 2)) return 2;
       if (pending_output) {
