@@ -332,17 +332,12 @@ static int conv_launch(int axis, f3d_devptr dst, f3d_devptr src, size_t w, size_
   F3dGeo g;
   if (!f3d::make_geo(&g, w, h, d, slab, who)) return 1;
   if (g.z_lo == g.z_hi) return 0;
-  if (axis == 2) {
-    const int r = static_cast<int>(radius);
-    if (!planes_inside(g, g.z_lo - r < 0 ? 0 : g.z_lo - r, g.z_hi + r > g.D ? g.D : g.z_hi + r, who)) return 1;
-  }
   const dim3 grid = grid_for(g.W, g.H, g.z_hi - g.z_lo), block(kBX, kBY, 1);
   float* o = f3d_ptr<float>(dst);
   const float* s = f3d_ptr<const float>(src);
   const int r = static_cast<int>(radius);
   if (axis == 0) hipLaunchKernelGGL(k_conv<0>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
   if (axis == 1) hipLaunchKernelGGL(k_conv<1>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
-  if (axis == 2) hipLaunchKernelGGL(k_conv<2>, grid, block, 0, f3d::stream(), o, s, g, taps, r);
   F3D_HIP(hipGetLastError());
   return 0;
 }
@@ -357,12 +352,6 @@ int f3d_conv_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, s
                   const f3d_slab* slab)
 {
   return conv_launch(1, dst, src, width, height, depth, kernel_radius, slab, "f3d_conv_cols");
-}
-
-int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
-                    const f3d_slab* slab)
-{
-  return conv_launch(2, dst, src, width, height, depth, kernel_radius, slab, "f3d_conv_slices");
 }
 
 int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result)

@@ -138,9 +138,10 @@ void CudaOperationConvolution3D::Execute(OperationParameters& params)
   if (kernel_length_ == 0) return;
   if (CheckDeviceError(f3d_set_conv_taps(kernel_, kernel_length_))) return;
   const size_t w = data_size.width, h = data_size.height, d = data_size.depth, r = kernel_radius_;
-  // rows: input -> output, columns: output -> temp, slices: temp -> output (reference :172-181)
-  if (CheckDeviceError(f3d_conv_rows(dev_output, dev_input, w, h, d, r, slab_))) return;
-  if (CheckDeviceError(f3d_conv_cols(dev_temp, dev_output, w, h, d, r, slab_))) return;
+  // The reference runs rows: input -> output, columns: output -> temp, slices: temp -> output (:172-181).  Rows and columns are
+  // one launch here (the row-convolved volume stays in LDS): input -> temp, then slices: temp -> output -- the same bits in
+  // dev_output, and dev_temp ends up holding the x/y-convolved volume as it does there.
+  if (CheckDeviceError(f3d_conv_rows_cols(dev_temp, dev_input, w, h, d, r, slab_))) return;
   CheckDeviceError(f3d_conv_slices(dev_output, dev_temp, w, h, d, r, slab_));
 }
 

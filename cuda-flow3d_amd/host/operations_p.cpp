@@ -804,8 +804,7 @@ void CudaOperationConvolution3DP::Execute(OperationParameters& params)
     const int base = chunk == D ? 0 : z0 - R;
     const f3d_slab wide = {base, lo, hi}, own = {base, z0, z1};
     if (!Upload(buf[0], box, lo - base, *p_input, W, H, lo, hi - lo)) return;
-    if (CheckDeviceError(f3d_conv_rows(buf[1], buf[0], W, H, D, R, &wide))) return;
-    if (CheckDeviceError(f3d_conv_cols(buf[2], buf[1], W, H, D, R, &wide))) return;
+    if (CheckDeviceError(f3d_conv_rows_cols(buf[2], buf[0], W, H, D, R, &wide))) return;  // rows + columns, one launch
     if (CheckDeviceError(f3d_conv_slices(buf[1], buf[2], W, H, D, R, &own))) return;
     if (!Download(*p_output, W, H, z0, z1 - z0, buf[1], box, z0 - base)) return;
   }

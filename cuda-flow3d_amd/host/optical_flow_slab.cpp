@@ -377,8 +377,7 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       const f3d_slab own = Window(D0, l.rank, 0, 0);
       const Role src[2] = {RAW0, RAW1}, dst[2] = {F0, F1};
       for (int i = 0; i < 2; ++i) {
-        if (!Check(f3d_conv_rows(l.buf[dst[i]], l.buf[src[i]], W0, H0, D0, R, &wide))) return false;
-        if (!Check(f3d_conv_cols(l.buf[TMP], l.buf[dst[i]], W0, H0, D0, R, &wide))) return false;
+        if (!Check(f3d_conv_rows_cols(l.buf[TMP], l.buf[src[i]], W0, H0, D0, R, &wide))) return false;  // rows + columns
         if (!Check(f3d_conv_slices(l.buf[dst[i]], l.buf[TMP], W0, H0, D0, R, &own))) return false;
       }
     }

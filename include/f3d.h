@@ -198,6 +198,11 @@ int f3d_conv_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, s
                   const f3d_slab* slab);
 int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
                     const f3d_slab* slab);
+/* convolutionRowsKernel followed by convolutionColumnsKernel in ONE launch (the two launches of
+ * cuda_operation_convolution.cpp:172-177): dst receives what f3d_conv_rows into a scratch volume and f3d_conv_cols from it
+ * would leave, bit for bit; the row-convolved volume only ever exists in LDS. */
+int f3d_conv_rows_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
+                       const f3d_slab* slab);
 
 /* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
 

@@ -204,7 +204,7 @@ def test_median(f3d, oracle, dims, cdims, r):
         dev.close()
 
 
-@pytest.mark.parametrize("sigma", [1.0, 2.0, 3.5, 5.0])
+@pytest.mark.parametrize("sigma", [1.0, 2.0, 3.5, 5.0, 8.0])
 @pytest.mark.parametrize("dims", [(37, 20, 9), (64, 8, 5), (130, 12, 33)])
 def test_gaussian(f3d, oracle, dims, sigma):
     """Clean zero-padded spec; the container height equals the data height as at the reference's only call site."""
@@ -224,6 +224,30 @@ def test_gaussian(f3d, oracle, dims, sigma):
         op.execute(dev_input=pin, dev_output=pout, dev_temp=ptmp, data_size=dims, gaussian_sigma=sigma)
         assert bit_same(dev.get(pout)[:D, :H, :W], exp[:D, :H, :W])
         op.destroy()
+        # the launchers one by one: single passes (f3d_conv_rows, f3d_conv_cols), the fused rows + columns launch and the
+        # z march give the same bits as the oracle's three passes, also on a window of planes
+        hip = f3d.hip()
+        taps = np.ascontiguousarray(taps_p, np.float32)
+        f3d.check(hip.f3d_set_conv_taps(taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps)))
+        g = oracle.geom(inp, z_hi=D)
+        ex = np.full_like(inp, np.nan)
+        oracle.conv_axis(ex, inp, dims, r_o, taps_o, 0)
+        exy = np.full_like(inp, np.nan)
+        oracle.conv_axis(exy, ex, dims, r_o, taps_o, 1)
+        a, b = dev.out(), dev.out()
+        f3d.check(hip.f3d_conv_rows(a, pin, W, H, D, r_p, None))
+        assert bit_same(dev.get(a)[:D, :H, :W], ex[:D, :H, :W])
+        f3d.check(hip.f3d_conv_cols(b, a, W, H, D, r_p, None))
+        assert bit_same(dev.get(b)[:D, :H, :W], exy[:D, :H, :W])
+        f3d.check(hip.f3d_conv_rows_cols(a, pin, W, H, D, r_p, None))
+        assert bit_same(dev.get(a)[:D, :H, :W], exy[:D, :H, :W])
+        if D > 2:
+            slab = f3d.Slab(0, 1, D - 1)
+            f3d.check(hip.f3d_memset2d(b, dev.cont.pitch, 0xFF, dev.cont.pitch, cdims[1] * cdims[2]))
+            f3d.check(hip.f3d_conv_slices(b, a, W, H, D, r_p, C.byref(slab)))
+            got = dev.get(b)
+            assert bit_same(got[1:D - 1, :H, :W], exp[1:D - 1, :H, :W]) and np.isnan(got[0]).all() and np.isnan(got[D - 1]).all()
+        assert hip.f3d_conv_rows_cols(a, a, W, H, D, r_p, None) != 0
     finally:
         dev.close()
 
