@@ -50,8 +50,11 @@ def log(*a):
 
 def solver_source_stamp():
     """sha256 (16 hex digits) of the solver kernel source: the PMC record is only valid for the kernels it was taken on"""
-    with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", "f3d_solve.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in ("f3d_solve.hip", "f3d_solve_pair8.h"):
+        with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(kernel):

@@ -20,9 +20,13 @@ namespace {
 constexpr int kGX = 64, kGY = 32;   // outputs per workgroup of k_gauss_xy
 constexpr int kMaxR = 25;           // 51 taps (MAX_KERNEL_LENGTH, convolution_3d.cu:49)
 
+// RT > 0: the radius as a compile-time constant (loops unrolled, taps in scalar registers, LDS offsets immediate) for the radii
+// the application really uses (sigma = 2 -> R = 6); RT = 0: any radius up to 25 at run time.
+template <int RT>
 __global__ __launch_bounds__(256) void k_gauss_xy(float* __restrict__ dst, const float* __restrict__ src, F3dGeo g,
-                                                  f3d::ConvTaps taps, int R)
+                                                  f3d::ConvTaps taps, int Rrt)
 {
+  const int R = RT > 0 ? RT : Rrt;
   extern __shared__ float lds[];
   const int PW = kGX + 2 * R, PH = kGY + 2 * R;
   float* A = lds;                // input patch  [PH][PW]
@@ -44,7 +48,12 @@ __global__ __launch_bounds__(256) void k_gauss_xy(float* __restrict__ dst, const
   for (int rr = wy; rr < PH; rr += 4) {
     const float* a = A + rr * PW + lane;  // a[R + j] = patch column x + j
     float sum = 0.f;
-    for (int j = -R; j <= R; ++j) sum = sum + taps.k[R - j] * a[R + j];
+    if (RT > 0) {
+#pragma unroll
+      for (int j = -RT; j <= RT; ++j) sum = sum + taps.k[RT - j] * a[RT + j];
+    } else {
+      for (int j = -R; j <= R; ++j) sum = sum + taps.k[R - j] * a[R + j];
+    }
     B[rr * kGX + lane] = sum;
   }
   __syncthreads();
@@ -54,7 +63,12 @@ __global__ __launch_bounds__(256) void k_gauss_xy(float* __restrict__ dst, const
     if (gx >= g.W || gy >= g.H) continue;
     const float* b = B + (oy + R) * kGX + lane;
     float sum = 0.f;
-    for (int j = -R; j <= R; ++j) sum = sum + taps.k[R - j] * b[j * kGX];
+    if (RT > 0) {
+#pragma unroll
+      for (int j = -RT; j <= RT; ++j) sum = sum + taps.k[RT - j] * b[j * kGX];
+    } else {
+      for (int j = -R; j <= R; ++j) sum = sum + taps.k[R - j] * b[j * kGX];
+    }
     dst[f3d_row(g, gy, z) + gx] = sum;
   }
 }
@@ -86,6 +100,43 @@ __global__ __launch_bounds__(256) void k_gauss_z(float* __restrict__ dst, const 
         s = s + 1 == K ? 0 : s + 1;
       }
       dst[f3d_row(g, y, zo) + x] = sum;
+    }
+  }
+}
+
+// The same march with the window in registers: 2 RT + 1 values, roles rotated by unrolling the plane loop 2 RT + 1 deep, so
+// nothing is ever moved.  Per output 2 RT + 1 multiplies and adds, one load, one store, no LDS.
+template <int RT>
+__global__ __launch_bounds__(256) void k_gauss_z_reg(float* __restrict__ dst, const float* __restrict__ src, F3dGeo g,
+                                                     f3d::ConvTaps taps, int zchunk)
+{
+  constexpr int K = 2 * RT + 1;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  if (x >= g.W || y >= g.H) return;
+  const size_t plane = static_cast<size_t>(g.Hc) * static_cast<size_t>(g.pitch);
+  const float* in = src + f3d_row(g, y, g.z_base) + x;   // in[(p - z_base) * plane] = plane p
+  float* out = dst + f3d_row(g, y, g.z_base) + x;
+  float win[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) win[i] = 0.f;
+  // plane p goes to win[(p - (z0 - RT)) mod K]; after it the window of output p - RT is complete
+  for (int pb = z0 - RT; pb < z1 + RT; pb += K) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int p = pb + i;
+      if (p < z1 + RT) {
+        win[i] = (p >= 0 && p < g.D) ? in[static_cast<size_t>(p - g.z_base) * plane] : 0.f;
+        const int zo = p - RT;
+        if (zo >= z0) {
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < K; ++j) sum = sum + taps.k[K - 1 - j] * win[(i + 1 + j) % K];  // oldest plane first: ascending z
+          out[static_cast<size_t>(zo - g.z_base) * plane] = sum;
+        }
+      }
     }
   }
 }
@@ -125,7 +176,12 @@ int f3d_conv_rows_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t heig
   const int R = static_cast<int>(kernel_radius);
   const size_t lds = static_cast<size_t>(kGY + 2 * R) * (kGX + 2 * R + kGX) * sizeof(float);
   const dim3 grid((g.W + kGX - 1) / kGX, (g.H + kGY - 1) / kGY, g.z_hi - g.z_lo), block(64, 4, 1);
-  hipLaunchKernelGGL(k_gauss_xy, grid, block, lds, f3d::stream(), f3d_ptr<float>(dst), f3d_ptr<const float>(src), g, f3d::conv_taps(), R);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, block, lds, f3d::stream(), f3d_ptr<float>(dst), f3d_ptr<const float>(src), g, f3d::conv_taps(), R);
+  };
+  if (R == 6) go(k_gauss_xy<6>);
+  else if (R == 3) go(k_gauss_xy<3>);
+  else go(k_gauss_xy<0>);
   F3D_HIP(hipGetLastError());
   return 0;
 }
@@ -152,8 +208,11 @@ int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height,
   const int zchunk = static_cast<int>((planes + chunks - 1) / chunks);
   const dim3 grid((g.W + 63) / 64, (g.H + 3) / 4, (planes + zchunk - 1) / zchunk), block(64, 4, 1);
   const size_t lds = static_cast<size_t>(2 * R + 1) * 256 * sizeof(float);
-  hipLaunchKernelGGL(k_gauss_z, grid, block, lds, f3d::stream(), f3d_ptr<float>(dst), f3d_ptr<const float>(src), g, f3d::conv_taps(), R,
-                     zchunk);
+  float* o = f3d_ptr<float>(dst);
+  const float* i = f3d_ptr<const float>(src);
+  if (R == 6) hipLaunchKernelGGL(k_gauss_z_reg<6>, grid, block, 0, f3d::stream(), o, i, g, f3d::conv_taps(), zchunk);
+  else if (R == 3) hipLaunchKernelGGL(k_gauss_z_reg<3>, grid, block, 0, f3d::stream(), o, i, g, f3d::conv_taps(), zchunk);
+  else hipLaunchKernelGGL(k_gauss_z, grid, block, lds, f3d::stream(), o, i, g, f3d::conv_taps(), R, zchunk);
   F3D_HIP(hipGetLastError());
   return 0;
 }

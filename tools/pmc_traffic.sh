@@ -19,8 +19,10 @@ for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        for key in ("k_sweep7", "k_sweep6", "k_phiksi6", "k_flat", "k_march_packed", "k_march"):
+        for key in ("k_pair8ILi0", "k_pair8ILi1", "k_pair8<0", "k_pair8<1", "k_sweep7", "k_sweep6", "k_phiksi6", "k_flat", "k_march_packed", "k_march"):
             if key in n:
+                if key.startswith("k_pair8"):
+                    key = "k_pair8" if key.endswith("0") else "k_pair8_sweep_phi_ksi"
                 if key == "k_flat":
                     key = "k_flat<float4>" if "float4" in n or "HIP_vector" in n else "k_flat<float>"
                 agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -28,6 +30,8 @@ for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
     for (k, c), v in sorted(agg.items()):
         res.setdefault(k, {})[c] = sum(v) / len(v)
         print(f"{d:10s} {k:18s} {c:11s} launches {len(v):3d}  avg {sum(v) / len(v):.6g} KiB")
+import hashlib
+res["_solver_source_sha16"] = hashlib.sha256(open("$R/cuda-flow3d_amd/csrc/f3d_solve.hip", "rb").read() + open("$R/cuda-flow3d_amd/csrc/f3d_solve_pair8.h", "rb").read()).hexdigest()[:16]
 json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
 PY
 rm -rf $O/cal_fetch $O/cal_write $O/k_fetch $O/k_write
