@@ -110,6 +110,7 @@ def hip():
         "f3d_conv_cols": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
         "f3d_conv_slices": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
         "f3d_conv_rows_cols": [_dp, _dp, _sz, _sz, _sz, _sz, _slabp],
+        "f3d_range_push": [C.c_char_p], "f3d_range_pop": [],
         "f3d_prof_enable": [C.c_int], "f3d_prof_reset": [], "f3d_prof_select": [C.c_uint],
         "f3d_prof_read": [C.c_int, _sz, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
         "f3d_abs_max": [_dp, _sz, _sz, _sz, _slabp, _fp],

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <vector>
 
@@ -196,6 +197,51 @@ int f3d_shutdown(void)
 }
 
 int f3d_is_initialized(void) { return S.ready ? 1 : 0; }
+
+namespace {
+struct Roctx {
+  bool tried = false;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+} X;
+
+bool roctx_ready()
+{
+  if (X.tried) return X.push != nullptr;
+  X.tried = true;
+  const char* want = std::getenv("F3D_ROCTX");
+  bool on = want && want[0] == '1';
+  if (!want) {  // a rocprofiler tool library in the process: ranges are wanted
+    for (const char* var : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"}) {
+      const char* v = std::getenv(var);
+      if (v && std::strstr(v, "rocprof")) on = true;
+    }
+  }
+  if (!on) return false;
+  void* h = nullptr;
+  for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return false;
+  X.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+  X.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+  if (!X.push || !X.pop) X.push = nullptr;
+  return X.push != nullptr;
+}
+}  // namespace
+
+int f3d_range_push(const char* name)
+{
+  if (name && roctx_ready()) X.push(name);
+  return 0;
+}
+
+int f3d_range_pop(void)
+{
+  if (roctx_ready()) X.pop();
+  return 0;
+}
 
 int f3d_device_name(char* name, size_t capacity)
 {

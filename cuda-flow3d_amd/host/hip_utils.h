@@ -20,6 +20,15 @@ inline bool CheckDeviceErrorAt(int status, const char* file, int line)
   return false;
 }
 
+// A profiler range for the lifetime of the object (f3d_range_push / f3d_range_pop: roctx, only when a profiler is attached).
+class ProfilerRange {
+ public:
+  explicit ProfilerRange(const char* name) { f3d_range_push(name); }
+  ~ProfilerRange() { f3d_range_pop(); }
+  ProfilerRange(const ProfilerRange&) = delete;
+  ProfilerRange& operator=(const ProfilerRange&) = delete;
+};
+
 // cuda_utils.cpp:21-57: pick the first device, print its name, create the context.
 bool InitDeviceContextWithFirstAvailableDevice();
 void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_height, size_t device_pitch);

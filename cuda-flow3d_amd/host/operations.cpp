@@ -52,6 +52,7 @@ bool CudaOperationBase::InitializeContainer(const OperationParameters* params)
 void CudaOperationAdd::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr operand_0, operand_1;
   DataSize4 data_size;
   GET_PARAM_OR_RETURN(params, DevicePtr, operand_0, "operand_0");
@@ -65,6 +66,7 @@ void CudaOperationAdd::Execute(OperationParameters& params)
 void CudaOperationStat::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr dev_flow_u, dev_flow_v, dev_flow_w;
   DataSize4 data_size;
   Stat3* p_stat;
@@ -122,6 +124,7 @@ void CudaOperationConvolution3D::PrintConvolutionKernel() const
 void CudaOperationConvolution3D::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr dev_input = 0, dev_output = 0, dev_temp = 0;
   DataSize4 data_size;
   float gaussian_sigma;
@@ -150,6 +153,7 @@ void CudaOperationConvolution3D::Execute(OperationParameters& params)
 void CudaOperationMedian::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr dev_input, dev_output;
   DataSize4 data_size;
   size_t radius;
@@ -182,6 +186,7 @@ void CudaOperationMedian::Execute(OperationParameters& params)
 void CudaOperationRegistration::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, dev_output;
   float hx, hy, hz;
   DataSize4 data_size;
@@ -208,6 +213,7 @@ void CudaOperationRegistration::Execute(OperationParameters& params)
 void CudaOperationResample::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
   DevicePtr dev_input = 0, dev_output = 0, dev_temp = 0;
   DataSize4 data_size, resample_size;
   GET_PARAM_OR_RETURN(params, DevicePtr, dev_input, "dev_input");
@@ -276,6 +282,7 @@ void CudaOperationSolve::Destroy()
 void CudaOperationSolve::Execute(OperationParameters& params)
 {
   if (!IsInitialized()) return;
+  ProfilerRange range(GetName());
 
   DevicePtr dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, dev_phi, dev_ksi;
   GET_PARAM_OR_RETURN(params, DevicePtr, dev_frame_0, "dev_frame_0");

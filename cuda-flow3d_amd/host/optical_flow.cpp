@@ -450,6 +450,9 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
     PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
     DataSize4 current = lv.size;
     float hx = lv.hx, hy = lv.hy, hz = lv.hz;
+    char range_name[64];
+    std::snprintf(range_name, sizeof(range_name), "level %d (%zu x %zu x %zu)", level, current.width, current.height, current.depth);
+    ProfilerRange level_range(range_name);
     if (!silent)
       std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", level, current.width, current.height, current.depth);
 

@@ -204,6 +204,13 @@ int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height,
 int f3d_conv_rows_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
                        const f3d_slab* slab);
 
+/* ---- profiler ranges (no reference counterpart; SURVEY.md section 5 "tracing") ---------------------------------
+ * roctx ranges around operators and pyramid levels so that rocprofv3 --marker-trace attributes kernels to them.
+ * librocprofiler-sdk-roctx is dlopen'ed on the first push and only when F3D_ROCTX=1 is set or a rocprofiler tool library
+ * is preloaded; otherwise both calls return at once.  Ranges nest; pop closes the innermost. */
+int f3d_range_push(const char* name);
+int f3d_range_pop(void);
+
 /* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
 
 enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_SWEEP_PHI_KSI = 3, F3D_K_COUNT = 4 };

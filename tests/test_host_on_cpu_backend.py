@@ -1,0 +1,98 @@
+"""The product's HOST code without a GPU: libf3d_host.so (drivers, operators, slab planner and exchanges, out-of-core chunking)
+built against tests/cpu_device -- the C ABI of include/f3d.h on host memory with the oracle's kernels as the compute -- once
+plainly and once under AddressSanitizer + UndefinedBehaviorSanitizer.  Whatever the drivers do with containers, swaps, windows,
+halos and chunks, a whole ComputeFlow must come out bit-identical to the oracle's own whole-pipeline function; under the
+sanitizers the same runs must finish without a report.
+
+Each case runs in a process of its own: the package is pointed at the stand-in library directory BEFORE it loads anything
+(a module global of the binding, patched here by the test -- the product never does that), and the sanitizer runtime has to
+be preloaded into the interpreter."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = os.path.join(ROOT, "tests", "cpu_device")
+
+CASE = textwrap.dedent('''
+    import importlib, os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["F3D_ROOT"])
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    pkg._LIBDIR = os.environ["F3D_TEST_LIBDIR"]          # test-only: the host-memory stand-in
+    from oracle import oracle as orc
+    what = sys.argv[1]
+    W, H, D = 26, 22, 20
+    f0, f1 = pkg.synth_pair(W, H, D)
+    kw = dict(warp_levels_count=5, outer_iterations_count=3, inner_iterations_count=5)
+    (eu, ev, ew), _ = orc.compute_flow(f0, f1, **kw)
+    same = lambda a, b: a.shape == b.shape and bool(np.all(a == b)) and not np.isnan(a).any()
+    if what == "resident":
+        flow = pkg.OpticalFlow(); flow.initialize(W, H, D)
+        got = flow.compute(f0, f1, silent=True, **kw)
+        flow.upload(f0, f1); flow.set_level_stats(True); flow.compute_resident(silent=True, **kw)
+        got2 = flow.download(); stats = flow.level_stats(); reg, unreg = flow.final_residual()
+        flow.destroy()
+        assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), "OpticalFlowE on the host backend differs from the oracle"
+        assert all(same(g, e) for g, e in zip(got2, (eu, ev, ew)))
+        assert len(stats) == 5 and reg[0] < unreg[0]
+        # even inner count (pairs only) and a single sweep per outer iteration (no pair at all)
+        for inner in (4, 1):
+            kw2 = dict(kw, inner_iterations_count=inner)
+            (xu, xv, xw), _ = orc.compute_flow(f0, f1, **kw2)
+            flow = pkg.OpticalFlow(); flow.initialize(W, H, D)
+            got = flow.compute(f0, f1, silent=True, **kw2); flow.destroy()
+            assert all(same(g, e) for g, e in zip(got, (xu, xv, xw))), inner
+    elif what == "slabs":
+        for ranks in (2, 3):
+            flow = pkg.SlabOpticalFlow(ranks, list(range(ranks)), halo_capacity=16); flow.initialize(W, H, D)
+            got = flow.compute(f0, f1, **kw); flow.destroy()
+            assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), f"{ranks} slabs on the host backend differ from the oracle"
+        # a rank list that is not 0 .. n-1 is refused
+        bad = pkg.SlabOpticalFlow(2, [1, 0], halo_capacity=16)
+        try:
+            bad.initialize(W, H, D); raise SystemExit("a permuted rank list was accepted")
+        except pkg.F3dError:
+            pass
+        bad.destroy()
+    elif what == "piecemeal":
+        os.environ["F3D_P_BUDGET_MB"] = "1.3"             # the finest levels go through the "device" in chunks
+        flow = pkg.PiecemealOpticalFlow(); flow.initialize(W, H, D); flow.set_full_pipeline(True)
+        got = flow.compute(f0, f1, silent=True, **kw); passes, streamed, resident = flow.stats(); flow.destroy()
+        assert streamed >= 1, (passes, streamed, resident)
+        assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), "OpticalFlowP --full on the host backend differs from the oracle"
+    pkg.shutdown()
+    print("ok", what)
+''')
+
+
+def build(target):
+    subprocess.run(["make", "-C", CPU, target, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(CPU, "_build", "asan" if target == "asan" else "plain")
+
+
+def run_case(what, libdir, sanitized):
+    env = dict(os.environ, F3D_ROOT=ROOT, F3D_TEST_LIBDIR=libdir, OMP_NUM_THREADS="2")
+    if sanitized:
+        asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+        ubsan = subprocess.run(["gcc", "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+        if not os.path.isabs(asan):
+            pytest.skip("no libasan in this toolchain")
+        env.update(LD_PRELOAD=f"{asan} {ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:handle_segv=1",
+                   UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", CASE, what], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and f"ok {what}" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal"])
+def test_host_drivers_equal_the_oracle_on_the_cpu_backend(what):
+    run_case(what, build("all"), sanitized=False)
+
+
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal"])
+def test_host_drivers_are_clean_under_asan_and_ubsan(what):
+    run_case(what, build("asan"), sanitized=True)
