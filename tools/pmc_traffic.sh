@@ -33,5 +33,21 @@ for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
 import hashlib
 res["_solver_source_sha16"] = hashlib.sha256(open("$R/cuda-flow3d_amd/csrc/f3d_solve.hip", "rb").read() + open("$R/cuda-flow3d_amd/csrc/f3d_solve_pair8.h", "rb").read()).hexdigest()[:16]
 json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
+# the record bench.py reads (profiles/rNN_pmc_traffic.json): HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+S = 512
+alg = {"k_pair8": 104.0, "k_pair8_sweep_phi_ksi": 92.0, "k_sweep7": 104.0, "k_sweep6": 52.0, "k_phiksi6": 40.0}
+out = {"_note": "HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                "separate passes over tools/kbench.py --size 512 (tools/pmc_traffic.sh); both counters are in KiB; FETCH_SIZE is doubled as "
+                "MI355X_MICROARCH.md prescribes for gfx950, and the same run calibrates it on tools/lab/stream_lab (k_flat reads 10 x 512 MiB, "
+                "writes 3 x 512 MiB).",
+       "_size": S, "_solver_source_sha16": res["_solver_source_sha16"],
+       "_calibration": {k: v for k, v in res.items() if k.startswith("k_flat")}}
+for k, b in alg.items():
+    if k in res and "FETCH_SIZE" in res[k] and "WRITE_SIZE" in res[k]:
+        hbm = (2 * res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024
+        out[k] = {"fetch_size_kib_reported": res[k]["FETCH_SIZE"], "write_size_kib": res[k]["WRITE_SIZE"], "hbm_bytes_per_launch": int(hbm),
+                  "algorithmic_bytes_per_launch": int(b * S ** 3), "ratio": round(hbm / (b * S ** 3), 3)}
+json.dump(out, open("$O/pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 PY
 rm -rf $O/cal_fetch $O/cal_write $O/k_fetch $O/k_write

@@ -32,9 +32,12 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
-        for name in ("k_sweep7", "k_sweep6", "k_phiksi6"):
-            if name in r["Kernel_Name"]:
-                agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        kn = r["Kernel_Name"]
+        for name, key in (("k_pair8<0", "k_pair8 (two sweeps)"), ("k_pair8<1", "k_pair8 (sweep + phi/ksi)"), ("k_sweep7", "k_sweep7"),
+                          ("k_sweep6", "k_sweep6"), ("k_phiksi6", "k_phiksi6")):
+            if name in kn:
+                agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                break
     for (k, c), v in sorted(agg.items()):
         lines.append(f"| {k} | {c} | {sum(v) / len(v):.6g} |")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
