@@ -279,6 +279,7 @@ __device__ __forceinline__ void sweep_voxel_s(const Face6& xm, const Face6& xp, 
 // (du becomes Su = u + du; Sv, Sw are kept beside dv, dw because the in-voxel Gauss-Seidel step still needs those).
 struct PlaneRegs {
   float f0, f1, phi, u, v, w, su, dv, dw, sv, sw, ksi;
+  float fz, ft;  // k_pair8 on precomputed frame derivatives: f0, f1 then hold fx, fy (dead code elsewhere)
 };
 
 __device__ __forceinline__ void plane_finish(PlaneRegs& p)
@@ -762,17 +763,25 @@ struct S3 {
 };
 
 // sweep_voxel_s, additionally handing out what stage 2 of the same voxel reuses (same operations, same order)
+// FD: the frame derivatives of the voxel are handed in (gfx, gfy, gfz, gft: computed once per level by k_frame_derivatives with
+// the same expressions) instead of being formed from the neighbours' frame values
+template <bool FD = false>
 __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, const Face6& ym, const Face6& yp,
                                              const Face6& zm, const Face6& zp, const float (&c)[kNL], float Uc, float Vc,
                                              float Wc, float dVc, float dWc, float ksi, float hx, float hy, float hz,
                                              const FDivs& fd, float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym,
-                                             bool has_zp, bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k)
+                                             bool has_zp, bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k,
+                                             float gfx = 0.f, float gfy = 0.f, float gfz = 0.f, float gft = 0.f)
 {
-  float fq[3] = {xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1], yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1],
-                 zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1]};
-  f_derivatives(fq, fd);
+  float fq[3] = {gfx, gfy, gfz};
+  if (!FD) {
+    fq[0] = xp.v[LF0] - xm.v[LF0] + xp.v[LF1] - xm.v[LF1];
+    fq[1] = yp.v[LF0] - ym.v[LF0] + yp.v[LF1] - ym.v[LF1];
+    fq[2] = zp.v[LF0] - zm.v[LF0] + zp.v[LF1] - zm.v[LF1];
+    f_derivatives(fq, fd);
+  }
   const float fx = fq[0], fy = fq[1], fz = fq[2];
-  const float ft = c[LF1] - c[LF0];
+  const float ft = FD ? gft : c[LF1] - c[LF0];
   k.fx = fx; k.fy = fy; k.fz = fz; k.ft = ft;
 
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
@@ -1194,6 +1203,27 @@ inline int max_planes_per_chunk(const F3dGeo& g)
   return planes < 1 ? 1 : (planes > 0x3fffffff ? 0x3fffffff : static_cast<int>(planes));
 }
 
+// Frame derivatives of a level, once: fx, fy, fz as A.3 / A.4 form them (the numerator left to right, one IEEE division by 4h)
+// and ft = F1 - F0.  They depend on the two frames of the level only, which no solver launch changes, so the 120 launches of a
+// level that would each recompute them read them instead (k_pair8 with FD).
+__global__ __launch_bounds__(256) void k_frame_derivatives(const float* __restrict__ f0, const float* __restrict__ f1, F3dGeo g, float hx,
+                                                           float hy, float hz, float* __restrict__ fx, float* __restrict__ fy,
+                                                           float* __restrict__ fz, float* __restrict__ ft)
+{
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (x >= g.W || y >= g.H) return;
+  const size_t c = f3d_row(g, y, z) + x;
+  const size_t xm = f3d_row(g, y, z) + f3d_mir(x - 1, g.W), xp = f3d_row(g, y, z) + f3d_mir(x + 1, g.W);
+  const size_t ym = f3d_row(g, f3d_mir(y - 1, g.H), z) + x, yp = f3d_row(g, f3d_mir(y + 1, g.H), z) + x;
+  const size_t zm = f3d_row(g, y, f3d_mir(z - 1, g.D)) + x, zp = f3d_row(g, y, f3d_mir(z + 1, g.D)) + x;
+  fx[c] = (f0[xp] - f0[xm] + f1[xp] - f1[xm]) / (4.f * hx);
+  fy[c] = (f0[yp] - f0[ym] + f1[yp] - f1[ym]) / (4.f * hy);
+  fz[c] = (f0[zp] - f0[zm] + f1[zp] - f1[zm]) / (4.f * hz);
+  ft[c] = f1[c] - f0[c];
+}
+
 #include "f3d_solve_pair8.h"
 
 // k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
@@ -1484,6 +1514,80 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
   f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
   F3D_HIP(hipGetLastError());
   return 0;
+}
+
+int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, size_t height, size_t depth, float hx, float hy,
+                          float hz, f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_frame_derivatives");
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_frame_derivatives")) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_frame_derivatives: every dimension must be at least 2");
+  for (f3d_devptr o : {fx, fy, fz, ft})
+    if (o == frame_0 || o == frame_1) return f3d::fail("f3d_frame_derivatives: an output aliases a frame");
+  if (g.z_lo == g.z_hi) return 0;
+  if (!slab_reach_ok(g, 1, "f3d_frame_derivatives")) return 1;
+  const dim3 grid((g.W + 63) / 64, (g.H + 3) / 4, g.z_hi - g.z_lo), block(64, 4, 1);
+  hipLaunchKernelGGL(k_frame_derivatives, grid, block, 0, f3d::stream(), f3d_ptr<const float>(frame_0), f3d_ptr<const float>(frame_1), g, hx,
+                     hy, hz, f3d_ptr<float>(fx), f3d_ptr<float>(fy), f3d_ptr<float>(fz), f3d_ptr<float>(ft));
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
+// the two fused launches on precomputed frame derivatives
+int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], size_t width, size_t height, size_t depth, float hx, float hy,
+             float hz, float alpha, float eps_s, float eps_d, const f3d_devptr (&out)[5], const f3d_slab* slab)
+{
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("%s: every dimension must be at least 2", who);
+  if (g.pitch % kLanes != 0) return f3d::fail("%s: the container pitch must be a multiple of 256 bytes (f3d_alloc_pitched gives that)", who);
+  if (with_weights && (out[3] == in[8] || out[4] == in[9] || out[3] == in[9] || out[4] == in[8]))
+    return f3d::fail("%s: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)", who);
+  if (g.z_lo == g.z_hi) return 0;
+  if (!slab_reach_ok(g, 2, who)) return 1;
+  PairArgs a = {};
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
+  for (int i = 0; i < 12; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
+  for (int i = 0; i < 5; ++i) a.out[i] = f3d_ptr<float>(out[i]);
+  a.hx = hx; a.hy = hy; a.hz = hz;
+  a.alpha = alpha;
+  a.eps_s = eps_s;
+  a.eps_d = eps_d;
+  const int kid = with_weights ? F3D_K_SWEEP_PHI_KSI : F3D_K_SWEEP2;
+  f3d::prof_begin(kid, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
+  if (with_weights) launch_pair8<PAIR_SP, 8, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+  else launch_pair8<PAIR_SS, 8, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+  f3d::prof_end(kid);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int f3d_solve_sweep2_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                        f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                        size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, f3d_devptr temp_du,
+                        f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep2_fd");
+  const f3d_devptr in[12] = {fx, fy, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi, fz, ft};
+  const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, 0, 0};
+  return pair8_fd("f3d_solve_sweep2_fd", false, in, width, height, depth, hx, hy, hz, equation_alpha, 0.f, 0.f, out, slab);
+}
+
+int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v,
+                               f3d_devptr flow_w, f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi,
+                               f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                               float equation_alpha, float equation_smoothness, float equation_data, f3d_devptr temp_du,
+                               f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep_phi_ksi_fd");
+  const f3d_devptr in[12] = {fx, fy, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi, fz, ft};
+  const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, phi_next, ksi_next};
+  return pair8_fd("f3d_solve_sweep_phi_ksi_fd", true, in, width, height, depth, hx, hy, hz, equation_alpha, equation_smoothness,
+                  equation_data, out, slab);
 }
 
 }  // extern "C"

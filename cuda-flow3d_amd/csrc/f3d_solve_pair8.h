@@ -38,29 +38,31 @@
 enum { PAIR_SS = 0, PAIR_SP = 1 };
 
 struct PairArgs {
-  const float* in[10];  // f0, f1(warped), u, v, w, du, dv, dw, phi, ksi
+  // f0, f1(warped), u, v, w, du, dv, dw, phi, ksi; on precomputed frame derivatives (FD): fx, fy in place of f0, f1 and
+  // fz, ft as arrays 10, 11
+  const float* in[12];
   float* out[5];        // temp_du, temp_dv, temp_dw; PAIR_SP: new phi, new ksi
   float hx, hy, hz, alpha;
   float eps_s, eps_d;   // PAIR_SP
   int plain_division;   // timing experiments (F3D_UDIV=0)
 };
 
-template <int TY>
+template <int TY, int NA = 10>
 struct Pair8Lds {
   static constexpr int NR = TY + 2;                   // row waves
   static constexpr int NJ = TY + 4;                   // ring rows: y0-2 .. y0+TY+1
   static constexpr int NK = (NJ + 3) / 4;             // row pieces (4 rows x 64 floats = 1 KiB) per array and plane
   static constexpr int NJP = NJ;                      // rows per array in the ring (a partial last piece masks its surplus lanes)
-  static constexpr int kHaloLanes = 10 * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
+  static constexpr int kHaloLanes = NA * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
   static constexpr int NH = (kHaloLanes + 63) / 64;   // halo instructions per plane
-  static constexpr int kRowFloats = 10 * NJP * 64;
+  static constexpr int kRowFloats = NA * NJP * 64;
   static constexpr int kHaloOff = kRowFloats;         // float offset of the halo area inside a slot
   static constexpr int kSlotFloats = kRowFloats + NH * 256;
   // Three slots hold TWO planes in flight: everything a step reads of plane p (its rows as z+1 plane during step p-1, its
   // neighbour rows and halo columns at the end of step p-1) has been read when barrier B_p falls, so at step q the loader
   // refills the slot of plane q with plane q+3 while q+1 is being read and q+2 is landing.
   static constexpr int kSlots = 3;
-  static constexpr int kPerPlane = 10 * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
+  static constexpr int kPerPlane = NA * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
 };
 
 // A wave-uniform pointer moved into scalar registers for good: the "s" operands of the hand-issued memory instructions need
@@ -137,11 +139,15 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
 
 // ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
 // arithmetic (LDS traffic, barriers and stores stay), bit 2 = the compute waves only keep the barriers
-template <int MODE, int TY, int ABL = 0>
+// FD: the kernel reads the frame derivatives fx, fy, fz, ft (k_frame_derivatives, once per level) instead of the frames: they
+// are centre values, so the frame entries of every neighbour -- their LDS reads, lane shifts, differences and the three
+// divisions by 4h -- drop out of stage 1 (a seventh of its arithmetic), for two more arrays to stream.
+template <int MODE, int TY, int ABL = 0, bool FD = false>
 __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                            int xcd_remap)
 {
-  using L = Pair8Lds<TY>;
+  constexpr int NA = FD ? 12 : 10;
+  using L = Pair8Lds<TY, NA>;
   constexpr int NR = L::NR, NJ = L::NJ, NK = L::NK, NJP = L::NJP, NH = L::NH;
   static_assert(TY <= 32, "the column wave holds one halo voxel per lane: 2 x TY <= 64");
   __shared__ __attribute__((aligned(16))) float ring[L::kSlots][L::kSlotFloats];
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   if (loader) {
     // the youngest wave of its SIMD would otherwise get the issue slots the arithmetic of the older two leaves over
     __builtin_amdgcn_s_setprio(3);
-    const float* base[10];
+    const float* base[NA];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) base[i] = uniform_ptr(a.in[i] + base_off);
+    for (int i = 0; i < NA; ++i) base[i] = uniform_ptr(a.in[i] + base_off);
     // row pieces: lane -> (row 4k + lane/16, floats 4 (lane%16) ..)
     unsigned rowb[NK];
     bool rowv[NK];
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       const int j = lq % NJ;
       const float* b = base[0];
 #pragma unroll
-      for (int i = 1; i < 10; ++i)
+      for (int i = 1; i < NA; ++i)
         if (arr == i) b = base[i];
       const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, g.H), 0, g.H - 1);
       // tiles at an x face fetch a piece from inside the row instead (never used: the mirror rule substitutes there)
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 #pragma unroll
       for (int k = 0; k < NK; ++k) off[k] = rowb[k] + poff;
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
+      for (int i = 0; i < NA; ++i) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
           if (NJ % 4 == 0 || rowv[k]) dma16(base[i], off[k], slot + (i * NJP + 4 * k) * kLanes);
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   auto fake_raw = [&](PlaneRegs& p) __attribute__((always_inline)) {  // ABL bit 3: no LDS traffic, values from registers
     p.f0 = opaque(seedv); p.f1 = opaque(seedv); p.u = opaque(seedv); p.v = opaque(seedv); p.w = opaque(seedv);
     p.su = opaque(seedv); p.dv = opaque(seedv); p.dw = opaque(seedv); p.phi = opaque(seedv); p.ksi = opaque(seedv);
+    p.fz = opaque(seedv); p.ft = opaque(seedv);
   };
   auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi) __attribute__((always_inline)) {
     if (ABL & 8) return fake_raw(p);
@@ -304,6 +311,10 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
     p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
     if (with_ksi) p.ksi = d[9 * st];
+    if (FD && with_ksi) {
+      p.fz = d[10 * st];
+      p.ft = d[11 * st];
+    }
   };
   auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi) __attribute__((always_inline)) {
     if (ABL & 8) return fake_raw(p);
@@ -312,6 +323,10 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
     p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
     if (with_ksi) p.ksi = d[9 * st];
+    if (FD && with_ksi) {
+      p.fz = d[10 * st];
+      p.ft = d[11 * st];
+    }
   };
 
   S3 hM = {0.f, 0.f, 0.f}, hC = {0.f, 0.f, 0.f};  // stage-1 result of planes q-2 and q-1 (SS: S = U + dU'; SP: dU')
@@ -450,8 +465,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
         kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
       } else
-      sweep_stage1(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                   fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN);
+      sweep_stage1<FD>(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
+                       fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN, C.f0,
+                       C.f1, C.fz, C.ft);
       pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
       pN.D[0] = rxp.u - rxm.u; pN.D[1] = nDy.u; pN.D[2] = P.u - M.u;
       pN.D[3] = rxp.v - rxm.v; pN.D[4] = nDy.v; pN.D[5] = P.v - M.v;
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
 }
 
-template <int MODE, int TY>
+template <int MODE, int TY, bool FD = false>
 void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
   const int planes = g.z_hi - g.z_lo;
@@ -606,6 +622,7 @@ void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_
   const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
   static const int abl = std::getenv("F3D_ABLATE8") ? std::atoi(std::getenv("F3D_ABLATE8")) : 0;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
+  if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
   if constexpr (MODE == PAIR_SS) {
     if (abl == 1) return go(k_pair8<MODE, TY, 1>);
     if (abl == 2) return go(k_pair8<MODE, TY, 2>);

@@ -46,3 +46,12 @@ bool FusedPhiKsiEnabled()
   }();
   return on;
 }
+
+bool FrameDerivativesEnabled()
+{
+  static const bool on = [] {
+    const char* e = std::getenv("F3D_FRAME_DERIVATIVES");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}

@@ -37,5 +37,7 @@ void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_he
 bool FusedSweepsEnabled();
 // The last sweep of an outer iteration and the phi/ksi of the next one are one launch unless F3D_FUSED_PHI_KSI=0.
 bool FusedPhiKsiEnabled();
+// The fused launches read frame derivatives computed once per level unless F3D_FRAME_DERIVATIVES=0.
+bool FrameDerivativesEnabled();
 
 #endif

@@ -271,11 +271,30 @@ bool CudaOperationSolve::EnsureWeightScratch()
   return true;
 }
 
+bool CudaOperationSolve::EnsureDerivativeScratch()
+{
+  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  for (DevicePtr& p : fder_) {
+    if (p) continue;
+    size_t pitch = 0;
+    if (f3d_alloc_pitched(&p, &pitch, dev_container_size_.width * sizeof(float), rows) != 0 || pitch != dev_container_size_.pitch) {
+      if (p) f3d_free(p);
+      p = 0;
+      return false;
+    }
+  }
+  return true;
+}
+
 void CudaOperationSolve::Destroy()
 {
   if (phi_alt_) f3d_free(phi_alt_);
   if (ksi_alt_) f3d_free(ksi_alt_);
   phi_alt_ = ksi_alt_ = 0;
+  for (DevicePtr& p : fder_) {
+    if (p) f3d_free(p);
+    p = 0;
+  }
   CudaOperationBase::Destroy();
 }
 
@@ -341,6 +360,12 @@ void CudaOperationSolve::Execute(OperationParameters& params)
                             outer_iterations_count > 1 && dev_container_size_.pitch % 256 == 0 && EnsureWeightScratch();
   DevicePtr phi_cur = dev_phi, ksi_cur = dev_ksi, phi_nxt = phi_alt_, ksi_nxt = ksi_alt_;
   bool weights_ready = false;
+  // The frame derivatives fx, fy, fz, ft depend on the two frames only: computed once here, read by every fused launch of the level
+  // instead of the frames (the reference recomputes them for every voxel in each of its 240 launches per level).
+  const bool on_derivatives = FusedSweepsEnabled() && FrameDerivativesEnabled() && slab_ == nullptr && inner_iterations_count >= 2 &&
+                              dev_container_size_.pitch % 256 == 0 && EnsureDerivativeScratch() &&
+                              !CheckDeviceError(f3d_frame_derivatives(dev_frame_0, dev_frame_1, w, h, d, hx, hy, hz, fder_[0], fder_[1],
+                                                                      fder_[2], fder_[3], nullptr));
   for (size_t i = 0; i < outer_iterations_count; ++i) {
     if (!weights_ready &&
         CheckDeviceError(f3d_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, w, h, d,
@@ -351,9 +376,16 @@ void CudaOperationSolve::Execute(OperationParameters& params)
       const bool pair = FusedSweepsEnabled() && j + 2 <= inner_iterations_count;
       const bool with_weights = !pair && fuse_weights && j + 1 == inner_iterations_count && i + 1 < outer_iterations_count;
       int status;
-      if (pair)
+      if (pair && on_derivatives)
+        status = f3d_solve_sweep2_fd(fder_[0], fder_[1], fder_[2], fder_[3], dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr,
+                                     *dw_ptr, phi_cur, ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      else if (pair)
         status = f3d_solve_sweep2(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur,
                                   ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      else if (with_weights && on_derivatives)
+        status = f3d_solve_sweep_phi_ksi_fd(fder_[0], fder_[1], fder_[2], fder_[3], dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr,
+                                            *dv_ptr, *dw_ptr, phi_cur, ksi_cur, w, h, d, hx, hy, hz, equation_alpha,
+                                            equation_smoothness, equation_data, *tdu_ptr, *tdv_ptr, *tdw_ptr, phi_nxt, ksi_nxt, slab_);
       else if (with_weights)
         status = f3d_solve_sweep_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr,
                                          phi_cur, ksi_cur, w, h, d, hx, hy, hz, equation_alpha, equation_smoothness, equation_data,

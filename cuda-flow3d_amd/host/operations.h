@@ -118,6 +118,10 @@ class CudaOperationSolve : public CudaOperationBase {
   // next outer iteration while other tiles still read the current ones); container sized, allocated on first use
   bool EnsureWeightScratch();
   DevicePtr phi_alt_ = 0, ksi_alt_ = 0;
+  // frame derivatives of the level (f3d_frame_derivatives once per Execute, then the _fd launchers): four more container-sized
+  // volumes owned by the operator
+  bool EnsureDerivativeScratch();
+  DevicePtr fder_[4] = {0, 0, 0, 0};
 };
 
 #endif

@@ -165,6 +165,24 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
                             float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
                             f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
 
+/* The frame derivatives of a level, once: fx, fy, fz = (((F0[+1] - F0[-1]) + F1[+1]) - F1[-1]) / (4 h) and ft = F1 - F0, exactly as
+ * compute_phi_ksi_3d and solve_3d form them for every voxel in every launch (src/kernels/solve_3d.cu:205-215, :438-448).  They depend
+ * on the two frames of the level only; the _fd launchers below read them instead of the frames.  A slab window [z_lo, z_hi) needs planes
+ * z_lo-1 .. z_hi of both frames inside the container. */
+int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, size_t height, size_t depth, float hx, float hy,
+                          float hz, f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, const f3d_slab* slab);
+/* f3d_solve_sweep2 and f3d_solve_sweep_phi_ksi on precomputed frame derivatives (same results bit for bit; the four derivative
+ * volumes must cover the planes the frames would have had to: z_lo-1 .. z_hi for a window [z_lo, z_hi)). */
+int f3d_solve_sweep2_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                        f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                        size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, f3d_devptr temp_du,
+                        f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
+int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v,
+                               f3d_devptr flow_w, f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi,
+                               f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                               float equation_alpha, float equation_smoothness, float equation_data, f3d_devptr temp_du,
+                               f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
+
 /* registration_3d, 12 args: cuda_operation_registration.cpp:110-122; kernel src/kernels/registration_3d.cu:28-82 */
 int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
              size_t width, size_t height, size_t depth, float hx, float hy, float hz, f3d_devptr output,

@@ -290,6 +290,52 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devp
                     ins[k] + (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f, o.W * sizeof(float));
   return 0;
 }
+// Frame derivatives: computed for real (same expressions as the device kernel), and the frames they came from are remembered by the
+// address of fx so that the _fd launchers can hand the oracle's frame-based kernels what they need.
+static std::map<f3d_devptr, std::pair<f3d_devptr, f3d_devptr>> g_frames_of;
+int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                          f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, const f3d_slab* slab)
+{
+  Geo o;
+  if (!make_geo(&o, width, height, depth, slab, "f3d_frame_derivatives")) return 1;
+  const float *a = P<float>(frame_0), *b = P<float>(frame_1);
+  const size_t plane = static_cast<size_t>(o.g.Hc) * o.g.pitch_f;
+  auto at = [&](int x, int y, int z) { return (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f + x; };
+  auto mir = [](int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - i - 2 : i); };
+  for (int z = o.g.z_lo; z < o.g.z_hi; ++z)
+    for (int y = 0; y < o.H; ++y)
+      for (int x = 0; x < o.W; ++x) {
+        const size_t c = at(x, y, z);
+        const size_t xm = at(mir(x - 1, o.W), y, z), xp = at(mir(x + 1, o.W), y, z);
+        const size_t ym = at(x, mir(y - 1, o.H), z), yp = at(x, mir(y + 1, o.H), z);
+        const size_t zm = at(x, y, mir(z - 1, o.D)), zp = at(x, y, mir(z + 1, o.D));
+        P<float>(fx)[c] = (a[xp] - a[xm] + b[xp] - b[xm]) / (4.f * hx);
+        P<float>(fy)[c] = (a[yp] - a[ym] + b[yp] - b[ym]) / (4.f * hy);
+        P<float>(fz)[c] = (a[zp] - a[zm] + b[zp] - b[zm]) / (4.f * hz);
+        P<float>(ft)[c] = b[c] - a[c];
+      }
+  g_frames_of[fx] = {frame_0, frame_1};
+  return 0;
+}
+int f3d_solve_sweep2_fd(f3d_devptr fx, f3d_devptr, f3d_devptr, f3d_devptr, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
+                        f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                        float alpha, f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw, const f3d_slab* slab)
+{
+  auto it = g_frames_of.find(fx);
+  if (it == g_frames_of.end()) return fail("f3d_solve_sweep2_fd: these derivatives were not made by f3d_frame_derivatives");
+  return f3d_solve_sweep2(it->second.first, it->second.second, u, v, w, du, dv, dw, phi, ksi, width, height, depth, hx, hy, hz, alpha, tdu, tdv,
+                          tdw, slab);
+}
+int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr, f3d_devptr, f3d_devptr, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du,
+                               f3d_devptr dv, f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx,
+                               float hy, float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw,
+                               f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  auto it = g_frames_of.find(fx);
+  if (it == g_frames_of.end()) return fail("f3d_solve_sweep_phi_ksi_fd: these derivatives were not made by f3d_frame_derivatives");
+  return f3d_solve_sweep_phi_ksi(it->second.first, it->second.second, u, v, w, du, dv, dw, phi, ksi, width, height, depth, hx, hy, hz, alpha,
+                                 eps_s, eps_d, tdu, tdv, tdw, phi_next, ksi_next, slab);
+}
 int f3d_warp(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, size_t width, size_t height, size_t depth, float hx,
              float hy, float hz, f3d_devptr output, const f3d_slab* slab)
 {

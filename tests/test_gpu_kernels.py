@@ -382,6 +382,50 @@ def test_sweep_and_next_phi_ksi_fused(f3d, oracle, dims, cdims, h):
         dev.close()
 
 
+@pytest.mark.parametrize("dims,cdims", CASES + BIG_CASES)
+@pytest.mark.parametrize("h", SPACINGS)
+def test_fused_launches_on_precomputed_frame_derivatives(f3d, oracle, dims, cdims, h):
+    """f3d_frame_derivatives once, then f3d_solve_sweep2_fd / f3d_solve_sweep_phi_ksi_fd: the same bits as the launches that
+    read the frames (and as the oracle).  The derivative volumes are checked on their own against numpy with the reference's
+    association order."""
+    rng = np.random.default_rng(hash((dims, h, 4)) % 2**32)
+    W, H, D = dims
+    arrs = solver_inputs(rng, dims, cdims)
+    alpha, eps_s, eps_d = 7.5, 0.001, 0.002
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, eps_s, eps_d)
+    # expected derivatives: mirrored neighbours, ((F0+ - F0-) + F1+) - F1-, one float32 division by 4h
+    f0, f1 = arrs[0][:D, :H, :W], arrs[1][:D, :H, :W]
+    def mirrored(a, axis, off):
+        n = a.shape[axis]
+        idx = np.arange(n) + off
+        idx = np.where(idx < 0, -idx, np.where(idx >= n, 2 * n - idx - 2, idx))
+        return np.take(a, idx, axis=axis)
+    def deriv(axis, hh):
+        num = ((mirrored(f0, axis, 1) - mirrored(f0, axis, -1)) + mirrored(f1, axis, 1)) - mirrored(f1, axis, -1)
+        return (num / (np.float32(4.0) * np.float32(hh))).astype(np.float32)
+    exp_d = [deriv(2, h[0]), deriv(1, h[1]), deriv(0, h[2]), (f1 - f0).astype(np.float32)]
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+        fd = [dev.out() for _ in range(4)]
+        f3d.check(f3d.hip().f3d_frame_derivatives(ptr[0], ptr[1], W, H, D, *h, *fd, None))
+        for name, g, e in zip(("fx", "fy", "fz", "ft"), fd, exp_d):
+            assert bit_same(dev.get(g)[:D, :H, :W], e), name
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(f3d.hip().f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, alpha, *outs[:3], None))
+        for name, g, e in zip("uvw", outs, s2):
+            assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W]), f"two sweeps on derivatives: d{name}"
+        f3d.check(f3d.hip().f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs, None))
+        for name, g, e in zip(("du", "dv", "dw", "phi", "ksi"), outs, list(s1) + [phi_n, ksi_n]):
+            assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W]), f"sweep + phi/ksi on derivatives: {name}"
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("dims,cdims", CASES[:5] + BIG_CASES[:1])
 def test_sweep_and_next_phi_ksi_slab_window(f3d, oracle, dims, cdims):
     """Slab launch of the fused sweep + phi/ksi: window [z_lo, z_hi) with two halo planes on either side inside the container."""

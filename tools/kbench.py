@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
 (f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
-   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|phi|both]
+   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|phi|both]
 """
 import argparse
 import ctypes as C
@@ -42,6 +42,8 @@ def main():
     h = (1.0, 1.0, 1.0)
     pkg.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
     pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+    fd = [cont.alloc(fill=0) for _ in range(4)]
+    pkg.check(hip.f3d_frame_derivatives(ptr[0], ptr[1], W, H, D, *h, *fd, None))
     pkg.sync()
     hip.f3d_prof_reset()
     hip.f3d_prof_enable(1)
@@ -52,6 +54,10 @@ def main():
             pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
         if a.kernel in ("sweep2", "both"):
             pkg.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+        if a.kernel in ("sweep2fd",):
+            pkg.check(hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, *out, None))
+        if a.kernel in ("sweeppkfd",):
+            pkg.check(hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
         if a.kernel in ("sweeppk", "both"):
             pkg.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
     pkg.sync()
