@@ -51,7 +51,7 @@ bool FrameDerivativesEnabled()
 {
   static const bool on = [] {
     const char* e = std::getenv("F3D_FRAME_DERIVATIVES");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   return on;
 }

@@ -37,7 +37,9 @@ void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_he
 bool FusedSweepsEnabled();
 // The last sweep of an outer iteration and the phi/ksi of the next one are one launch unless F3D_FUSED_PHI_KSI=0.
 bool FusedPhiKsiEnabled();
-// The fused launches read frame derivatives computed once per level unless F3D_FRAME_DERIVATIVES=0.
+// F3D_FRAME_DERIVATIVES=1: the fused launches read frame derivatives computed once per level instead of the frames.  Off by
+// default: measured on the MI355X it trades a seventh of the stage-1 arithmetic for a fifth more bytes through the loader and
+// comes out even; the launchers stay tested because they need 36 registers fewer.
 bool FrameDerivativesEnabled();
 
 #endif
