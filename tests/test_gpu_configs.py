@@ -3,10 +3,11 @@ pyramid (40 levels x 40 outer x 5 inner, Gaussian sigma 2, median 5^3).
 
 The oracle cannot reach these sizes, so the checks are differential and size independent:
   * the flow is finite and recovers the known translation (+2, -1, +0.5) in the textured interior;
-  * the same bits come out of four independent schedules of the same arithmetic -- the tuned resident driver, the
-    resident driver with every tuning switch that regroups work turned off (one launch per sweep, ordinary IEEE
-    division: F3D_FUSED_SWEEPS=0 F3D_UDIV=0), the z-slab multi-GPU driver with 8 ranks in this process, and the
-    out-of-core driver with a budget that cuts the finest levels into chunks;
+  * the same bits come out of independent schedules of the same arithmetic -- the tuned resident driver (three fused launches
+    per outer iteration), the resident driver with the fusions turned off (one launch per sweep, ordinary IEEE division:
+    F3D_FUSED_SWEEPS=0 F3D_UDIV=0), with the round-1 kernels, with frame derivatives computed once per level, the z-slab
+    multi-GPU driver with 8 ranks in this process, and the out-of-core driver with a budget that cuts the finest levels
+    into chunks;
   * the sha256 of (u, v, w) equals the digest committed in tests/golden/config_digests.json (a drift guard: every level
     of these runs goes through the kernels that tests/test_gpu_kernels.py pins against the oracle at 18^3 ... 584x388).
 Bit-exactness is the bar (max |diff| == 0); the north star's tolerance is RMS 1e-4.
@@ -94,9 +95,14 @@ def test_c4_digest_is_the_committed_one(c4):
     assert digest(c4["flow"]) == committed("c4_512_default_sha256")
 
 
-def test_c4_untuned_schedule_gives_the_same_bits(c4):
-    """one launch per sweep and ordinary division everywhere, in a process of its own (the switches are read once)"""
-    env = dict(os.environ, F3D_FUSED_SWEEPS="0", F3D_UDIV="0", F3D_SMALL_LEVEL="0")
+@pytest.mark.parametrize("switches", [
+    {"F3D_FUSED_SWEEPS": "0", "F3D_UDIV": "0"},     # one launch per sweep and per phi/ksi, ordinary division everywhere
+    {"F3D_PAIR8": "0", "F3D_FUSED_PHI_KSI": "0"},    # the round-1 schedule: k_sweep7 pairs, separate phi/ksi and fifth sweep
+    {"F3D_FRAME_DERIVATIVES": "1"},                   # fused launches on frame derivatives computed once per level
+], ids=["unfused", "round1-kernels", "frame-derivatives"])
+def test_c4_other_schedules_give_the_same_bits(c4, switches):
+    """the same solve under switches that regroup the work, each in a process of its own (the switches are read once)"""
+    env = dict(os.environ, **switches)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "digest_solve.py"), "--size", "512"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
