@@ -4,19 +4,22 @@
 // k_sweep7): it uses sweep_stage1 / sweep_stage2 / PlaneRegs / Face6 / the uniform-divisor helpers defined there.
 //
 // Why.  k_sweep7 (two fused sweeps, every row wave loads its own row with `global_load_dword`) moves the bytes of one
-// sweep for the work of two but runs at 45 % of the HBM peak in real bytes: a CU accepts ~128 vector-memory
-// instructions, a dword-per-lane load carries 256 B, so a CU never has more than ~32 KB on its way, and each of the twelve
-// waves spends ~800 cycles of every step in the issue stage while the vector unit idles (profiles/r01_summary.md,
-// tools/lab/issue_lab).  Here NO compute wave issues a load:
+// sweep for the work of two but spends a sixth of every step in the vector-memory issue stage: a CU accepts ~128
+// vector-memory instructions, a dword-per-lane load carries 256 B, so a CU never has more than ~32 KB on its way
+// (profiles/r01_summary.md, tools/lab/issue_lab).  Here NO compute wave issues a load:
 //
 //   * one LOADER wave per workgroup fetches every input plane with `global_load_lds_dwordx4` -- 16 B per lane, 1 KiB per
-//     instruction, four 64-float row segments at a time, straight into an LDS ring of four raw planes (34 instructions per
-//     plane instead of ~150) -- and keeps TWO planes (68 KB per CU) in flight behind a counted `s_waitcnt vmcnt`;
+//     instruction, four 64-float row segments at a time, straight into an LDS ring of three raw planes (34 instructions per
+//     plane instead of ~150) -- and keeps TWO planes in flight behind a counted `s_waitcnt vmcnt`: everything a step reads of
+//     plane p has been read when the barrier of step p falls, so three slots are enough for that;
 //   * the row waves read their operands from the ring with ds_read: their own row of plane q+1 (kept in registers for the
-//     three steps it serves as z+1, centre and z-1), the rows above and below of plane q, and the x-halo columns; nothing is
-//     re-published, so the 40 KB face image and the halo rings of k_sweep7 are gone and the plane-in-flight registers with them;
+//     three steps it serves as z+1, centre and z-1) after the barrier, the rows above and below and the x-halo column of the
+//     next step's plane at the END of the step; nothing is re-published, so the 40 KB face image and the halo rings of
+//     k_sweep7 are gone and the plane-in-flight registers with them;
 //   * stage 2 works exactly like k_sweep7's: stage-1 results of the neighbours come from an LDS image (rows), DPP (lanes), the
 //     column wave (tile edges) and registers (planes).
+// What it buys and what bounds it now (vector unit, L2 -> LDS delivery and the LDS pipe, each about half of the launch and
+// only partly overlapped): DESIGN.md section 3.
 //
 // Two flavours of the second stage:
 //   PAIR_SS  stage 1 = sweep, stage 2 = sweep              -- f3d_solve_sweep2 (two iterations of cuda_operation_solve.cpp:222-255)
