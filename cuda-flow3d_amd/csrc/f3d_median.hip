@@ -12,6 +12,8 @@
 // -0 and +0 (they compare equal); values are otherwise identical.
 #include "f3d_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kBX = 64;
@@ -25,9 +27,10 @@ __device__ __forceinline__ void cmp_exchange(float& a, float& b)
   b = hi;
 }
 
-// Batcher's odd-even merge sort for arbitrary N, fully unrolled over a register array.
+// Batcher's odd-even merge sort for arbitrary N, fully unrolled over a register array.  Exchanges whose results nobody
+// reads afterwards disappear at compile time, so a caller that looks at a few ranks only pays for what feeds them.
 template <int N>
-__device__ __forceinline__ float rank_middle(float (&v)[N])
+__device__ __forceinline__ void sort_network(float (&v)[N])
 {
 #pragma unroll
   for (int p = 1; p < N; p <<= 1) {
@@ -42,7 +45,24 @@ __device__ __forceinline__ float rank_middle(float (&v)[N])
       }
     }
   }
+}
+
+template <int N>
+__device__ __forceinline__ float rank_middle(float (&v)[N])
+{
+  sort_network(v);
   return v[N / 2];
+}
+
+// The element of rank NB (0-based) of the union of two SORTED lists a[0 .. NB] (NB + 1 values) and b[0 .. NB-1]: with
+// i values taken from a and NB + 1 - i from b it is min over i of max(a[i-1], b[NB-i]) -- NB max, NB min.
+template <int NB>
+__device__ __forceinline__ float rank_nb_of_two_sorted(const float* a, const float* b)
+{
+  float r = a[NB];
+#pragma unroll
+  for (int i = 1; i <= NB; ++i) r = fminf(r, fmaxf(a[i - 1], b[NB - i]));
+  return r;
 }
 
 // LDS-staged variant: a workgroup of 64 x 4 lanes marches along z over a chunk of planes.  The (64 + 2h) x (4 + 2h)
@@ -90,6 +110,72 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict
     const float med = rank_middle<R * R * R>(v);
     if (owner) out[f3d_row(g, y, z) + x] = med;
     __syncthreads();  // the slot of plane z - HALF is overwritten by the next fetch
+  }
+}
+
+// Two outputs per lane and step.  The windows of voxels (x, y, z) and (x, y, z+1) share R-1 of their R planes: S, (R-1) R^2
+// values.  With m = (R^3 - 1) / 2 the rank looked for, an element of S can be the median of S u P (P = the R^2 values of the
+// one plane a window has for itself) only if its rank inside S lies in [m - R^2, m], and the median is then the element of
+// rank R^2 among those R^2 + 1 candidates and the sorted P.  So a pair costs ONE pruned sorting network over S (ranks
+// m - R^2 .. m), two small full sorts and two min/max chains -- 2 524 min/max for two outputs at R = 5 against 2 x 2 244 of
+// the single-output network -- and holds ~110 values at a time instead of 125 + temporaries.
+template <int R>
+__global__ __launch_bounds__(kBX* kBY) void k_median_pair(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
+                                                         int zchunk)
+{
+  constexpr int HALF = R / 2;
+  constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
+  constexpr int NS = R + 1;  // ring slots: planes z-HALF .. z+HALF+1
+  constexpr int RR = R * R, NSH = (R - 1) * RR, M = (R * R * R - 1) / 2;
+  __shared__ float ring[NS][TH][TW];
+  const int tid = threadIdx.y * kBX + threadIdx.x;
+  const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
+  const int x = x0 + threadIdx.x;
+  const int y = y0 + threadIdx.y;
+  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const bool owner = x < g.W && y < g.H;
+  const int zz_max = z1 - 1 + HALF;  // the last plane this chunk may touch (a slab window holds nothing beyond it)
+
+  auto slot_of = [&](int zz) { return ((zz % NS) + NS) % NS; };
+  auto fetch = [&](int zz) {
+    const int zm = f3d_clampi(f3d_mir(min(zz, zz_max), g.D), 0, g.D - 1);
+    float(*dst)[TW] = ring[slot_of(zz)];
+    for (int i = tid; i < TW * TH; i += kBX * kBY) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const int xs = f3d_clampi(f3d_mir(x0 + tx - HALF, g.W), 0, g.W - 1);
+      const int ys = f3d_clampi(f3d_mir(y0 + ty - HALF, g.H), 0, g.H - 1);
+      dst[ty][tx] = in[f3d_row(g, ys, zm) + xs];
+    }
+  };
+  auto gather = [&](int zz, float* v) __attribute__((always_inline)) {
+    const float(*pl)[TW] = ring[slot_of(zz)];
+#pragma unroll
+    for (int iy = 0; iy < R; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < R; ++ix) v[iy * R + ix] = pl[threadIdx.y + iy][threadIdx.x + ix];
+  };
+  for (int zz = z0 - HALF; zz < z0 + HALF; ++zz) fetch(zz);
+  for (int z = z0; z < z1; z += 2) {
+    fetch(z + HALF);
+    fetch(z + HALF + 1);
+    __syncthreads();
+    float s[NSH];
+#pragma unroll
+    for (int iz = 0; iz < R - 1; ++iz) gather(z - HALF + 1 + iz, s + iz * RR);
+    sort_network(s);
+    float p[RR];
+    gather(z - HALF, p);
+    sort_network(p);
+    const float med_a = rank_nb_of_two_sorted<RR>(s + (M - RR), p);
+    gather(z + HALF + 1, p);
+    sort_network(p);
+    const float med_b = rank_nb_of_two_sorted<RR>(s + (M - RR), p);
+    if (owner) {
+      out[f3d_row(g, y, z) + x] = med_a;
+      if (z + 1 < z1) out[f3d_row(g, y, z + 1) + x] = med_b;
+    }
+    __syncthreads();  // the slots of planes z - HALF and z - HALF + 1 are overwritten by the next fetches
   }
 }
 
@@ -167,10 +253,15 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
     long nz = (8192 + tiles - 1) / tiles;
     if (nz > planes) nz = planes;
     if (nz < 1) nz = 1;
-    const int zchunk = static_cast<int>((planes + nz - 1) / nz);
+    int zchunk = static_cast<int>((planes + nz - 1) / nz);
+    // F3D_MEDIAN_PAIR=0: the one-output-per-step network (timing comparisons)
+    static const bool pairs = !(std::getenv("F3D_MEDIAN_PAIR") && std::atoi(std::getenv("F3D_MEDIAN_PAIR")) == 0);
+    if (pairs && (zchunk & 1)) ++zchunk;  // whole pairs: only the last chunk of an odd range computes a voxel for nothing
     const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
-    if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-    if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    if (radius == 3 && pairs) hipLaunchKernelGGL(k_median_pair<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    if (radius == 5 && pairs) hipLaunchKernelGGL(k_median_pair<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    if (radius == 3 && !pairs) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    if (radius == 5 && !pairs) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
   }
   F3D_HIP(hipGetLastError());
   return 0;
