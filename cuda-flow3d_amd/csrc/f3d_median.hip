@@ -179,6 +179,88 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_pair(const float* __restric
   }
 }
 
+#include "f3d_median_nets.h"
+
+// 5^3 with the SORTED planes kept: a lane holds the sorted 25-lists of the four newest planes in registers, so a pair of
+// outputs costs two fresh plane sorts (2 x 280 min/max), two merges of neighbouring plane lists (2 x 238), the pruned merge
+// that yields the 26 candidates (244) and the two selection chains (2 x 50): 1 380 for two outputs against 2 524 with the
+// sort of the raw 100 in k_median_pair.  Planes are named Q0 .. Q5 = z-2 .. z+3; a step consumes the lists of Q0 and Q1 and
+// produces those of Q4 and Q5, so six register arrays rotate by two per step and the march is unrolled three steps deep to
+// make the rotation a renaming.  ~200 live values at the peak: two waves per SIMD, like the single-output network.
+__global__ __launch_bounds__(kBX* kBY) void k_median_keep(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
+                                                         int zchunk)
+{
+  constexpr int R = 5, HALF = 2;
+  constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
+  constexpr int NS = R + 1;
+  __shared__ float ring[NS][TH][TW];
+  const int tid = threadIdx.y * kBX + threadIdx.x;
+  const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
+  const int x = x0 + threadIdx.x;
+  const int y = y0 + threadIdx.y;
+  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z1 = min(z0 + zchunk, g.z_hi);
+  const bool owner = x < g.W && y < g.H;
+  const int zz_max = z1 - 1 + HALF;
+
+  auto slot_of = [&](int zz) { return ((zz % NS) + NS) % NS; };
+  auto fetch = [&](int zz) {
+    const int zm = f3d_clampi(f3d_mir(min(zz, zz_max), g.D), 0, g.D - 1);
+    float(*dst)[TW] = ring[slot_of(zz)];
+    for (int i = tid; i < TW * TH; i += kBX * kBY) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const int xs = f3d_clampi(f3d_mir(x0 + tx - HALF, g.W), 0, g.W - 1);
+      const int ys = f3d_clampi(f3d_mir(y0 + ty - HALF, g.H), 0, g.H - 1);
+      dst[ty][tx] = in[f3d_row(g, ys, zm) + xs];
+    }
+  };
+  auto sorted_plane = [&](int zz, float (&v)[25]) __attribute__((always_inline)) {
+    const float(*pl)[TW] = ring[slot_of(zz)];
+#pragma unroll
+    for (int iy = 0; iy < R; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < R; ++ix) v[iy * R + ix] = pl[threadIdx.y + iy][threadIdx.x + ix];
+    sort_network(v);
+  };
+  // one pair of outputs: q0 .. q3 come in sorted, q4 and q5 are made here
+  auto step = [&](const float (&q0)[25], const float (&q1)[25], const float (&q2)[25], const float (&q3)[25], float (&q4)[25],
+                  float (&q5)[25], int z) __attribute__((always_inline)) {
+    fetch(z + HALF);
+    fetch(z + HALF + 1);
+    __syncthreads();
+    sorted_plane(z + HALF, q4);
+    float c[26];
+    {
+      float ab[50], cd[50];
+      merge25(q1, q2, ab);
+      merge25(q3, q4, cd);
+      candidates(ab, cd, c);
+    }
+    const float med_a = rank_nb_of_two_sorted<25>(c, q0);
+    sorted_plane(z + HALF + 1, q5);
+    const float med_b = rank_nb_of_two_sorted<25>(c, q5);
+    if (owner) {
+      out[f3d_row(g, y, z) + x] = med_a;
+      if (z + 1 < z1) out[f3d_row(g, y, z + 1) + x] = med_b;
+    }
+    __syncthreads();
+  };
+  float L0[25], L1[25], L2[25], L3[25], L4[25], L5[25];
+  for (int zz = z0 - HALF; zz < z0 + HALF; ++zz) fetch(zz);
+  __syncthreads();
+  sorted_plane(z0 - 2, L0);
+  sorted_plane(z0 - 1, L1);
+  sorted_plane(z0, L2);
+  sorted_plane(z0 + 1, L3);
+  for (int z = z0; z < z1; z += 6) {
+    step(L0, L1, L2, L3, L4, L5, z);
+    if (z + 2 >= z1) break;
+    step(L2, L3, L4, L5, L0, L1, z + 2);
+    if (z + 4 >= z1) break;
+    step(L4, L5, L0, L1, L2, L3, z + 4);
+  }
+}
+
 __device__ __forceinline__ unsigned order_key(float f)
 {
   const unsigned b = __float_as_uint(f);
@@ -247,21 +329,54 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
     const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo);
     hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), in, out, g);
   } else {
-    // z-chunks: enough workgroups to fill the chip, long enough to amortise the ring prologue
     const int planes = g.z_hi - g.z_lo;
     const long tiles = static_cast<long>((g.W + kBX - 1) / kBX) * ((g.H + kBY - 1) / kBY);
-    long nz = (8192 + tiles - 1) / tiles;
-    if (nz > planes) nz = planes;
-    if (nz < 1) nz = 1;
-    int zchunk = static_cast<int>((planes + nz - 1) / nz);
-    // F3D_MEDIAN_PAIR=0: the one-output-per-step network (timing comparisons)
-    static const bool pairs = !(std::getenv("F3D_MEDIAN_PAIR") && std::atoi(std::getenv("F3D_MEDIAN_PAIR")) == 0);
-    if (pairs && (zchunk & 1)) ++zchunk;  // whole pairs: only the last chunk of an odd range computes a voxel for nothing
-    const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
-    if (radius == 3 && pairs) hipLaunchKernelGGL(k_median_pair<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-    if (radius == 5 && pairs) hipLaunchKernelGGL(k_median_pair<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-    if (radius == 3 && !pairs) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-    if (radius == 5 && !pairs) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    // F3D_MEDIAN_PAIR: 0 = the one-output-per-step network, 1 = k_median_pair, 2 = k_median_keep (timing comparisons);
+    // unset = whichever the model below prefers.  Read per call (a launch costs far more) so that tests can switch it.
+    const char* forced_env = std::getenv("F3D_MEDIAN_PAIR");
+    const int forced = forced_env ? std::atoi(forced_env) : -1;
+    if (forced == 0) {
+      // z-chunks: enough workgroups to fill the chip, long enough to amortise the ring prologue
+      long nz = (8192 + tiles - 1) / tiles;
+      if (nz > planes) nz = planes;
+      if (nz < 1) nz = 1;
+      const int zchunk = static_cast<int>((planes + nz - 1) / nz);
+      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
+      if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+      if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    } else {
+      // Both kernels are bound by the vector unit: a chunk of zc planes costs its min/max count (per pair of planes 2 600
+      // resp. 1 430, plus the four plane sorts k_median_keep starts with and a few hundred for the ring prologue), a
+      // workgroup puts one wave on each SIMD of its CU, so 256 workgroups make a round whatever the occupancy, and below
+      // two waves per SIMD nothing hides the LDS latency (x 1.3, measured).  Even chunks, so that only the last chunk of
+      // an odd range computes a plane for nothing.  (512^3: keep 3.6 ms, pair 5.1-5.5 ms, single-output network 9.0 ms.)
+      const bool can_keep = radius == 5 && forced != 1;
+      const bool can_pair = !(radius == 5 && forced == 2);
+      const long pair_ops = radius == 5 ? 2600 : 330;
+      int zchunk = 2;
+      bool keep = false;
+      long best = -1;
+      for (int zc = 2; zc <= planes + 1; zc += 2) {
+        const long wgs = tiles * ((planes + zc - 1) / zc);
+        const long rounds = (wgs + 255) / 256, thin = wgs < 512 ? 13 : 10;
+        const long cost_pair = rounds * thin * (300 + (zc / 2) * pair_ops);
+        const long cost_keep = rounds * thin * (300 + 1200 + (zc / 2) * 1430);
+        if (can_pair && (best < 0 || cost_pair < best)) {
+          best = cost_pair;
+          zchunk = zc;
+          keep = false;
+        }
+        if (can_keep && (best < 0 || cost_keep < best)) {
+          best = cost_keep;
+          zchunk = zc;
+          keep = true;
+        }
+      }
+      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
+      if (radius == 3) hipLaunchKernelGGL(k_median_pair<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+      if (radius == 5 && keep) hipLaunchKernelGGL(k_median_keep, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+      if (radius == 5 && !keep) hipLaunchKernelGGL(k_median_pair<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+    }
   }
   F3D_HIP(hipGetLastError());
   return 0;

@@ -204,6 +204,32 @@ def test_median(f3d, oracle, dims, cdims, r):
         dev.close()
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("dims,window", [((70, 9, 23), None), ((37, 21, 9), None), ((130, 6, 14), None), ((9, 6, 4), None),
+                                         ((66, 10, 31), (7, 24)), ((20, 12, 17), (0, 5)), ((20, 12, 17), (12, 17))])
+def test_median_kernel_variants(f3d, oracle, dims, window, variant, monkeypatch):
+    """The three 5^3 kernels -- one output per step, two outputs sharing the network of the four common planes, sorted planes kept
+    in registers (three steps unrolled, odd plane counts, chunks) -- give the oracle's values, also on a slab window whose
+    container holds nothing beyond the two halo planes."""
+    monkeypatch.setenv("F3D_MEDIAN_PAIR", variant)
+    rng = np.random.default_rng(23)
+    W, H, D = dims
+    inp = box_in_container(rng, dims, dims, -2, 2)
+    inp[rng.random((D, H, W)) < 0.3] = 0.5
+    inp[rng.random((D, H, W)) < 0.1] = 0.0
+    exp = oracle.median(inp, dims, 5)
+    z_lo, z_hi = window or (0, D)
+    z_base, top = max(0, z_lo - 2), min(D, z_hi + 2)
+    dev = Dev(f3d, (W, H, top - z_base))
+    try:
+        pin, pout = dev.put(np.ascontiguousarray(inp[z_base:top])), dev.out()
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        f3d.check(f3d.hip().f3d_median(pin, W, H, D, 5, pout, C.byref(slab)))
+        assert same(dev.get(pout)[z_lo - z_base:z_hi - z_base], exp[z_lo:z_hi])
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("sigma", [1.0, 2.0, 3.5, 5.0, 8.0])
 @pytest.mark.parametrize("dims", [(37, 20, 9), (64, 8, 5), (130, 12, 33)])
 def test_gaussian(f3d, oracle, dims, sigma):
