@@ -462,7 +462,7 @@ def run_multi(args):
                                       "n <= 4 outer iterations)"
                                       + (" -- REHEARSAL: shared-memory transport, ranks share devices"
                                          if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep7 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
+            "roofline": {"bound": "hbm", "kernel": "k_pair8 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
                                                    "slab incl. widened windows",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches},
