@@ -1479,11 +1479,12 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
   return 0;
 }
 
-int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
-                            f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
-                            size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
-                            float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
-                            f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                                  f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                                  size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                                  float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                                  f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab,
+                                  int keep_below, int keep_above)
 {
   F3D_REQUIRE_READY("f3d_solve_sweep_phi_ksi");
   F3dGeo g;
@@ -1496,6 +1497,8 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 2, "f3d_solve_sweep_phi_ksi")) return 1;
   PairArgs a = {};
+  a.keep_below = keep_below != 0;
+  a.keep_above = keep_above != 0;
   static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
   a.plain_division = plain_division;
   const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
@@ -1514,6 +1517,17 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
   f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
   F3D_HIP(hipGetLastError());
   return 0;
+}
+
+int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                            f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                            size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                            float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                            f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  return f3d_solve_sweep_phi_ksi_edges(frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi, width, height,
+                                       depth, hx, hy, hz, equation_alpha, equation_smoothness, equation_data, temp_du, temp_dv,
+                                       temp_dw, phi_next, ksi_next, slab, 0, 0);
 }
 
 int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, size_t height, size_t depth, float hx, float hy,

@@ -48,6 +48,9 @@ struct PairArgs {
   float hx, hy, hz, alpha;
   float eps_s, eps_d;   // PAIR_SP
   int plain_division;   // timing experiments (F3D_UDIV=0)
+  // PAIR_SP: also store the sweep on plane z_lo-1 / z_hi of the window -- the launch computes them anyway for the weights of
+  // planes z_lo and z_hi-1 (f3d_solve_sweep_phi_ksi_edges: a z-slab that owns one plane more than it can give weights to)
+  int keep_below, keep_above;
 };
 
 template <int TY, int NA = 10>
@@ -492,7 +495,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       }
     }
     // PAIR_SP: the sweep's result is final -- store it for the planes this chunk owns
-    if (MODE == PAIR_SP && do1 && owner && q >= z0 && q < z1) {
+    if (MODE == PAIR_SP && do1 && owner && (q >= z0 || (a.keep_below && q == g.z_lo - 1)) &&
+        (q < z1 || (a.keep_above && q == g.z_hi))) {
       const unsigned off = xb + rowoff(yy, q);
       gst(obase[0], off, r_du);
       gst(obase[1], off, r_dv);

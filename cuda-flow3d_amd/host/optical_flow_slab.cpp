@@ -19,6 +19,7 @@ OpticalFlowSlab::OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int 
   // thin slabs of small levels: several outer iterations per exchange (0 = the rule in Pyramid(), n = force n)
   if (const char* f = std::getenv("F3D_SLAB_OUTER_PER_EXCHANGE")) forced_outer_per_exchange_ = std::atoi(f);
   if (const char* f = std::getenv("F3D_SLAB_SMALL_LEVEL_VOXELS")) small_level_voxels_ = std::atof(f);
+  if (const char* f = std::getenv("F3D_SLAB_FUSED_PHI_KSI")) fused_weights_ = std::atoi(f) != 0;
 }
 
 OpticalFlowSlab::~OpticalFlowSlab() { Destroy(); }
@@ -196,6 +197,56 @@ bool OpticalFlowSlab::ExchangeEnd(size_t width, size_t height)
   return true;
 }
 
+// The weights of an outer iteration on planes [lo, hi): whatever the fused last sweep of the previous iteration has not
+// written already.  With an exchange in between that is the zone next to each neighbour (the plane whose weights need the
+// neighbour's new increments, and the halo planes); inside a group of iterations without exchange it is nothing.
+bool OpticalFlowSlab::CompleteWeights(Local& l, int lo, int hi, int D, size_t W, size_t H, float hx, float hy, float hz,
+                                      float equation_smoothness, float equation_data)
+{
+  lo = std::max(0, lo);
+  hi = std::min(D, hi);
+  auto run = [&](int from, int to) {
+    if (to <= from) return true;
+    f3d_slab s;
+    s.z_base = ZBase(D, l.rank);
+    s.z_lo = from;
+    s.z_hi = to;
+    return Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx, hy, hz,
+                             equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &s));
+  };
+  const bool some = l.weights_hi > l.weights_lo;
+  const int have_lo = l.weights_lo, have_hi = l.weights_hi;
+  l.weights_lo = l.weights_hi = 0;
+  if (!some) return run(lo, hi);
+  return run(lo, std::min(hi, have_lo)) && run(std::max(lo, have_hi), hi);
+}
+
+bool OpticalFlowSlab::SweepAndNextWeights(Local& l, const Role (&in)[3], const Role (&out)[3], int sweep_lo, int sweep_hi, int D,
+                                          size_t W, size_t H, float hx, float hy, float hz, float equation_alpha,
+                                          float equation_smoothness, float equation_data, bool& launched)
+{
+  launched = false;
+  // the weights of a plane need the new increments of both z neighbours: inside the volume the first and the last plane of
+  // the range have to wait for a neighbour's (at a face the mirrored plane is the rank's own)
+  const bool shrink_lo = sweep_lo > 0, shrink_hi = sweep_hi < D;
+  f3d_slab s;
+  s.z_base = ZBase(D, l.rank);
+  s.z_lo = sweep_lo + (shrink_lo ? 1 : 0);
+  s.z_hi = sweep_hi - (shrink_hi ? 1 : 0);
+  if (s.z_hi - s.z_lo < 1) return true;
+  if (!Check(f3d_solve_sweep_phi_ksi_edges(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]],
+                                           l.buf[in[2]], l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha,
+                                           equation_smoothness, equation_data, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]],
+                                           l.buf[PHI2], l.buf[KSI2], &s, shrink_lo ? 1 : 0, shrink_hi ? 1 : 0)))
+    return false;
+  std::swap(l.buf[PHI], l.buf[PHI2]);
+  std::swap(l.buf[KSI], l.buf[KSI2]);
+  l.weights_lo = s.z_lo;
+  l.weights_hi = s.z_hi;
+  launched = true;
+  return true;
+}
+
 // One outer iteration (phi/ksi + K sweeps) of a rank that has neighbours, ordered so that the exchange of the new
 // increments runs beside most of the arithmetic.  With own planes [a, b), H = K + 1 planes travelling each way and R_s
 // sweeps still to come after stage s (a stage = a fused pair or a single sweep):
@@ -208,7 +259,9 @@ bool OpticalFlowSlab::ExchangeEnd(size_t width, size_t height)
 //     stage, whose zone output would overwrite planes the interior's last-but-one stage still reads; hence the edge
 //     containers, copied into place at the end;
 //   * finally the received halos are unpacked.  Every voxel is computed once, by the same kernels on the same inputs as in
-//     the plain order, so the bits do not change (tests/test_gpu_slab_procs.py).
+//     the plain order, so the bits do not change (tests/test_gpu_slab_procs.py);
+//   * the interior's last sweep also writes the weights of the NEXT outer iteration for its planes (one launch, see
+//     SweepAndNextWeights); the next call then computes phi/ksi only for the two zones and the halo planes.
 bool OpticalFlowSlab::SweepsOverlapped(Local& l, int D, size_t W, size_t H, int K, float hx, float hy, float hz,
                                        float equation_alpha, float equation_smoothness, float equation_data)
 {
@@ -254,16 +307,33 @@ bool OpticalFlowSlab::SweepsOverlapped(Local& l, int D, size_t W, size_t H, int 
   };
   const size_t last = stages.size() - 1;
   const Role* final_out = (last % 2 == 0) ? tmp : cur;
+  // the last stage of the interior can take the next weights along when it is a single sweep (an exchange always follows here)
+  const bool fuse_last = fused_weights_ && FusedSweepsEnabled() && FusedPhiKsiEnabled() && !stages[last].pair;
+  const bool had_weights = l.weights_hi > l.weights_lo;
+  if (fuse_last || had_weights) {
+    if (!CompleteWeights(l, a - K, b + K, D, W, H, hx, hy, hz, equation_smoothness, equation_data)) return false;
+  }
+  const bool weights_done = fuse_last || had_weights;
   for (Zone z : {LOW, HIGH}) {
     if ((z == LOW && !has_lo) || (z == HIGH && !has_hi)) continue;
-    if (!phi(zone(z, K))) return false;
+    if (!weights_done && !phi(zone(z, K))) return false;
     for (size_t s = 0; s <= last; ++s)
       if (!stage(s, zone(z, stages[s].rest), s == last)) return false;
   }
   if (!ExchangeBegin(D, W, H, {edge[0], edge[1], edge[2]}, {final_out[0], final_out[1], final_out[2]}, Hs, Hs)) return false;
-  if (!phi(zone(INNER, K))) return false;
-  for (size_t s = 0; s <= last; ++s)
-    if (!stage(s, zone(INNER, stages[s].rest), false)) return false;
+  if (!weights_done && !phi(zone(INNER, K))) return false;
+  for (size_t s = 0; s <= last; ++s) {
+    const f3d_slab win = zone(INNER, stages[s].rest);
+    if (s == last && fuse_last) {
+      const Role* in = (s % 2 == 0) ? cur : tmp;
+      bool launched = false;
+      if (!SweepAndNextWeights(l, {in[0], in[1], in[2]}, {final_out[0], final_out[1], final_out[2]}, win.z_lo, win.z_hi, D, W, H, hx, hy,
+                               hz, equation_alpha, equation_smoothness, equation_data, launched))
+        return false;
+      if (launched) continue;
+    }
+    if (!stage(s, win, false)) return false;
+  }
   const int base = a - halo_;
   for (int k = 0; k < 3; ++k) {
     if (has_lo && !Check(f3d_copy_planes(l.buf[final_out[k]], a - base, l.buf[edge[k]], a - base, Hs, W, H))) return false;
@@ -519,9 +589,11 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     }
 
     // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per n_ex outer iterations
-    for (Local& l : locals_)
+    for (Local& l : locals_) {
+      l.weights_lo = l.weights_hi = 0;
       for (Role r : {DU, DV, DW})
         if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, W * sizeof(float), crows))) return false;
+    }
     // Overlapped order: one rank per process, a slab thick enough that zones and interior are distinct, and an exchange
     // to hide (not after the last outer iteration)
     const PlaneRange own_here = OwnedPlanes(D, locals_[0].rank, n_ranks_);
@@ -536,19 +608,35 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       }
       const int n = static_cast<int>(std::min<size_t>(n_ex, outer_iterations_count - i));
       for (Local& l : locals_) {
+        const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+        if (own.empty()) continue;
         // iteration j of the n leaves the increments valid on the slab widened by g = (n-1-j)(K+1) planes
         for (int j = 0; j < n; ++j) {
           const int g = (n - 1 - j) * (K + 1);
-          const f3d_slab pw = Window(D, l.rank, g + K, g + K);
-          if (!Check(f3d_phi_ksi(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx,
-                                 hy, hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &pw)))
-            return false;
+          // the weights on the slab widened by g + K planes: all of them, or what the fused last sweep of the previous
+          // iteration could not know yet (after an exchange: the planes next to the neighbours and the halo; else nothing)
+          if (!CompleteWeights(l, own.lo - (g + K), own.hi + (g + K), D, W, H, hx, hy, hz, equation_smoothness, equation_data)) return false;
           // sweep s runs on the slab widened by g + K-1-s planes; a fused pair (s, s+1) is launched on the window of
           // sweep s+1 and computes sweep s on one plane more on either side by itself
           for (int s = 0; s < K;) {
             const bool pair = FusedSweepsEnabled() && s + 2 <= K;
             const int shrink = g + K - 1 - s - (pair ? 1 : 0);
             const f3d_slab sw = Window(D, l.rank, shrink, shrink);
+            // the last sweep of an iteration that is not the level's last takes the next weights along (one launch)
+            if (!pair && s == K - 1 && i + static_cast<size_t>(j) + 1 < outer_iterations_count && fused_weights_ &&
+                FusedSweepsEnabled() && FusedPhiKsiEnabled()) {
+              bool launched = false;
+              if (!SweepAndNextWeights(l, {DU, DV, DW}, {TDU, TDV, TDW}, sw.z_lo, sw.z_hi, D, W, H, hx, hy, hz, equation_alpha,
+                                       equation_smoothness, equation_data, launched))
+                return false;
+              if (launched) {
+                std::swap(l.buf[DU], l.buf[TDU]);
+                std::swap(l.buf[DV], l.buf[TDV]);
+                std::swap(l.buf[DW], l.buf[TDW]);
+                s += 1;
+                continue;
+              }
+            }
             const int status =
                 pair ? f3d_solve_sweep2(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
                                         l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],

@@ -50,10 +50,13 @@ class OpticalFlowSlab : public OpticalFlowBase {
   bool silent = true;
 
  private:
-  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, EDU, EDV, EDW, kRoles };
+  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, EDU, EDV, EDW, PHI2, KSI2, kRoles };
   struct Local {
     int rank;
     DevicePtr buf[kRoles];
+    // planes [weights_lo, weights_hi) of PHI / KSI already hold the weights of the coming outer iteration (written by the
+    // fused last sweep of the previous one); empty = none
+    int weights_lo = 0, weights_hi = 0;
   };
 
   bool Pyramid(OperationParameters& params);
@@ -69,6 +72,17 @@ class OpticalFlowSlab : public OpticalFlowBase {
   // one outer iteration's sweeps with the halo exchange hidden behind the interior of the slab (see the .cpp)
   bool SweepsOverlapped(Local& l, int D, size_t W, size_t H, int K, float hx, float hy, float hz, float equation_alpha,
                         float equation_smoothness, float equation_data);
+  // phi / ksi on planes [lo, hi) of the level (clipped to it), skipping the planes that already hold them
+  bool CompleteWeights(Local& l, int lo, int hi, int D, size_t W, size_t H, float hx, float hy, float hz, float equation_smoothness,
+                       float equation_data);
+  // The last sweep of an outer iteration fused with the weights of the next one (f3d_solve_sweep_phi_ksi_edges): the sweep on
+  // [sweep_lo, sweep_hi) from `in` into `out`, the weights on the planes of that range whose z neighbours' new increments
+  // are at hand -- all but the first and the last one, unless that is a face of the volume.  `launched` stays false (and
+  // the caller runs a plain sweep) when the range is too thin for that.
+  bool SweepAndNextWeights(Local& l, const Role (&in)[3], const Role (&out)[3], int sweep_lo, int sweep_hi, int D, size_t W, size_t H,
+                           float hx, float hy, float hz, float equation_alpha, float equation_smoothness, float equation_data,
+                           bool& launched);
+  bool fused_weights_ = true;  // F3D_SLAB_FUSED_PHI_KSI=0 turns the fused last sweep off
   bool Check(int status);
 
   int n_ranks_;

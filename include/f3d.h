@@ -165,6 +165,18 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
                             float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
                             f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
 
+/* The same launch for a z-slab that exchanges its increments AFTER it (host/optical_flow_slab.cpp): the sweep is computed on
+ * planes z_lo-1 .. z_hi anyway (the weights of z_lo and z_hi-1 need it); keep_below / keep_above also STORE it there, so a rank
+ * launches on the window [own.lo + 1, own.hi - 1) and ends up with the sweep on all of its planes and the next weights on all
+ * but the two whose neighbours it does not have yet (those follow from f3d_phi_ksi once the halo planes have arrived).  Planes
+ * outside the volume do not exist: keep_below at z_lo = 0 and keep_above at z_hi = depth are ignored. */
+int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                                  f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
+                                  size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                                  float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                                  f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab,
+                                  int keep_below, int keep_above);
+
 /* The frame derivatives of a level, once: fx, fy, fz = (((F0[+1] - F0[-1]) + F1[+1]) - F1[-1]) / (4 h) and ft = F1 - F0, exactly as
  * compute_phi_ksi_3d and solve_3d form them for every voxel in every launch (src/kernels/solve_3d.cu:205-215, :438-448).  They depend
  * on the two frames of the level only; the _fd launchers below read them instead of the frames.  A slab window [z_lo, z_hi) needs planes

@@ -263,10 +263,11 @@ int f3d_solve_sweep2(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f
                   P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, P<float>(tdu), P<float>(tdv), P<float>(tdw), &o.g);
   return 0;
 }
-int f3d_solve_sweep_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
-                            f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy,
-                            float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw,
-                            f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+int f3d_solve_sweep_phi_ksi_edges(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
+                                  f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx,
+                                  float hy, float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv,
+                                  f3d_devptr tdw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab, int keep_below,
+                                  int keep_above)
 {
   Geo o;
   if (!make_geo(&o, width, height, depth, slab, "f3d_solve_sweep_phi_ksi")) return 1;
@@ -284,11 +285,19 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devp
   float* outs[3] = {P<float>(tdu), P<float>(tdv), P<float>(tdw)};
   const float* ins[3] = {a.data(), b.data(), c.data()};
   for (int k = 0; k < 3; ++k)
-    for (int z = o.g.z_lo; z < o.g.z_hi; ++z)
+    for (int z = o.g.z_lo - (keep_below && o.g.z_lo > 0 ? 1 : 0); z < o.g.z_hi + (keep_above && o.g.z_hi < o.D ? 1 : 0); ++z)
       for (int y = 0; y < o.H; ++y)
         std::memcpy(outs[k] + (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f,
                     ins[k] + (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f, o.W * sizeof(float));
   return 0;
+}
+int f3d_solve_sweep_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
+                            f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy,
+                            float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw,
+                            f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  return f3d_solve_sweep_phi_ksi_edges(f0, f1, u, v, w, du, dv, dw, phi, ksi, width, height, depth, hx, hy, hz, alpha, eps_s, eps_d, tdu, tdv,
+                                       tdw, phi_next, ksi_next, slab, 0, 0);
 }
 // Frame derivatives: computed for real (same expressions as the device kernel), and the frames they came from are remembered by the
 // address of fx so that the _fd launchers can hand the oracle's frame-based kernels what they need.

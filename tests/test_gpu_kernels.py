@@ -479,6 +479,42 @@ def test_sweep_and_next_phi_ksi_slab_window(f3d, oracle, dims, cdims):
         dev.close()
 
 
+@pytest.mark.parametrize("keep", [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize("dims,cdims,window", [((37, 20, 9), (64, 32, 16), (2, 7)), ((129, 10, 9), (192, 12, 9), (0, 6)),
+                                               ((65, 6, 5), (128, 8, 8), (2, 5)), ((64, 8, 5), (64, 8, 8), (1, 4))])
+def test_sweep_and_next_phi_ksi_keeps_the_edge_planes(f3d, oracle, dims, cdims, window, keep):
+    """f3d_solve_sweep_phi_ksi_edges: the weights on [z_lo, z_hi) as before, the sweep ALSO on plane z_lo-1 / z_hi where asked for
+    and where such a plane exists (the z-slab driver launches it on [own.lo+1, own.hi-1)); nothing else is written."""
+    rng = np.random.default_rng(13)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, 0.001, 0.001)
+    z_lo, z_hi = window
+    z_base, top = max(0, z_lo - 2), min(D, z_hi + 2)
+    sub = lambda a: np.ascontiguousarray(a[z_base:top])
+    dev = Dev(f3d, (cdims[0], cdims[1], top - z_base))
+    try:
+        ptr = [dev.put(sub(a)) for a in arrs] + [dev.put(sub(phi_o)), dev.put(sub(ksi_o))]
+        outs = [dev.out() for _ in range(5)]
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        f3d.check(f3d.hip().f3d_solve_sweep_phi_ksi_edges(*ptr, W, H, D, *h, 7.5, 0.001, 0.001, *outs, C.byref(slab), *keep))
+        s_lo = z_lo - (1 if keep[0] and z_lo > 0 else 0)
+        s_hi = z_hi + (1 if keep[1] and z_hi < D else 0)
+        for g, e in zip(outs[:3], s1):
+            got = dev.get(g)
+            assert bit_same(got[s_lo - z_base:s_hi - z_base, :H, :W], e[s_lo:s_hi, :H, :W])
+            assert np.isnan(got[:s_lo - z_base]).all() and np.isnan(got[s_hi - z_base:]).all()  # Dev.out() poisons with NaN
+        for g, e in zip(outs[3:], (phi_n, ksi_n)):
+            got = dev.get(g)
+            assert bit_same(got[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+            assert np.isnan(got[:z_lo - z_base]).all() and np.isnan(got[z_hi - z_base:]).all()
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("value", [0, 0xFF, 0x3C])
 def test_memset2d_sub_box(f3d, value):
     """f3d_memset2d (cuMemsetD2D8 of optical_flow_e.cpp:305-310): width_bytes of every row set, the rest of the pitch and
