@@ -16,7 +16,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBDIR = os.path.join(_HERE, "lib")
+_LIBDIR = os.environ.get("F3D_LIBDIR") or os.path.join(_HERE, "lib")  # F3D_LIBDIR: A/B timing of two builds in one GPU call
 
 DEFAULT_PARAMS = dict(
     warp_levels_count=40, warp_scale_factor=0.95, outer_iterations_count=40, inner_iterations_count=5,
