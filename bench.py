@@ -222,6 +222,24 @@ def profiler_attached():
     return "rocprof" in blob and os.environ.get("F3D_BENCH_FORCE_EVENTS") != "1"
 
 
+def golden_plane_digest(size):
+    """the committed per-plane digest of the default solve of the size^3 synthetic pair (tests/test_gpu_configs.py pins it
+    against the resident, unfused, 8-slab and out-of-core drivers), or None"""
+    key = {512: "c4_512_default_plane_sha256", 1024: "c5_1024_default_plane_sha256"}.get(size)
+    path = os.path.join(ROOT, "tests", "golden", "config_digests.json")
+    if key is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(key)
+
+
+def parity_record(size, digest):
+    want = golden_plane_digest(size)
+    return {"what": "sha256 over the per-plane sha256 of the (u, v, w) this run left on the device(s) against the committed "
+                    "single-GPU result of the same pair (tests/golden/config_digests.json; bit-exact or false)",
+            "digest": digest, "golden": want, "match": (digest == want) if want else None}
+
+
 def run_single(args):
     pkg = importlib.import_module("cuda-flow3d_amd")
     S = args.size
@@ -282,6 +300,9 @@ def run_single(args):
         f1_ms, f1_n, f1_vox = f1_ms * extra, f1_n * extra, f1_vox * extra
     hip.f3d_prof_reset()
 
+    # outside the timed region: the bits of the result against the committed single-GPU digest
+    parity = parity_record(S, pkg.combine_plane_digests(pkg.flow_plane_digests(flow.download())))
+    log(f"[bench] result digest {parity['digest'][:16]}... matches the committed one: {parity['match']}")
     inclusive = None
     if not args.no_extra:
         log("[bench] host-inclusive step (H2D + solve + D2H) ...")
@@ -318,6 +339,7 @@ def run_single(args):
                    "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
         "host_inclusive": inclusive,
+        "parity": parity,
         "whole_run_roofline_frac": round(whole / (wall / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if whole else None,
         "roofline": {
             "bound": "hbm", "kernel": dom_name,
@@ -444,6 +466,14 @@ def run_multi(args):
         tot_bytes += bpv * vox.value
         launches += n.value
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+    # outside the timed region: every rank hashes the planes it owns, rank 0 compares the whole with the single-GPU digest
+    mine = pkg.flow_plane_digests(flow.download(), lo, hi)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    parity = None
+    if rank == 0:
+        parity = parity_record(S, pkg.combine_plane_digests([[d for part in gathered for d in part[c]] for c in range(3)]))
+        log(f"[bench] result digest {parity['digest'][:16]}... matches the committed single-GPU one: {parity['match']}")
     flow.destroy()
     pkg.comm_destroy()
     if rank == 0:
@@ -451,7 +481,7 @@ def run_multi(args):
             "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
             "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "parity": parity,
             "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair"
                                    + (" (BASELINE config 5, the multi-GPU scaling workload)" if S == 1024 else "")
                                    + ", full coarse-to-fine pyramid "

@@ -308,6 +308,27 @@ def synth_planes(width, height, depth, z_lo, z_hi, frame_0, frame_1):
     return m.value
 
 
+def flow_plane_digests(flow, z_lo=0, z_hi=None):
+    """sha256 of every plane z_lo <= z < z_hi of each of (u, v, w) (float32, -0 normalised to +0): three lists of 32-byte
+    digests.  Planes hash independently, so the ranks of a z-slab run can each hash what they own."""
+    import hashlib
+    out = []
+    for vol in flow:
+        hi = vol.shape[0] if z_hi is None else z_hi
+        out.append([hashlib.sha256(np.ascontiguousarray(vol[z] + np.float32(0.0)).tobytes()).digest() for z in range(z_lo, hi)])
+    return out
+
+
+def combine_plane_digests(per_component):
+    """One hex digest from the per-plane digests of (u, v, w), all planes of u first, in plane order."""
+    import hashlib
+    h = hashlib.sha256()
+    for comp in per_component:
+        for d in comp:
+            h.update(d)
+    return h.hexdigest()
+
+
 # ---- device memory ---------------------------------------------------------------------------------------------
 
 class Containers:

@@ -91,8 +91,12 @@ def test_c4_resident_is_finite_and_recovers_the_translation(c4):
     check_translation(c4["flow"], 512, 1.977)
 
 
-def test_c4_digest_is_the_committed_one(c4):
+def test_c4_digest_is_the_committed_one(f3d, c4):
     assert digest(c4["flow"]) == committed("c4_512_default_sha256")
+    # the per-plane form bench.py checks its own results against (every rank of a z-slab run hashes the planes it owns)
+    assert f3d.combine_plane_digests(f3d.flow_plane_digests(c4["flow"])) == committed("c4_512_default_plane_sha256")
+    lower, upper = f3d.flow_plane_digests(c4["flow"], 0, 200), f3d.flow_plane_digests(c4["flow"], 200, 512)
+    assert f3d.combine_plane_digests([a + b for a, b in zip(lower, upper)]) == committed("c4_512_default_plane_sha256")
 
 
 @pytest.mark.parametrize("switches", [
@@ -140,5 +144,6 @@ def test_c5_1024_resident_equals_eight_slabs(f3d):
         assert np.isfinite(c).all()
     check_translation(exp, 1024, 1.839)
     assert digest(exp) == committed("c5_1024_default_sha256")
+    assert f3d.combine_plane_digests(f3d.flow_plane_digests(exp)) == committed("c5_1024_default_plane_sha256")
     got = slabs(f3d, f0, f1, 8)
     same3(got, exp, "1024^3, 8 z-slabs")

@@ -22,8 +22,10 @@ flow.initialize(n, n, n)
 flow.upload(f0, f1)
 secs = flow.compute_resident(silent=True)
 h = hashlib.sha256()
-for x in flow.download():
+result = flow.download()
+for x in result:
     h.update(np.ascontiguousarray(x + np.float32(0.0)).tobytes())
 flow.destroy()
 switches = {k: v for k, v in os.environ.items() if k.startswith("F3D_")}
 print(f"{n}^3 {secs:.2f} s {h.hexdigest()} {switches}")
+print(f"per-plane digest (tests/golden/config_digests.json *_plane_sha256) {pkg.combine_plane_digests(pkg.flow_plane_digests(result))}")

@@ -1,2 +1,5 @@
 mkdir -p gpurun_out/r2
-for i in 1 2 3; do for v in old new; do for s in 256 512; do for k in sweep2 sweeppk; do echo -n "$v "; F3D_LIBDIR=$GRAFT_REPO_ROOT/ab_$v python tools/kbench.py --size $s --reps 100 --kernel $k 2>&1 | tail -1; done; done; done; done > gpurun_out/r2/ab1.log 2>&1; cat gpurun_out/r2/ab1.log
+python bench.py --no-extra > gpurun_out/r2/bench7.json 2> gpurun_out/r2/bench7.err; python - <<'PY'
+import json; b=json.load(open('gpurun_out/r2/bench7.json')); print(b['value'], b['parity'], b['roofline'].get('traffic'), b['roofline'].get('hbm_frac'))
+PY
+F3D_COMM_BACKEND=shm timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 1 --warmup 0 --size 512 > gpurun_out/r2/bench_shm2.json 2> gpurun_out/r2/bench_shm2.err; tail -n 3 gpurun_out/r2/bench_shm2.err; cut -c1-700 gpurun_out/r2/bench_shm2.json
