@@ -765,13 +765,18 @@ struct S3 {
 // sweep_voxel_s, additionally handing out what stage 2 of the same voxel reuses (same operations, same order)
 // FD: the frame derivatives of the voxel are handed in (gfx, gfy, gfz, gft: computed once per level by k_frame_derivatives with
 // the same expressions) instead of being formed from the neighbours' frame values
-template <bool FD = false>
+// XSEL: the x-face weights are applied by selection (k_pair8): has_xp / has_xm are looked at only where `at_x_face` (wave-
+// uniform) says the tile touches a face of the volume, so an interior tile multiplies by alpha / hx^2 from a scalar register
+// instead of carrying two per-lane weights through the march.  Same bits: the weight of a missing neighbour is 0, and a phi
+// average (positive, finite) times +0 is the +0 the selection writes.
+template <bool FD = false, bool XSEL = false>
 __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, const Face6& ym, const Face6& yp,
                                              const Face6& zm, const Face6& zp, const float (&c)[kNL], float Uc, float Vc,
                                              float Wc, float dVc, float dWc, float ksi, float hx, float hy, float hz,
                                              const FDivs& fd, float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym,
                                              bool has_zp, bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k,
-                                             float gfx = 0.f, float gfy = 0.f, float gfz = 0.f, float gft = 0.f)
+                                             float gfx = 0.f, float gfy = 0.f, float gfz = 0.f, float gft = 0.f,
+                                             bool at_x_face = true)
 {
   float fq[3] = {gfx, gfy, gfz};
   if (!FD) {
@@ -791,8 +796,8 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
   const float hx_2 = alpha / (hx * hx);
   const float hy_2 = alpha / (hy * hy);
   const float hz_2 = alpha / (hz * hz);
-  const float wxp = static_cast<float>(has_xp) * hx_2;
-  const float wxm = static_cast<float>(has_xm) * hx_2;
+  const float wxp = XSEL ? hx_2 : static_cast<float>(has_xp) * hx_2;
+  const float wxm = XSEL ? hx_2 : static_cast<float>(has_xm) * hx_2;
   const float wyp = static_cast<float>(has_yp) * hy_2;
   const float wym = static_cast<float>(has_ym) * hy_2;
   const float wzp = static_cast<float>(has_zp) * hz_2;
@@ -805,6 +810,10 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
   k.pw[3] = (ym.v[LPHI] + c[LPHI]) / 2.f * wym;
   k.pw[4] = (zp.v[LPHI] + c[LPHI]) / 2.f * wzp;
   k.pw[5] = (zm.v[LPHI] + c[LPHI]) / 2.f * wzm;
+  if (XSEL && at_x_face) {
+    k.pw[0] = has_xp ? k.pw[0] : 0.f;
+    k.pw[1] = has_xm ? k.pw[1] : 0.f;
+  }
   const float sumH = (k.pw[0] + k.pw[1] + k.pw[2] + k.pw[3] + k.pw[4] + k.pw[5]);
   const float sumU = k.pw[0] * (xp.v[LSU] - Uc) + k.pw[1] * (xm.v[LSU] - Uc) + k.pw[2] * (yp.v[LSU] - Uc) +
                      k.pw[3] * (ym.v[LSU] - Uc) + k.pw[4] * (zp.v[LSU] - Uc) + k.pw[5] * (zm.v[LSU] - Uc);
@@ -1375,7 +1384,11 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   if (pair8_enabled() && g.pitch % kLanes == 0) {  // the loader fetches whole 64-float row segments in 16-byte pieces
-    static const int ty = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 8;
+    // 8 or 12 core rows per tile (12 or 16 waves per workgroup), whichever the round model prices lower for this level;
+    // F3D_PAIR8_TY=8 / 12 pins one
+    static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
+    int ty = forced;
+    if (ty != 8 && ty != 12) ty = pair8_plan(g, 12).cost * 128 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
     if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
     else launch_pair8<PAIR_SS, 8>(pair_args(a), g, t.zchunk, t.xcd_remap);
     return;

@@ -90,6 +90,16 @@ __device__ __forceinline__ float opaque(float seed)
   return seed;
 }
 
+// The lane number, made anew: 16 waves per workgroup (TY = 12) leave 128 registers per lane, and the one value the
+// allocator then keeps in scratch across the march is the lane number itself -- reloading it costs a scratch load per step
+// whose s_waitcnt vmcnt(0) also waits for the stores issued by hand; two vector instructions make it again instead.
+__device__ __forceinline__ int fresh_lane()
+{
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // one 1-KiB piece: lane L's 16 bytes land at lds_dst + 16 L
 __device__ __forceinline__ void dma16(const float* base, unsigned byte_off, float* lds_dst)
 {
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const int ty = (tile / ntx) % nty;
   const int tz = tile / (ntx * nty);
 
-  const int lane = threadIdx.x;
+  int lane = threadIdx.x;  // re-made at the top of every step where registers are short (see fresh_lane)
   const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const bool colw = r == NR;
   const bool loader = r == NR + 1;
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const bool left_face = tx == 0;
   const bool right_face = x0 + kLanes >= g.W;
   const bool tile_at_x_face = __builtin_amdgcn_readfirstlane(static_cast<int>(left_face || right_face)) != 0;
+  // the column wave's right halo column is the last column of the volume when W = 64 k + 1
+  const bool col_at_x_face = __builtin_amdgcn_readfirstlane(static_cast<int>(left_face || right_face || x0 + kLanes == g.W - 1)) != 0;
 
   const int zb = qs > 0 ? qs - 1 : 0;  // lowest plane touched: byte offsets inside the chunk stay small and positive
   const size_t base_off = f3d_row(g, 0, zb);
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   auto step = [&](auto colw_c, auto slot_c, PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) __attribute__((always_inline)) {
     constexpr bool CW = decltype(colw_c)::value;  // the column wave runs a loop of its own: no value merges with the row waves
     constexpr int SLOT = decltype(slot_c)::value;
+    if constexpr (TY > 8) lane = fresh_lane();
     if (!(ABL & 8)) __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
     if (ABL & 4) return;
     const float* Sp = &ring[SLOT][0];
@@ -471,9 +484,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
         kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
       } else
-      sweep_stage1<FD>(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy, a.hz,
-                       fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw, kN, C.f0,
-                       C.f1, C.fz, C.ft);
+      sweep_stage1<FD, true>(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy,
+                             a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw,
+                             kN, C.f0, C.f1, C.fz, C.ft, CW ? col_at_x_face : tile_at_x_face);
       pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
       pN.D[0] = rxp.u - rxm.u; pN.D[1] = nDy.u; pN.D[2] = P.u - M.u;
       pN.D[3] = rxp.v - rxm.v; pN.D[4] = nDy.v; pN.D[5] = P.v - M.v;
@@ -597,29 +610,44 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
 }
 
+// one workgroup per CU at a time: z-chunks by the round model of k_sweep7 (a chunk costs its planes plus ~7 steps of prologue
+// and repeated stage-1 planes, 256 workgroups run per round), at least two planes per chunk.  `cost` is in plane steps of ONE
+// workgroup; a step of a 16-wave workgroup (TY = 12) takes ~1.28 x a step of a 12-wave one (TY = 8) -- measured at 128^3 ... 512^3
+// (tools/kbench.py with F3D_PAIR8_TY): 12 rows win where the rows divide well (384^3: -9.5 %, 512^3: -4 %), 8 rows where one
+// round of workgroups covers the level (256^3: +6 %, 128^3: +6 %) -- so the caller compares cost x step.
+struct Pair8Plan {
+  int zchunk;
+  long cost;
+};
+inline Pair8Plan pair8_plan(const F3dGeo& g, int ty)
+{
+  const int planes = g.z_hi - g.z_lo;
+  const long tiles = static_cast<long>((g.W + kLanes - 1) / kLanes) * ((g.H + ty - 1) / ty);
+  const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
+  const int zc_limit = max_planes_per_chunk(g);
+  Pair8Plan p = {std::min(planes, zc_limit), -1};
+  for (int nzc = 1; nzc <= max_chunks; ++nzc) {
+    const int zc = (planes + nzc - 1) / nzc;
+    if (zc > zc_limit) continue;
+    const long wgs = tiles * ((planes + zc - 1) / zc);
+    const long cost = ((wgs + 255) / 256) * (zc + 7);
+    if (p.cost < 0 || cost < p.cost) {
+      p.cost = cost;
+      p.zchunk = zc;
+    }
+  }
+  if (p.cost < 0) p.cost = static_cast<long>((tiles + 255) / 256) * (p.zchunk + 7);
+  return p;
+}
+
 template <int MODE, int TY, bool FD = false>
 void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
   const int planes = g.z_hi - g.z_lo;
   const int ntx = (g.W + kLanes - 1) / kLanes;
   const int nty = (g.H + TY - 1) / TY;
-  // one workgroup per CU at a time: z-chunks by the round model of k_sweep7 (a chunk costs its planes plus ~7 steps of
-  // prologue and repeated stage-1 planes, 256 workgroups run per round), at least two planes per chunk
-  const long tiles = static_cast<long>(ntx) * nty;
-  const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
   const int zc_limit = max_planes_per_chunk(g);
-  int zchunk = std::min(planes, zc_limit);
-  long best = -1;
-  for (int nzc = 1; nzc <= max_chunks; ++nzc) {
-    const int zc = (planes + nzc - 1) / nzc;
-    if (zc > zc_limit) continue;
-    const long wgs = tiles * ((planes + zc - 1) / zc);
-    const long cost = ((wgs + 255) / 256) * (zc + 7);
-    if (best < 0 || cost < best) {
-      best = cost;
-      zchunk = zc;
-    }
-  }
+  int zchunk = pair8_plan(g, TY).zchunk;
   if (force_zchunk > 0) zchunk = force_zchunk;
   zchunk = std::min(zchunk, zc_limit);
   const int nz = (planes + zchunk - 1) / zchunk;

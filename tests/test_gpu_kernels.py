@@ -659,3 +659,54 @@ def test_solver_kernels_at_minimum_sizes(f3d, oracle, dims, cdims):
             assert bit_same(dev.get(g)[:D, :H, :W], e[:D, :H, :W])
     finally:
         dev.close()
+
+
+def _random_shapes(n, seed):
+    """seeded random boxes inside random containers: widths around the 64-lane tile edges, a few rows, a few planes"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        W = int(rng.choice([rng.integers(2, 20), rng.integers(60, 70), rng.integers(120, 135), rng.integers(180, 200)]))
+        H = int(rng.integers(2, 30))
+        D = int(rng.integers(2, 14))
+        cd = (W + int(rng.integers(0, 9)), H + int(rng.integers(0, 4)), D + int(rng.integers(0, 3)))
+        h = tuple(float(x) for x in np.round(rng.uniform(0.6, 6.0, 3), 3))
+        out.append(((W, H, D), cd, h))
+    return out
+
+
+@pytest.mark.parametrize("dims,cdims,h", _random_shapes(14, 20261004))
+def test_solver_launchers_on_random_shapes(f3d, oracle, dims, cdims, h):
+    """phi/ksi, one sweep, two fused sweeps and sweep + next phi/ksi on seeded random boxes, containers and grid spacings (the
+    fixed CASES above were chosen by hand around known tile edges; these were not chosen at all)."""
+    rng = np.random.default_rng(abs(hash((dims, cdims))) % 2**32)
+    W, H, D = dims
+    eps_s, eps_d, alpha = 0.001, 0.001, 7.5
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, eps_s, eps_d)
+    dev = Dev(f3d, cdims)
+    hip = f3d.hip()
+    box = lambda p: dev.get(p)[:D, :H, :W]
+    cut = lambda a: a[:D, :H, :W]
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.out(), dev.out()
+        f3d.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, eps_s, eps_d, phi, ksi, None))
+        assert bit_same(box(phi), cut(phi_o)) and bit_same(box(ksi), cut(ksi_o))
+        outs = [dev.out() for _ in range(3)]
+        f3d.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, alpha, *outs, None))
+        for g, e in zip(outs, s1):
+            assert bit_same(box(g), cut(e))
+        outs = [dev.out() for _ in range(3)]
+        f3d.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, alpha, *outs, None))
+        for g, e in zip(outs, s2):
+            assert bit_same(box(g), cut(e))
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs, None))
+        for g, e in zip(outs, list(s1) + [phi_n, ksi_n]):
+            assert bit_same(box(g), cut(e))
+    finally:
+        dev.close()

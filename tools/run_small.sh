@@ -1,5 +1,3 @@
 mkdir -p gpurun_out/r2
-python bench.py --no-extra > gpurun_out/r2/bench7.json 2> gpurun_out/r2/bench7.err; python - <<'PY'
-import json; b=json.load(open('gpurun_out/r2/bench7.json')); print(b['value'], b['parity'], b['roofline'].get('traffic'), b['roofline'].get('hbm_frac'))
-PY
-F3D_COMM_BACKEND=shm timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 1 --warmup 0 --size 512 > gpurun_out/r2/bench_shm2.json 2> gpurun_out/r2/bench_shm2.err; tail -n 3 gpurun_out/r2/bench_shm2.err; cut -c1-700 gpurun_out/r2/bench_shm2.json
+python -X faulthandler -m pytest tests/test_gpu_kernels.py tests/test_gpu_configs.py -q -x -k "not c5" > gpurun_out/r2/k9.log 2>&1; tail -2 gpurun_out/r2/k9.log
+grep -q " passed" gpurun_out/r2/k9.log && for v in 8 0 8 0; do F3D_PAIR8_TY=$v python bench.py --no-extra 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('TY', $v, b['value'], b['ms_per_step'], b['roofline']['avg_launch_us'], b['parity']['match'])"; done > gpurun_out/r2/ty_bench.log 2>&1; cat gpurun_out/r2/ty_bench.log
