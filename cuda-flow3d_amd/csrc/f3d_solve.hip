@@ -1388,7 +1388,8 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
     // F3D_PAIR8_TY=8 / 12 pins one
     static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
     int ty = forced;
-    if (ty != 8 && ty != 12) ty = pair8_plan(g, 12).cost * 128 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
+    static const long step12 = std::getenv("F3D_PAIR8_STEP12") ? std::atol(std::getenv("F3D_PAIR8_STEP12")) : 128;  // % of a TY = 8 step
+    if (ty != 8 && ty != 12) ty = pair8_plan(g, 12).cost * step12 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
     if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
     else launch_pair8<PAIR_SS, 8>(pair_args(a), g, t.zchunk, t.xcd_remap);
     return;
