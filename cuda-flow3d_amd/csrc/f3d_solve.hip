@@ -776,7 +776,7 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
                                              const FDivs& fd, float alpha, bool has_xp, bool has_xm, bool has_yp, bool has_ym,
                                              bool has_zp, bool has_zm, float& r_du, float& r_dv, float& r_dw, Carry& k,
                                              float gfx = 0.f, float gfy = 0.f, float gfz = 0.f, float gft = 0.f,
-                                             bool at_x_face = true)
+                                             bool at_x_face = true, float w_x = 0.f, float w_y = 0.f, float w_z = 0.f)
 {
   float fq[3] = {gfx, gfy, gfz};
   if (!FD) {
@@ -793,9 +793,10 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
   k.J12 = fx * fy; k.J13 = fx * fz; k.J23 = fy * fz;
   k.J14 = fx * ft; k.J24 = fy * ft; k.J34 = fz * ft;
 
-  const float hx_2 = alpha / (hx * hx);
-  const float hy_2 = alpha / (hy * hy);
-  const float hz_2 = alpha / (hz * hz);
+  // XSEL callers hand in alpha / h^2 made on the host (pair_consts: the same float operations)
+  const float hx_2 = XSEL ? w_x : alpha / (hx * hx);
+  const float hy_2 = XSEL ? w_y : alpha / (hy * hy);
+  const float hz_2 = XSEL ? w_z : alpha / (hz * hz);
   const float wxp = XSEL ? hx_2 : static_cast<float>(has_xp) * hx_2;
   const float wxm = XSEL ? hx_2 : static_cast<float>(has_xm) * hx_2;
   const float wyp = static_cast<float>(has_yp) * hy_2;
@@ -1380,16 +1381,21 @@ PairArgs pair_args(const SolveArgs& a)
   return p;
 }
 
+// 8 or 12 core rows per tile of k_pair8 (12 or 16 waves per workgroup), whichever the round model prices lower for this level;
+// F3D_PAIR8_TY=8 / 12 pins one, F3D_PAIR8_STEP12 = cost of a 16-wave step in % of a 12-wave one (timing experiments)
+int pair8_rows(const F3dGeo& g)
+{
+  static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
+  static const long step12 = std::getenv("F3D_PAIR8_STEP12") ? std::atol(std::getenv("F3D_PAIR8_STEP12")) : 128;
+  if (forced == 8 || forced == 12) return forced;
+  return pair8_plan(g, 12).cost * step12 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
+}
+
 void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   if (pair8_enabled() && g.pitch % kLanes == 0) {  // the loader fetches whole 64-float row segments in 16-byte pieces
-    // 8 or 12 core rows per tile (12 or 16 waves per workgroup), whichever the round model prices lower for this level;
-    // F3D_PAIR8_TY=8 / 12 pins one
-    static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
-    int ty = forced;
-    static const long step12 = std::getenv("F3D_PAIR8_STEP12") ? std::atol(std::getenv("F3D_PAIR8_STEP12")) : 128;  // % of a TY = 8 step
-    if (ty != 8 && ty != 12) ty = pair8_plan(g, 12).cost * step12 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
+    const int ty = pair8_rows(g);
     if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
     else launch_pair8<PAIR_SS, 8>(pair_args(a), g, t.zchunk, t.xcd_remap);
     return;
@@ -1527,7 +1533,8 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
   a.eps_s = equation_smoothness;
   a.eps_d = equation_data;
   f3d::prof_begin(F3D_K_SWEEP_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  launch_pair8<PAIR_SP, 8>(a, g, tuning().zchunk, tuning().xcd_remap);
+  if (pair8_rows(g) == 12) launch_pair8<PAIR_SP, 12>(a, g, tuning().zchunk, tuning().xcd_remap);
+  else launch_pair8<PAIR_SP, 8>(a, g, tuning().zchunk, tuning().xcd_remap);
   f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
   F3D_HIP(hipGetLastError());
   return 0;

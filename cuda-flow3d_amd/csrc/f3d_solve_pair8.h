@@ -51,7 +51,35 @@ struct PairArgs {
   // PAIR_SP: also store the sweep on plane z_lo-1 / z_hi of the window -- the launch computes them anyway for the weights of
   // planes z_lo and z_hi-1 (f3d_solve_sweep_phi_ksi_edges: a z-slab that owns one plane more than it can give weights to)
   int keep_below, keep_above;
+  // Wave-uniform constants, made on the HOST by pair_consts() with the operations the kernels used to run per wave (float
+  // products, IEEE float / double divisions: the same bits): as kernel arguments they sit in scalar registers or are
+  // re-read from the argument segment by a scalar load when registers are short.  Formed on the device they were vector
+  // values -- 10 + VGPRs of loop-invariant doubles that a 128-register build kept in scratch.
+  double r4[3], r2[3];   // RN64(1 / (4 h)), RN64(1 / (2 h))
+  float d4[3], d2[3];    // 4 h, 2 h
+  float w[3];            // alpha / (h * h)
+  float eps_s2, eps_d2;  // PAIR_SP: eps * eps
+  int fdivs_ok, sdivs_ok;
 };
+
+inline bool host_divisor_ok(float d) { return d >= 0x1p-20f && d <= 0x1p20f; }  // udiv_divisor_ok
+inline void pair_consts(PairArgs& a)
+{
+  const float h[3] = {a.hx, a.hy, a.hz};
+  a.fdivs_ok = a.sdivs_ok = 1;
+  for (int i = 0; i < 3; ++i) {
+    a.d4[i] = 4.f * h[i];
+    a.d2[i] = 2.f * h[i];
+    a.r4[i] = 1.0 / static_cast<double>(a.d4[i]);
+    a.r2[i] = 1.0 / static_cast<double>(a.d2[i]);
+    a.w[i] = a.alpha / (h[i] * h[i]);
+    a.fdivs_ok = a.fdivs_ok && host_divisor_ok(a.d4[i]);
+    a.sdivs_ok = a.sdivs_ok && host_divisor_ok(a.d4[i]) && host_divisor_ok(a.d2[i]);
+  }
+  a.eps_s2 = a.eps_s * a.eps_s;
+  a.eps_d2 = a.eps_d * a.eps_d;
+  if (a.plain_division) a.fdivs_ok = a.sdivs_ok = 0;
+}
 
 template <int TY, int NA = 10>
 struct Pair8Lds {
@@ -120,7 +148,7 @@ struct CarryP {  // PAIR_SP: what phi/ksi of a voxel reuses from its sweep
 // A.3 for one voxel from the increments after the sweep: n?.{u,v,w} = dU, dV, dW of the six neighbours
 __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, const S3& xp, const S3& ym, const S3& yp,
                                                const S3& zm, const S3& zp, float du, float dv_c, float dw,
-                                               const SolveDivs& dv, float eps_s, float eps_d, float& phi, float& ksi)
+                                               const SolveDivs& dv, float eps_s2, float eps_d2, float& phi, float& ksi)
 {
   float q[9] = {k.D[0] + xp.u - xm.u, k.D[1] + yp.u - ym.u, k.D[2] + zp.u - zm.u,
                 k.D[3] + xp.v - xm.v, k.D[4] + yp.v - ym.v, k.D[5] + zp.v - zm.v,
@@ -142,7 +170,7 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
   }
   const float dux = q[0], duy = q[1], duz = q[2], dvx = q[3], dvy = q[4], dvz = q[5], dwx = q[6], dwy = q[7], dwz = q[8];
   phi = 1.f / (2.f * sqrtf(dux * dux + duy * duy + duz * duz + dvx * dvx + dvy * dvy + dvz * dvz + dwx * dwx +
-                           dwy * dwy + dwz * dwz + eps_s * eps_s));
+                           dwy * dwy + dwz * dwz + eps_s2));
   const float fx = k.fx, fy = k.fy, fz = k.fz, ft = k.ft;
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
   const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
@@ -150,7 +178,7 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
   float s = (J11 * du + J12 * dv_c + J13 * dw + J14) * du + (J12 * du + J22 * dv_c + J23 * dw + J24) * dv_c +
             (J13 * du + J23 * dv_c + J33 * dw + J34) * dw + (J14 * du + J24 * dv_c + J34 * dw + J44);
   s = static_cast<float>(s > 0) * s;
-  ksi = 1.f / (2.f * sqrtf(s + eps_d * eps_d));
+  ksi = 1.f / (2.f * sqrtf(s + eps_d2));
 }
 
 // ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
@@ -281,12 +309,14 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   }
 
   // ================================================= compute waves =================================================
-  FDivs fdivs = make_f_divs(a.hx, a.hy, a.hz);
-  fdivs.ok = fdivs.ok && !a.plain_division;
+  FDivs fdivs;
+  fdivs.x4 = UDiv{a.r4[0], a.d4[0]}; fdivs.y4 = UDiv{a.r4[1], a.d4[1]}; fdivs.z4 = UDiv{a.r4[2], a.d4[2]};
+  fdivs.ok = a.fdivs_ok != 0;
   SolveDivs sdivs = {};
   if (MODE == PAIR_SP) {
-    sdivs = make_solve_divs(a.hx, a.hy, a.hz);
-    sdivs.ok = sdivs.ok && !a.plain_division;
+    sdivs.x2 = UDiv{a.r2[0], a.d2[0]}; sdivs.y2 = UDiv{a.r2[1], a.d2[1]}; sdivs.z2 = UDiv{a.r2[2], a.d2[2]};
+    sdivs.x4 = fdivs.x4; sdivs.y4 = fdivs.y4; sdivs.z4 = fdivs.z4;
+    sdivs.ok = a.sdivs_ok != 0;
   }
 
   // row waves
@@ -486,7 +516,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       } else
       sweep_stage1<FD, true>(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy,
                              a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw,
-                             kN, C.f0, C.f1, C.fz, C.ft, CW ? col_at_x_face : tile_at_x_face);
+                             kN, C.f0, C.f1, C.fz, C.ft, CW ? col_at_x_face : tile_at_x_face, a.w[0], a.w[1], a.w[2]);
       pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
       pN.D[0] = rxp.u - rxm.u; pN.D[1] = nDy.u; pN.D[2] = P.u - M.u;
       pN.D[3] = rxp.v - rxm.v; pN.D[4] = nDy.v; pN.D[5] = P.v - M.v;
@@ -554,7 +584,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       } else if (MODE == PAIR_SS)
         sweep_stage2(kC, xm, xp, ym, yp, zm, zp, hC_dv, hC_dw, o0, o1, o2);
       else
-        phi_ksi_stage2(pC, xm, xp, ym, yp, zm, zp, hC.u, hC.v, hC.w, sdivs, a.eps_s, a.eps_d, o0, o1);
+        phi_ksi_stage2(pC, xm, xp, ym, yp, zm, zp, hC.u, hC.v, hC.w, sdivs, a.eps_s2, a.eps_d2, o0, o1);
     }
     asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(sN.u), "v"(sN.v), "v"(sN.w));
     hM = hC;
@@ -641,8 +671,10 @@ inline Pair8Plan pair8_plan(const F3dGeo& g, int ty)
 }
 
 template <int MODE, int TY, bool FD = false>
-void launch_pair8(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
+void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
+  PairArgs a = args;
+  pair_consts(a);
   const int planes = g.z_hi - g.z_lo;
   const int ntx = (g.W + kLanes - 1) / kLanes;
   const int nty = (g.H + TY - 1) / TY;
