@@ -96,6 +96,41 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample(const float* __restrict__
   }
 }
 
+// The x pass through LDS: a wave streams its source row in with 16 bytes per lane (every level reads the full-size original
+// of both frames, so this pass moves the most bytes of the three) and gathers the windows of its outputs from there.
+constexpr int kResampleRowMax = 2048;  // floats of a source row a wave can stage (longer rows: k_resample<0>)
+__global__ __launch_bounds__(kBX* kBY) void k_resample_x_lds(const float* __restrict__ in, float* __restrict__ out, F3dGeo gi,
+                                                             F3dGeo g, int in_n, float delta, float normalization)
+{
+  __shared__ __attribute__((aligned(16))) float rowbuf[kBY][kResampleRowMax];
+  const int y = blockIdx.y * kBY + threadIdx.y;
+  const int z = g.z_lo + blockIdx.z;
+  if (y >= g.H) return;
+  float* row = rowbuf[threadIdx.y];
+  const float* src = in + f3d_row(gi, y, z);
+  for (int k = threadIdx.x * 4; k < in_n; k += kBX * 4) *reinterpret_cast<float4*>(row + k) = *reinterpret_cast<const float4*>(src + k);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads what its own lanes wrote
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const size_t out_row = f3d_row(g, y, z);
+  for (int x = threadIdx.x; x < g.W; x += kBX) {
+    const float left_f = static_cast<float>(x) * delta;
+    const float right_f = static_cast<float>(x + 1) * delta;
+    const int left_i = static_cast<int>(floorf(left_f));
+    const int right_i = static_cast<int>(fminf(static_cast<float>(in_n), ceilf(right_f)));
+    const int cnt = right_i - left_i;
+    float value = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+      float frac = 1.f;
+      if (j == 0) frac = static_cast<float>(left_i + 1) - left_f;
+      if (j == cnt - 1) frac = right_f - static_cast<float>(left_i + j);
+      if (cnt == 1) frac = delta;
+      value = value + row[left_i + j] * frac;
+    }
+    out[out_row + x] = value * normalization;
+  }
+}
+
 // The y and z passes with four x per lane: the source window belongs to the row, x is contiguous, so a lane moves 16 bytes per
 // load.  Rows start on 256-byte boundaries (f3d_alloc_pitched) and the pitch is a multiple of four floats, so the last piece of
 // a row may read padding; only the columns inside the box are stored.
@@ -342,10 +377,12 @@ static int resample_launch(int axis, f3d_devptr input, f3d_devptr output, size_t
   const int out_n = axis == 0 ? g.W : (axis == 1 ? g.H : g.D);
   const float delta = static_cast<float>(n) / static_cast<float>(out_n);          // resample_3d.cu: the kernels' own divisions
   const float normalization = static_cast<float>(out_n) / static_cast<float>(n);
-  if (axis == 0) hipLaunchKernelGGL(k_resample<0>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
   // 16 bytes per lane where every row of both containers starts 16-byte aligned
   const bool x4 = g.pitch % 4 == 0 && gi.pitch % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  const bool staged = x4 && n <= kResampleRowMax && (n + 3) / 4 * 4 <= gi.pitch;
+  if (axis == 0 && staged) hipLaunchKernelGGL(k_resample_x_lds, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
+  if (axis == 0 && !staged) hipLaunchKernelGGL(k_resample<0>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
   if (axis == 1 && x4) hipLaunchKernelGGL(k_resample_x4<1>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
   if (axis == 2 && x4) hipLaunchKernelGGL(k_resample_x4<2>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
   if (axis == 1 && !x4) hipLaunchKernelGGL(k_resample<1>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
