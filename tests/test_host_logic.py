@@ -296,3 +296,17 @@ def _staged(vol, base, planes, lo, hi):
     c = np.full((planes,) + vol.shape[1:], np.nan, np.float32)
     c[lo - base:hi - base] = vol[lo:hi]
     return c
+
+
+def test_generated_median_networks_are_current():
+    """csrc/f3d_median_nets.h is what tools/gen_median_nets.py writes (the generator checks every network against sorted()
+    on random inputs with ties before it emits it), so the committed header cannot drift from its checked source."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_median_nets", os.path.join(root, "tools", "gen_median_nets.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, counts = gen.main()
+    assert counts == [238, 244]
+    with open(gen.HEADER) as f:
+        assert f.read() == text
