@@ -96,6 +96,7 @@ def hip():
         "f3d_event_sync": [C.c_void_p], "f3d_event_elapsed_ms": [_fp, C.c_void_p, C.c_void_p],
         "f3d_event_destroy": [C.c_void_p], "f3d_stream_sync": [],
         "f3d_phi_ksi": [_dp] * 8 + [_sz] * 3 + [C.c_float] * 5 + [_dp, _dp, _slabp],
+        "f3d_phi_ksi_zones": [_dp] * 8 + [_sz] * 3 + [C.c_float] * 5 + [_dp, _dp, _slabp, _slabp],
         "f3d_solve_sweep": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
         "f3d_solve_sweep2": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
         "f3d_solve_sweep_phi_ksi": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 6 + [_dp] * 5 + [_slabp],

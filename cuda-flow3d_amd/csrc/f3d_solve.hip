@@ -48,6 +48,9 @@ struct SolveArgs {
   float p0, p1;  // sweep: alpha, unused; phi_ksi: eps_smooth, eps_data
   unsigned long long* probe = nullptr;  // timing experiments (k_sweep7 with ABL bit 3): [wave][phase] cycle sums
   int plain_division = 0;               // timing experiments (F3D_UDIV=0): every division the ordinary IEEE sequence
+  // k_phiksi6 on TWO windows of the same container in one launch (f3d_phi_ksi_zones): z-chunks nz_first and up belong to
+  // [z2_lo, z2_hi); none when z2_hi <= z2_lo
+  int z2_lo = 0, z2_hi = 0, nz_first = 0;
 };
 
 enum { F0 = 0, F1 = 1, U = 2, V = 3, Wf = 4, DU = 5, DV = 6, DW = 7, PHI = 8 };
@@ -595,8 +598,9 @@ __global__ __launch_bounds__(kLanes* kTY3, 4) void k_phiksi6(SolveArgs a, F3dGeo
 
   const int lane = threadIdx.x;
   const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
+  const bool second = a.z2_hi > a.z2_lo && tz >= a.nz_first;  // wave-uniform
+  const int z0 = second ? a.z2_lo + (tz - a.nz_first) * zchunk : g.z_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, second ? a.z2_hi : g.z_hi);
   const int y0 = ty * kTY3;
   const int y = y0 + r;
   const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_frame_derivatives(const float* __restri
 
 // k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
 template <bool SWEEP>
-void launch_solver(const SolveArgs& a, const F3dGeo& g)
+void launch_solver(const SolveArgs& args, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   const int planes = g.z_hi - g.z_lo;
@@ -1274,7 +1278,12 @@ void launch_solver(const SolveArgs& a, const F3dGeo& g)
   }
   if (t.zchunk > 0) zchunk = t.zchunk;
   zchunk = std::min(zchunk, max_planes_per_chunk(g));
-  const int nz = (planes + zchunk - 1) / zchunk;
+  SolveArgs a = args;
+  int nz = (planes + zchunk - 1) / zchunk;
+  if (!SWEEP && a.z2_hi > a.z2_lo) {  // the chunks of the second window follow those of the first
+    a.nz_first = nz;
+    nz += (a.z2_hi - a.z2_lo + zchunk - 1) / zchunk;
+  }
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = t.xcd_remap ? per_xcd * 8 : n_tiles;
@@ -1435,6 +1444,44 @@ int f3d_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_d
   a.p0 = equation_smoothness;
   a.p1 = equation_data;
   f3d::prof_begin(F3D_K_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
+  launch_solver<false>(a, g);
+  f3d::prof_end(F3D_K_PHI_KSI);
+  F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_phi_ksi_zones(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                      f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, size_t width, size_t height, size_t depth, float hx,
+                      float hy, float hz, float equation_smoothness, float equation_data, f3d_devptr phi, f3d_devptr ksi,
+                      const f3d_slab* zone_a, const f3d_slab* zone_b)
+{
+  F3D_REQUIRE_READY("f3d_phi_ksi_zones");
+  if (!zone_a || !zone_b) return f3d::fail("f3d_phi_ksi_zones: two windows are required");
+  if (zone_a->z_base != zone_b->z_base) return f3d::fail("f3d_phi_ksi_zones: both windows must address the same container planes (z_base)");
+  F3dGeo g, g2;
+  if (!f3d::make_geo(&g, width, height, depth, zone_a, "f3d_phi_ksi_zones")) return 1;
+  if (!f3d::make_geo(&g2, width, height, depth, zone_b, "f3d_phi_ksi_zones")) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_phi_ksi_zones: every dimension must be at least 2");
+  if (g.z_lo == g.z_hi || g2.z_lo == g2.z_hi)  // one of them empty: the ordinary launch on the other
+    return f3d_phi_ksi(frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, width, height, depth, hx, hy, hz,
+                       equation_smoothness, equation_data, phi, ksi, g.z_lo == g.z_hi ? zone_b : zone_a);
+  if (!(g.z_hi <= g2.z_lo || g2.z_hi <= g.z_lo)) return f3d::fail("f3d_phi_ksi_zones: the windows overlap");
+  if (!slab_reach_ok(g, 1, "f3d_phi_ksi_zones") || !slab_reach_ok(g2, 1, "f3d_phi_ksi_zones")) return 1;
+  SolveArgs a;
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
+  const f3d_devptr in[8] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw};
+  for (int i = 0; i < 8; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
+  a.in[8] = a.in[9] = nullptr;
+  a.out[0] = f3d_ptr<float>(phi);
+  a.out[1] = f3d_ptr<float>(ksi);
+  a.out[2] = nullptr;
+  a.hx = hx; a.hy = hy; a.hz = hz;
+  a.p0 = equation_smoothness;
+  a.p1 = equation_data;
+  a.z2_lo = g2.z_lo;
+  a.z2_hi = g2.z_hi;
+  f3d::prof_begin(F3D_K_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo + g2.z_hi - g2.z_lo));
   launch_solver<false>(a, g);
   f3d::prof_end(F3D_K_PHI_KSI);
   F3D_HIP(hipGetLastError());

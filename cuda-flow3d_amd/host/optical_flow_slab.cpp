@@ -218,7 +218,18 @@ bool OpticalFlowSlab::CompleteWeights(Local& l, int lo, int hi, int D, size_t W,
   const int have_lo = l.weights_lo, have_hi = l.weights_hi;
   l.weights_lo = l.weights_hi = 0;
   if (!some) return run(lo, hi);
-  return run(lo, std::min(hi, have_lo)) && run(std::max(lo, have_hi), hi);
+  const int a_hi = std::min(hi, have_lo), b_lo = std::max(lo, have_hi);
+  if (a_hi > lo && hi > b_lo) {  // both zones: one launch
+    f3d_slab za, zb;
+    za.z_base = zb.z_base = ZBase(D, l.rank);
+    za.z_lo = lo;
+    za.z_hi = a_hi;
+    zb.z_lo = b_lo;
+    zb.z_hi = hi;
+    return Check(f3d_phi_ksi_zones(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], W, H, D, hx,
+                                   hy, hz, equation_smoothness, equation_data, l.buf[PHI], l.buf[KSI], &za, &zb));
+  }
+  return run(lo, a_hi) && run(b_lo, hi);
 }
 
 bool OpticalFlowSlab::SweepAndNextWeights(Local& l, const Role (&in)[3], const Role (&out)[3], int sweep_lo, int sweep_hi, int D,

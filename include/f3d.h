@@ -137,6 +137,14 @@ int f3d_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_d
                 float equation_smoothness, float equation_data, f3d_devptr phi, f3d_devptr ksi,
                 const f3d_slab* slab);
 
+/* compute_phi_ksi_3d on TWO disjoint windows of the same container in one launch: the two zones of a z-slab whose weights had
+ * to wait for the neighbours' increments (host/optical_flow_slab.cpp: CompleteWeights) -- two launches of a few planes each
+ * otherwise.  Same results as two f3d_phi_ksi calls; an empty window falls back to one. */
+int f3d_phi_ksi_zones(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                      f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, size_t width, size_t height, size_t depth, float hx,
+                      float hy, float hz, float equation_smoothness, float equation_data, f3d_devptr phi, f3d_devptr ksi,
+                      const f3d_slab* zone_a, const f3d_slab* zone_b);
+
 /* solve_3d, 20 args: cuda_operation_solve.cpp:224-244; kernel src/kernels/solve_3d.cu:264-508.
  * One Jacobi sweep (in-voxel Gauss-Seidel du->dv->dw) into temp_d*; the caller ping-pongs the buffers. */
 int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,

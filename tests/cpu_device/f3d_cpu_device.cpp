@@ -237,6 +237,14 @@ int f3d_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_de
               o.D, hx, hy, hz, eps_s, eps_d, P<float>(phi), P<float>(ksi), &o.g);
   return 0;
 }
+int f3d_phi_ksi_zones(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv, f3d_devptr dw,
+                      size_t width, size_t height, size_t depth, float hx, float hy, float hz, float eps_s, float eps_d, f3d_devptr phi,
+                      f3d_devptr ksi, const f3d_slab* zone_a, const f3d_slab* zone_b)
+{
+  if (!zone_a || !zone_b || zone_a->z_base != zone_b->z_base) return fail("f3d_phi_ksi_zones: two windows of one container are required");
+  const int first = f3d_phi_ksi(f0, f1, u, v, w, du, dv, dw, width, height, depth, hx, hy, hz, eps_s, eps_d, phi, ksi, zone_a);
+  return first ? first : f3d_phi_ksi(f0, f1, u, v, w, du, dv, dw, width, height, depth, hx, hy, hz, eps_s, eps_d, phi, ksi, zone_b);
+}
 int f3d_solve_sweep(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv, f3d_devptr dw,
                     f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz, float alpha,
                     f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw, const f3d_slab* slab)

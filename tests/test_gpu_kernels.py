@@ -479,6 +479,39 @@ def test_sweep_and_next_phi_ksi_slab_window(f3d, oracle, dims, cdims):
         dev.close()
 
 
+@pytest.mark.parametrize("dims,cdims,zones", [((37, 20, 19), (64, 32, 19), ((0, 6), (13, 19))), ((129, 10, 12), (192, 12, 12), ((1, 3), (7, 11))),
+                                              ((70, 70, 30), (128, 72, 30), ((2, 8), (20, 26))), ((64, 8, 9), (64, 8, 9), ((0, 1), (8, 9)))])
+def test_phi_ksi_on_two_zones_in_one_launch(f3d, oracle, dims, cdims, zones):
+    """f3d_phi_ksi_zones = f3d_phi_ksi on each of two disjoint windows of one container; planes outside both stay untouched."""
+    rng = np.random.default_rng(14)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.out(), dev.out()
+        za, zb = f3d.Slab(0, *zones[0]), f3d.Slab(0, *zones[1])
+        f3d.check(f3d.hip().f3d_phi_ksi_zones(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, C.byref(za), C.byref(zb)))
+        for got, exp in ((dev.get(phi), phi_o), (dev.get(ksi), ksi_o)):
+            inside = np.zeros(D, bool)
+            for lo, hi in zones:
+                inside[lo:hi] = True
+                assert bit_same(got[lo:hi, :H, :W], exp[lo:hi, :H, :W])
+            assert np.isnan(got[:D][~inside]).all()
+        # an empty window: the ordinary launch on the other one
+        phi2 = dev.out()
+        empty = f3d.Slab(0, 3, 3)
+        f3d.check(f3d.hip().f3d_phi_ksi_zones(*ptr, W, H, D, *h, 0.001, 0.001, phi2, ksi, C.byref(empty), C.byref(zb)))
+        assert bit_same(dev.get(phi2)[zones[1][0]:zones[1][1], :H, :W], phi_o[zones[1][0]:zones[1][1], :H, :W])
+        # overlapping windows are refused
+        bad = f3d.Slab(0, zones[1][0] - 1 if zones[1][0] > 0 else 0, zones[1][1])
+        assert f3d.hip().f3d_phi_ksi_zones(*ptr, W, H, D, *h, 0.001, 0.001, phi2, ksi, C.byref(bad), C.byref(zb)) != 0
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("keep", [(1, 1), (1, 0), (0, 1)])
 @pytest.mark.parametrize("dims,cdims,window", [((37, 20, 9), (64, 32, 16), (2, 7)), ((129, 10, 9), (192, 12, 9), (0, 6)),
                                                ((65, 6, 5), (128, 8, 8), (2, 5)), ((64, 8, 5), (64, 8, 8), (1, 4))])
