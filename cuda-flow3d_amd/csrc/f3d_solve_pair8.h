@@ -327,6 +327,11 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const bool owner = core && x < g.W && y < g.H;
   const int side = lane < 32 ? 0 : 1;
   const int jr = r + 1;  // ring row of this wave's row
+  // Stage 2 reads the stage-1 results of rows y-1 and y+1 from the LDS image; at a y face of the volume the missing neighbour is
+  // the opposite one (mirror rule), which for a row wave is simply the other image row: chosen here, once, by a scalar select
+  // instead of six vector selects per step.
+  const int r_ym = y == 0 ? r + 1 : r - 1;
+  const int r_yp = y == g.H - 1 ? r - 1 : r + 1;
   const unsigned xb = static_cast<unsigned>(x) * 4u;
   // column wave: lane = side * 32 + core row (lanes beyond TY rows repeat the last row and publish nothing)
   const bool cactive = (lane & 31) < TY;
@@ -559,8 +564,8 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         yp.u = opaque(seedv); yp.v = opaque(seedv); yp.w = opaque(seedv);
         eu = opaque(seedv); ev = opaque(seedv); ew = opaque(seedv);
       } else {
-        ym.u = img1[pb][0][r - 1][lane]; ym.v = img1[pb][1][r - 1][lane]; ym.w = img1[pb][2][r - 1][lane];
-        yp.u = img1[pb][0][r + 1][lane]; yp.v = img1[pb][1][r + 1][lane]; yp.w = img1[pb][2][r + 1][lane];
+        ym.u = img1[pb][0][r_ym][lane]; ym.v = img1[pb][1][r_ym][lane]; ym.w = img1[pb][2][r_ym][lane];
+        yp.u = img1[pb][0][r_yp][lane]; yp.v = img1[pb][1][r_yp][lane]; yp.w = img1[pb][2][r_yp][lane];
         eu = hc1[pb][0][side][r - 1]; ev = hc1[pb][1][side][r - 1]; ew = hc1[pb][2][side][r - 1];
       }
       xm.u = lane_left_or(hC.u, eu); xm.v = lane_left_or(hC.v, ev); xm.w = lane_left_or(hC.w, ew);
@@ -573,8 +578,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         if (x == 0) xm = xp;
         if (x == g.W - 1) xp = xm;
       }
-      if (y == 0) ym = yp;
-      if (y == g.H - 1) yp = ym;
+      // (y faces: r_ym / r_yp already name the opposite row there)
       if (t == 0) zm = zp;
       if (t == g.D - 1) zp = zm;
       if (ABL & 2) {
