@@ -574,13 +574,21 @@ class OpticalFlow:
         self.dims = (width, height, depth)
         return True
 
-    def compute(self, frame_0, frame_1, silent=True, **kw):
+    def compute(self, frame_0, frame_1, silent=True, out=None, **kw):
+        """OpticalFlowE::ComputeFlow: upload, solve, download.  `out` = three preallocated C-contiguous float32 [z,y,x] arrays
+        to receive u, v, w (the reference's caller owns its flow volumes too, page-locked or not); fresh ones otherwise."""
         f0, p0 = _f32(frame_0)
         f1, p1 = _f32(frame_1)
         w, h, d = self.dims
         if f0.shape != (d, h, w) or f1.shape != (d, h, w):
             raise ValueError(f"frames must be [z,y,x] = {(d, h, w)}")
-        u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
+        if out is None:
+            u, v, ww = (np.empty((d, h, w), np.float32) for _ in range(3))
+        else:
+            u, v, ww = out
+            for a in (u, v, ww):
+                if a.dtype != np.float32 or a.shape != (d, h, w) or not a.flags["C_CONTIGUOUS"]:
+                    raise ValueError(f"out arrays must be C-contiguous float32 [z,y,x] = {(d, h, w)}")
         prm = make_params(**kw)
         check(host().f3d_flow_compute(self._h, p0, p1, C.byref(prm), int(silent), u.ctypes.data_as(_fp),
                                       v.ctypes.data_as(_fp), ww.ctypes.data_as(_fp)), "f3d_flow_compute")

@@ -119,6 +119,30 @@ def test_resident_path_equals_host_path(f3d):
     check3(b, a, "resident vs host entry point")
 
 
+def test_compute_into_the_callers_page_locked_volumes(f3d):
+    """ComputeFlow with the caller's own (here page-locked) flow volumes, as the reference's caller has them: the same bits
+    as into fresh arrays, wrong shapes refused before anything runs."""
+    import ctypes as C
+    f0, f1 = f3d.synth_pair(40, 36, 24)
+    kw = dict(warp_levels_count=10, outer_iterations_count=6)
+    a = run_flow(f3d, f0, f1, **kw)
+    out = tuple(np.zeros((24, 36, 40), np.float32) for _ in range(3))
+    hip = f3d.hip()
+    pinned = [o for o in out if hip.f3d_host_register(C.c_void_p(o.ctypes.data), o.nbytes) == 0]
+    flow = f3d.OpticalFlow()
+    flow.initialize(40, 36, 24)
+    try:
+        got = flow.compute(f0, f1, out=out, **kw)
+        assert all(g is o for g, o in zip(got, out))
+        check3(got, a, "caller-owned outputs")
+        with pytest.raises(ValueError):
+            flow.compute(f0, f1, out=(out[0], out[1], np.zeros((24, 36, 41), np.float32)), **kw)
+    finally:
+        flow.destroy()
+        for o in pinned:
+            hip.f3d_host_unregister(C.c_void_p(o.ctypes.data))
+
+
 def test_solve_operator_through_the_bag(f3d, oracle):
     """CudaOperationSolve with the reference's parameter keys; the swapped du/temp pointers come back through the bag."""
     rng = np.random.default_rng(5)
