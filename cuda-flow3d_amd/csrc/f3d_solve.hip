@@ -1396,8 +1396,14 @@ int pair8_rows(const F3dGeo& g)
 {
   static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
   static const long step12 = std::getenv("F3D_PAIR8_STEP12") ? std::atol(std::getenv("F3D_PAIR8_STEP12")) : 128;
-  if (forced == 8 || forced == 12) return forced;
-  return pair8_plan(g, 12).cost * step12 < pair8_plan(g, 8).cost * 100 ? 12 : 8;
+  if (forced == 4 || forced == 8 || forced == 12) return forced;
+  const long c8 = pair8_plan(g, 8).cost * 100, c12 = pair8_plan(g, 12).cost * step12;
+  // 4 rows (8 waves): where a level is so small that every workgroup has a CU to itself, a step of two waves per SIMD takes
+  // ~0.8 of a 12-wave step (two sweeps at 24^3 12.9 -> 10.7 us, 40^3 13.2 -> 11.0 us, 64^3 14.1 -> 13.5 us; from 72^3 up 8 rows win); two such
+  // workgroups on one CU would fit (80 KB of LDS each) but gain nothing, so the same one-per-CU round model prices them
+  static const long step4 = std::getenv("F3D_PAIR8_STEP4") ? std::atol(std::getenv("F3D_PAIR8_STEP4")) : 80;
+  if (pair8_plan(g, 4).cost * step4 < std::min(c8, c12)) return 4;
+  return c12 < c8 ? 12 : 8;
 }
 
 void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
@@ -1405,7 +1411,8 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
   const Tuning& t = tuning();
   if (pair8_enabled() && g.pitch % kLanes == 0) {  // the loader fetches whole 64-float row segments in 16-byte pieces
     const int ty = pair8_rows(g);
-    if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
+    if (ty == 4) launch_pair8<PAIR_SS, 4>(pair_args(a), g, t.zchunk, t.xcd_remap);
+    else if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
     else launch_pair8<PAIR_SS, 8>(pair_args(a), g, t.zchunk, t.xcd_remap);
     return;
   }
@@ -1580,7 +1587,8 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
   a.eps_s = equation_smoothness;
   a.eps_d = equation_data;
   f3d::prof_begin(F3D_K_SWEEP_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  if (pair8_rows(g) == 12) launch_pair8<PAIR_SP, 12>(a, g, tuning().zchunk, tuning().xcd_remap);
+  if (pair8_rows(g) == 4) launch_pair8<PAIR_SP, 4>(a, g, tuning().zchunk, tuning().xcd_remap);
+  else if (pair8_rows(g) == 12) launch_pair8<PAIR_SP, 12>(a, g, tuning().zchunk, tuning().xcd_remap);
   else launch_pair8<PAIR_SP, 8>(a, g, tuning().zchunk, tuning().xcd_remap);
   f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
   F3D_HIP(hipGetLastError());

@@ -652,8 +652,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 struct Pair8Plan {
   int zchunk;
   long cost;
+  long wgs = 0;
 };
-inline Pair8Plan pair8_plan(const F3dGeo& g, int ty)
+inline Pair8Plan pair8_plan(const F3dGeo& g, int ty, long per_round = 256)
 {
   const int planes = g.z_hi - g.z_lo;
   const long tiles = static_cast<long>((g.W + kLanes - 1) / kLanes) * ((g.H + ty - 1) / ty);
@@ -664,13 +665,17 @@ inline Pair8Plan pair8_plan(const F3dGeo& g, int ty)
     const int zc = (planes + nzc - 1) / nzc;
     if (zc > zc_limit) continue;
     const long wgs = tiles * ((planes + zc - 1) / zc);
-    const long cost = ((wgs + 255) / 256) * (zc + 7);
+    const long cost = ((wgs + per_round - 1) / per_round) * (zc + 7);
     if (p.cost < 0 || cost < p.cost) {
       p.cost = cost;
       p.zchunk = zc;
+      p.wgs = wgs;
     }
   }
-  if (p.cost < 0) p.cost = static_cast<long>((tiles + 255) / 256) * (p.zchunk + 7);
+  if (p.cost < 0) {
+    p.cost = static_cast<long>((tiles + per_round - 1) / per_round) * (p.zchunk + 7);
+    p.wgs = tiles;
+  }
   return p;
 }
 
