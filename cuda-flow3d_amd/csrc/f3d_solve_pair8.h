@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 }
 
 // one workgroup per CU at a time: z-chunks by the round model of k_sweep7 (a chunk costs its planes plus ~7 steps of prologue
-// and repeated stage-1 planes, 256 workgroups run per round), at least two planes per chunk.  `cost` is in plane steps of ONE
+// and repeated stage-1 planes, 256 workgroups run per round).  `cost` is in plane steps of ONE
 // workgroup; a step of a 16-wave workgroup (TY = 12) takes ~1.28 x a step of a 12-wave one (TY = 8) -- measured at 128^3 ... 512^3
 // (tools/kbench.py with F3D_PAIR8_TY): 12 rows win where the rows divide well (384^3: -9.5 %, 512^3: -4 %), 8 rows where one
 // round of workgroups covers the level (256^3: +6 %, 128^3: +6 %) -- so the caller compares cost x step.
@@ -658,7 +658,7 @@ inline Pair8Plan pair8_plan(const F3dGeo& g, int ty, long per_round = 256)
 {
   const int planes = g.z_hi - g.z_lo;
   const long tiles = static_cast<long>((g.W + kLanes - 1) / kLanes) * ((g.H + ty - 1) / ty);
-  const int max_chunks = planes / 2 > 0 ? planes / 2 : 1;
+  const int max_chunks = planes > 0 ? planes : 1;  // down to one plane per chunk: three steps instead of four where one round covers it
   const int zc_limit = max_planes_per_chunk(g);
   Pair8Plan p = {std::min(planes, zc_limit), -1};
   for (int nzc = 1; nzc <= max_chunks; ++nzc) {
