@@ -18,8 +18,8 @@
 //     k_sweep7 are gone and the plane-in-flight registers with them;
 //   * stage 2 works exactly like k_sweep7's: stage-1 results of the neighbours come from an LDS image (rows), DPP (lanes), the
 //     column wave (tile edges) and registers (planes).
-// What it buys and what bounds it now (vector unit, L2 -> LDS delivery and the LDS pipe, each about half of the launch and
-// only partly overlapped): DESIGN.md section 3.
+// What it buys and what bounds it now (with 12-row tiles at four waves per SIMD: the vector-issue rate, 8.6e8 instructions
+// per 512^3 two-sweep launch x 4 cycles / 1024 SIMDs = the whole launch): DESIGN.md section 3.
 //
 // Two flavours of the second stage:
 //   PAIR_SS  stage 1 = sweep, stage 2 = sweep              -- f3d_solve_sweep2 (two iterations of cuda_operation_solve.cpp:222-255)
@@ -30,7 +30,12 @@
 // the stages are values the reference computes twice from the same operands (fx, fy, fz, ft, the J products, U[x+1] - U[x-1]).
 //
 // Tile: TY core rows x 64 columns, marching along z.  Waves: TY + 2 row waves (rows y0-1 .. y0+TY), one column wave
-// (stage 1 of the 2 x TY voxels left and right of the tile), one loader wave.  TY = 8 -> 12 waves, three per SIMD.
+// (stage 1 of the 2 x TY voxels left and right of the tile), one loader wave.  TY = 12 -> 16 waves, four per SIMD, 117 / 125
+// VGPRs (SS / SP); TY = 8 -> 12 waves; TY = 4 -> 8 waves for levels so small that a workgroup has its CU to itself.  The
+// launcher prices the three shapes per level (pair8_rows in f3d_solve.hip).  Nothing that is the same for every lane of a wave
+// is computed by the vector unit: the reciprocals of 2h and 4h, alpha / h^2 and eps^2 arrive as kernel arguments (pair_consts),
+// the x-face weights are applied by selection in tiles that touch a face, the lane number is re-made per step where registers
+// are short -- formed per wave they cost 11-22 VGPRs of loop-invariant values and with them the fourth wave per SIMD.
 //
 // x faces.  A 16-byte DMA piece cannot mirror inside itself, so lanes beyond the volume (x >= W) hold whatever the padded
 // row holds and the reference's mirror rule is applied where it matters: at x = 0 the left neighbour IS the right one
