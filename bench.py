@@ -49,11 +49,17 @@ def log(*a):
 
 
 def solver_source_stamp():
-    """sha256 (16 hex digits) of the solver kernel source: the PMC record is only valid for the kernels it was taken on"""
+    """sha256 (16 hex digits) of the solver kernel source with comments and white space taken out (a reworded comment is not
+    another kernel): the PMC record is only valid for the kernels it was taken on.  tools/pmc_traffic.sh stamps its record
+    with this function."""
+    import re
     h = hashlib.sha256()
     for name in ("f3d_solve.hip", "f3d_solve_pair8.h"):
-        with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", name)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)     # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                  # line comments (no string of these files holds "//")
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -31,7 +31,11 @@ for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
         res.setdefault(k, {})[c] = sum(v) / len(v)
         print(f"{d:10s} {k:18s} {c:11s} launches {len(v):3d}  avg {sum(v) / len(v):.6g} KiB")
 import hashlib
-res["_solver_source_sha16"] = hashlib.sha256(open("$R/cuda-flow3d_amd/csrc/f3d_solve.hip", "rb").read() + open("$R/cuda-flow3d_amd/csrc/f3d_solve_pair8.h", "rb").read()).hexdigest()[:16]
+import sys
+sys.path.insert(0, "$R")
+sys.argv = ["bench.py"]
+import bench  # the stamp bench.py checks the record against (kernel sources without comments and white space)
+res["_solver_source_sha16"] = bench.solver_source_stamp()
 json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
 # the record bench.py reads (profiles/rNN_pmc_traffic.json): HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
 S = 512
