@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A MODEL (not a measurement) of the strong-scaling bench: per level, time = launch-latency floor + bandwidth part / N with
 the redundant halo planes of the communication-avoiding windows + what the exchanges cost where they are not hidden.
-Constants come from this round's one-GPU measurements: 2.15 s per 512^3 solve (round 2), ~2 ms of launch latency
+Constants come from this round's one-GPU measurements: 1.97 s per 512^3 solve (end of round 2), ~2 ms of launch latency
 per level (40 outer x ~50 us), ~50 us per exchange (pack + grouped send/recv + unpack; an assumption until a multi-GPU
 box has been measured).   python tools/scale_model.py [--size 512]"""
 import argparse
@@ -15,7 +15,7 @@ S, K, OUTER = a.size, 5, 40
 levels = [math.ceil(S * 0.95 ** l) for l in range(40)]
 floor = 2.0e-3
 vox = [d ** 3 for d in levels]
-t1_total = 2.15 * (S / 512) ** 3 if S != 512 else 2.15
+t1_total = 1.97 * (S / 512) ** 3 if S != 512 else 1.97
 c = (t1_total - 40 * floor) / sum(vox)
 print(f"{S}^3: one GPU {t1_total:.2f} s (input), {c * 1e9:.2f} ns per voxel-level above a {floor * 1e3:.1f} ms floor per level")
 for n in (1, 2, 4, 8):
