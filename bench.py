@@ -22,8 +22,10 @@ One JSON line on stdout carries the metric plus
                  host cores on BASELINE config 2 (128^3, full default pyramid), timed fully.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu] [--no-extra]
-For N > 1 launch through torch.distributed.run (one rank per GPU); the volume is z-slab partitioned and the default size
-is BASELINE config 5 (1024^3).
+For N > 1 the volume is z-slab partitioned over one rank per GPU and the default size is BASELINE config 5 (1024^3).  Two ways
+in: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment), or
+bare -- `python bench.py --gpus N` starts the N rank processes itself (launch_ranks: the parent never loads the native
+library or touches the GPU, forwards rank 0's JSON line, and exits non-zero if any rank fails or hangs).
 """
 import argparse
 import ctypes as C
@@ -218,7 +220,7 @@ def host_inclusive(pkg, flow, S, reps=2):
     finally:
         for a in pinned:
             hip.f3d_host_unregister(C.c_void_p(a.ctypes.data))
-    return {"ms_per_step": round(dt * 1e3, 3), "value": round(S ** 3 / dt / 1e6, 4), "unit": "Mvoxels/s",
+    return {"ms_per_step": round(dt * 1e3, 3), "value": round(S ** 3 / dt / 1e6, 4), "unit": "Mvoxels/s", "steps": reps,
             "note": "timer before H2D, after D2H (the reference's placement); the two frames and the three flow volumes are the "
                     "caller's, page-locked (the reference's ALLOCATE_PINNED_MEMORY switch)"}
 
@@ -314,7 +316,7 @@ def run_single(args):
     inclusive = None
     if not args.no_extra:
         log("[bench] host-inclusive step (H2D + solve + D2H) ...")
-        inclusive = host_inclusive(pkg, flow, S)
+        inclusive = host_inclusive(pkg, flow, S, reps=min(args.steps, 10))   # as many steps as the timed region (at most 10)
     flow.destroy()
 
     def gbs(bytes_per_voxel, vox, ms):
@@ -467,17 +469,22 @@ def run_multi(args):
     wall = tw.item()
 
     tot_ms, tot_bytes, launches = 0.0, 0.0, 0
+    per_kernel = {}
     for kid, bpv in ((1, SWEEP_BYTES_PER_VOXEL), (2, 2 * SWEEP_BYTES_PER_VOXEL)):
         ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
         pkg.check(hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox)))
         tot_ms += ms.value
         tot_bytes += bpv * vox.value
         launches += n.value
+        per_kernel[kid] = (ms.value, n.value, vox.value)
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+    comm = pkg.comm_info()      # what RCCL itself says about the communicator this run used, and what went through it
     # outside the timed region: every rank hashes the planes it owns, rank 0 compares the whole with the single-GPU digest
     mine = pkg.flow_plane_digests(flow.download(), lo, hi)
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(mine, gathered, dst=0)
+    comms = [None] * world if rank == 0 else None
+    dist.gather_object(comm, comms, dst=0)
     parity = None
     if rank == 0:
         parity = parity_record(S, pkg.combine_plane_digests([[d for part in gathered for d in part[c]] for c in range(3)]))
@@ -485,6 +492,23 @@ def run_multi(args):
     flow.destroy()
     pkg.comm_destroy()
     if rank == 0:
+        whole = TOTAL_BYTES.get(S)
+        roof = {"bound": "hbm", "kernel": "k_pair8 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
+                                          "slab incl. widened windows",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches}
+        traffic = measured_traffic("k_pair8")
+        ms2, n2, vox2 = per_kernel[2]
+        if traffic and traffic.get("traffic") and n2:
+            # the fused launches of this run priced with the bytes per voxel the memory system moved in the committed counter
+            # passes (one unsplit launch of the finest level): slab windows re-read two more halo planes per chunk, so this is
+            # a lower bound of the real rate
+            tsize = traffic.pop("_size", 512)
+            per_voxel = traffic["traffic"] / float(tsize) ** 3
+            real = per_voxel * vox2 / (ms2 * 1e-3) / 1e9
+            roof.update({"traffic": traffic["traffic"], "traffic_scope": traffic["traffic_scope"],
+                         "hbm_GBs": round(real, 1), "hbm_frac": round(real / HBM_PEAK_GBS, 4),
+                         "hbm_frac_scope": f"the {n2} two-sweep launches of rank 0 at the measured {per_voxel:.1f} B per voxel"})
         out = {
             "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
             "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -500,21 +524,107 @@ def run_multi(args):
                                       "n <= 4 outer iterations)"
                                       + (" -- REHEARSAL: shared-memory transport, ranks share devices"
                                          if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_pair8 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
-                                                   "slab incl. widened windows",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches},
+            "launched_by": "bench.py itself (one child process per rank)" if os.environ.get("F3D_BENCH_LAUNCHED") == "1"
+                           else "an external launcher (RANK / WORLD_SIZE were set)",
+            # the communicator as the transport reports it: `rccl_ranks` is ncclCommCount's answer on rank 0, not WORLD_SIZE
+            "rccl_ranks": comm["ranks"], "comm_backend": comm["backend"],
+            "comm": {"per_rank": comms,
+                     "halo_GB_sent_per_step": round(sum(c["sent_bytes"] for c in comms) / 1e9 / (args.steps + args.warmup), 4),
+                     "exchanges_per_step_rank0": comm["exchanges"] // max(1, args.steps + args.warmup)},
+            "whole_run_roofline_frac": round(whole / (wall / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4) if whole else None,
+            "roofline": roof,
         }
+        if not args.no_extra:
+            # the legs of the one-GPU line that do not depend on N, so that every line of a scaling run is self-contained: the
+            # like-for-like sample on rank 0's device and the host-CPU baseline (the other ranks wait at the barrier below)
+            log("[bench] fixed sample on rank 0's GPU (phi/ksi + 5 sweeps on a 512^3 level) ...")
+            out["fixed_sample"] = {"what": "phi/ksi + 5 sweeps on a 512^3 level (SURVEY.md 8d): six kernel passes per voxel, "
+                                           "on rank 0's device alone", "gpu": fixed_sample_gpu(pkg, 512)}
+            if not args.no_cpu:
+                log("[bench] fixed sample and BASELINE config 2 on the host cores (oracle) ...")
+                out["fixed_sample"]["cpu"] = fixed_sample_cpu(512)
+                cb = cpu_baseline(golden_pairs())
+                if cb:
+                    out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` started bare: the parent becomes a launcher.  It imports neither the native package nor
+    torch and never touches HIP (a process that has initialised the GPU must not be re-executed, and a parent holding a HIP
+    context would sit on device 0); it starts N children of this same script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (child r uses device r), passes rank 0's stdout -- the ONE JSON line -- through, lets the
+    children's stderr through as it comes, and waits.  Any child that fails, or the whole job exceeding --launch-timeout,
+    ends the others (exact PIDs, SIGTERM then SIGKILL) and makes the exit code non-zero."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sock:       # a free rendezvous port for gloo
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "F3D_BENCH_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL   # only rank 0 prints the line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    log(f"[bench] launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    deadline = time.time() + args.launch_timeout
+    line, failed = None, None
+    import threading
+    box = {}
+
+    def read_rank0():
+        box["out"] = procs[0].stdout.read()
+    reader = threading.Thread(target=read_rank0, daemon=True)
+    reader.start()
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                failed = f"no result after {args.launch_timeout} s"
+                break
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        failed = "interrupted"
+    if failed:
+        stop_all()
+    reader.join(5)
+    text = (box.get("out") or b"").decode(errors="replace")
+    for candidate in text.splitlines():
+        if candidate.startswith("{"):
+            line = candidate
+    if failed or line is None:
+        log(f"[bench] launcher: {failed or 'rank 0 printed no result line'}")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
-    # the native side prints its init/progress lines with printf: keep stdout for the ONE JSON line
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    sys.stdout = os.fdopen(real_stdout, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -524,7 +634,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU legs (cpu_baseline, fixed_sample.cpu)")
     ap.add_argument("--no-extra", action="store_true", help="only the timed steps: no host-inclusive step, fixed sample, "
                                                            "configs 2/3 or CPU legs (profiling runs)")
+    ap.add_argument("--launch-timeout", type=int, default=3300, help="--gpus N started bare: seconds the launcher waits for the "
+                                                                     "ranks before it ends them")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started bare (the way `--gpus 1` is): become the launcher -- before anything loads the native library
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    # the native side prints its init/progress lines with printf: keep stdout for the ONE JSON line
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real_stdout, "w")
     multi = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
     if args.size <= 0:
         args.size = 1024 if multi else 512

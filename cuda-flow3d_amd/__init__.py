@@ -121,6 +121,7 @@ def hip():
         "f3d_abs_max": [_dp, _sz, _sz, _sz, _slabp, _fp],
         "f3d_comm_unique_id": [C.c_void_p], "f3d_comm_init": [C.c_void_p, C.c_int, C.c_int], "f3d_comm_destroy": [],
         "f3d_comm_rank": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "f3d_comm_info": [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_ulonglong)] * 2,
         "f3d_pack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_unpack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_copy_planes": [_dp, C.c_int, _dp, C.c_int, C.c_int, _sz, _sz],
@@ -738,6 +739,16 @@ def comm_init(unique_id, rank, n_ranks, device=-1):
 
 def comm_destroy():
     hip().f3d_comm_destroy()
+
+
+def comm_info():
+    """what the transport says about itself: RCCL's own rank count / rank / device for the live communicator, bytes and
+    exchanges this rank has handed to it"""
+    be, n, r, dev = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    sent, ex = C.c_ulonglong(), C.c_ulonglong()
+    check(hip().f3d_comm_info(C.byref(be), C.byref(n), C.byref(r), C.byref(dev), C.byref(sent), C.byref(ex)), "f3d_comm_info")
+    return {"backend": {0: "none", 1: "rccl", 2: "shm"}.get(be.value, "?"), "ranks": n.value, "rank": r.value,
+            "device": dev.value, "sent_bytes": sent.value, "exchanges": ex.value}
 
 
 class SlabOpticalFlow:

@@ -31,6 +31,9 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: older libraries may lack it
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional, f3d_comm_info only
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;  // optional
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;  // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -40,6 +43,7 @@ struct Rccl {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
   float* d_scalar = nullptr;
+  unsigned long long sent_bytes = 0, exchanges = 0;  // what this rank has handed to the transport (f3d_comm_info)
   // split exchange (f3d_comm_sendrecv_begin / _end): the transfer runs on its own stream beside the kernels
   hipStream_t side = nullptr;
   hipEvent_t packed = nullptr, arrived = nullptr;
@@ -77,6 +81,9 @@ int load_rccl()
   F3D_SYM(GetErrorString, "ncclGetErrorString");
 #undef F3D_SYM
   R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(dlsym(R.handle, "ncclCommAbort"));
+  R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.handle, "ncclCommCount"));
+  R.CommCuDevice = reinterpret_cast<decltype(R.CommCuDevice)>(dlsym(R.handle, "ncclCommCuDevice"));
+  R.CommUserRank = reinterpret_cast<decltype(R.CommUserRank)>(dlsym(R.handle, "ncclCommUserRank"));
   return 0;
 }
 
@@ -189,6 +196,7 @@ int shm_sendrecv(const float* send_buf, const size_t* send_offset, const size_t*
     const int d = peers[i];
     if (d < 0 || d >= M.n_ranks) return f3d::fail("f3d_comm_sendrecv: bad peer %d", d);
     if (!send_count[i]) continue;
+    R.sent_bytes += send_count[i] * sizeof(float);
     if (send_count[i] > M.cap_floats)
       return f3d::fail("f3d_comm (shm): message of %zu floats exceeds the outbox (%zu); raise F3D_SHM_CAP_MB", send_count[i], M.cap_floats);
     if (shm_wait([&] { return mine->taken[d].load(std::memory_order_acquire) == mine->posted[d].load(std::memory_order_relaxed); },
@@ -208,6 +216,7 @@ int shm_sendrecv(const float* send_buf, const size_t* send_offset, const size_t*
     F3D_HIP(hipMemcpy(recv_buf + recv_offset[i], shm_outbox(s, M.rank), recv_count[i] * sizeof(float), hipMemcpyHostToDevice));
     theirs->taken[M.rank].fetch_add(1, std::memory_order_release);
   }
+  ++R.exchanges;
   return 0;
 }
 
@@ -338,6 +347,8 @@ int grouped_sendrecv(const float* send_buf, const size_t* send_offset, const siz
     }
     return f3d::fail("%s: RCCL error %d (%s); the communicator was aborted", who, static_cast<int>(e), R.GetErrorString ? R.GetErrorString(e) : "?");
   }
+  for (int i = 0; i < n_peers; ++i) R.sent_bytes += send_count[i] * sizeof(float);
+  ++R.exchanges;
   return 0;
 }
 
@@ -407,6 +418,7 @@ int f3d_comm_destroy(void)
   }
   R.rank = 0;
   R.n_ranks = 1;
+  R.sent_bytes = R.exchanges = 0;
   return 0;
 }
 
@@ -414,6 +426,29 @@ int f3d_comm_rank(int* rank, int* n_ranks)
 {
   if (rank) *rank = R.rank;
   if (n_ranks) *n_ranks = R.n_ranks;
+  return 0;
+}
+
+int f3d_comm_info(int* backend, int* comm_ranks, int* comm_rank, int* comm_device, unsigned long long* sent_bytes,
+                  unsigned long long* exchanges)
+{
+  int be = 0, n = 0, r = -1, dev = -1;
+  if (M.active) {
+    be = 2;
+    n = M.n_ranks;
+    r = M.rank;
+  } else if (R.comm) {
+    be = 1;  // the counts are the communicator's own answers, not what f3d_comm_init was told
+    if (R.CommCount) F3D_NCCL(R.CommCount(R.comm, &n));
+    if (R.CommUserRank) F3D_NCCL(R.CommUserRank(R.comm, &r));
+    if (R.CommCuDevice) F3D_NCCL(R.CommCuDevice(R.comm, &dev));
+  }
+  if (backend) *backend = be;
+  if (comm_ranks) *comm_ranks = n;
+  if (comm_rank) *comm_rank = r;
+  if (comm_device) *comm_device = dev;
+  if (sent_bytes) *sent_bytes = R.sent_bytes;
+  if (exchanges) *exchanges = R.exchanges;
   return 0;
 }
 

@@ -269,6 +269,12 @@ int f3d_comm_unique_id(void* id128);
 int f3d_comm_init(const void* id128, int rank, int n_ranks);
 int f3d_comm_destroy(void);
 int f3d_comm_rank(int* rank, int* n_ranks);
+/* What the transport itself says (any pointer may be null): backend 0 = none, 1 = RCCL, 2 = the shared-memory rehearsal
+ * transport; with RCCL comm_ranks / comm_rank / comm_device are the answers of ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice for the live communicator (-1 where the library lacks the query); sent_bytes / exchanges count what
+ * this rank has handed to the transport since f3d_comm_init (bench.py reports them per run). */
+int f3d_comm_info(int* backend, int* comm_ranks, int* comm_rank, int* comm_device, unsigned long long* sent_bytes,
+                  unsigned long long* exchanges);
 /* Gather `count` container planes (sub-box width x height of each) of `field`, starting at container plane
  * plane0, into the dense staging buffer at staging[offset_floats ...]; unpack is the inverse. */
 int f3d_pack_planes(f3d_devptr field, int plane0, int count, size_t width, size_t height, f3d_devptr staging,

@@ -445,6 +445,16 @@ int f3d_comm_unique_id(void* id128) { std::memset(id128, 0, 128); return 0; }
 int f3d_comm_init(const void*, int rank, int n_ranks) { return (rank == 0 && n_ranks == 1) ? 0 : fail("the host-memory backend serves one rank"); }
 int f3d_comm_destroy(void) { return 0; }
 int f3d_comm_rank(int* rank, int* n_ranks) { if (rank) *rank = 0; if (n_ranks) *n_ranks = 1; return 0; }
+int f3d_comm_info(int* backend, int* comm_ranks, int* comm_rank, int* comm_device, unsigned long long* sent_bytes, unsigned long long* exchanges)
+{
+  if (backend) *backend = 0;
+  if (comm_ranks) *comm_ranks = 0;
+  if (comm_rank) *comm_rank = -1;
+  if (comm_device) *comm_device = -1;
+  if (sent_bytes) *sent_bytes = 0;
+  if (exchanges) *exchanges = 0;
+  return 0;
+}
 static void plane_copy(float* field, int plane0, int count, size_t width, size_t height, float* staging, bool pack)
 {
   const size_t pitch_f = g_container.pitch / sizeof(float);
