@@ -255,9 +255,46 @@ void CudaOperationResample::ResampleZ(DevicePtr input, DevicePtr output, DataSiz
 
 // ---- solve (cuda_operation_solve.cpp:75-281) ------------------------------------------------------------------
 
+bool CudaOperationSolve::ScratchFits() const
+{
+  return scratch_size_.width == dev_container_size_.width && scratch_size_.height == dev_container_size_.height &&
+         scratch_size_.depth == dev_container_size_.depth && scratch_size_.pitch == dev_container_size_.pitch;
+}
+
+void CudaOperationSolve::FreeScratch()
+{
+  if (phi_alt_) f3d_free(phi_alt_);
+  if (ksi_alt_) f3d_free(ksi_alt_);
+  phi_alt_ = ksi_alt_ = 0;
+  for (DevicePtr& p : fder_) {
+    if (p) f3d_free(p);
+    p = 0;
+  }
+  scratch_size_ = {0, 0, 0, 0};
+}
+
+bool CudaOperationSolve::Initialize(const OperationParameters* params)
+{
+  const bool ok = InitializeContainer(params);
+  // scratch of another container (an earlier Initialize without Destroy in between) would be too small or mis-pitched for the
+  // fused launches, which write whole container-sized volumes into it
+  if (!ScratchFits()) FreeScratch();
+  return ok;
+}
+
+size_t CudaOperationSolve::ScratchVolumes()
+{
+  size_t n = 0;
+  if (FusedSweepsEnabled() && FusedPhiKsiEnabled()) n += 2;
+  if (FusedSweepsEnabled() && FrameDerivativesEnabled()) n += 4;
+  return n;
+}
+
 bool CudaOperationSolve::EnsureWeightScratch()
 {
+  if (!ScratchFits()) FreeScratch();
   if (phi_alt_ && ksi_alt_) return true;
+  scratch_size_ = dev_container_size_;
   const size_t rows = dev_container_size_.height * dev_container_size_.depth;
   for (DevicePtr* p : {&phi_alt_, &ksi_alt_}) {
     if (*p) continue;
@@ -273,6 +310,8 @@ bool CudaOperationSolve::EnsureWeightScratch()
 
 bool CudaOperationSolve::EnsureDerivativeScratch()
 {
+  if (!ScratchFits()) FreeScratch();
+  scratch_size_ = dev_container_size_;
   const size_t rows = dev_container_size_.height * dev_container_size_.depth;
   for (DevicePtr& p : fder_) {
     if (p) continue;
@@ -288,13 +327,7 @@ bool CudaOperationSolve::EnsureDerivativeScratch()
 
 void CudaOperationSolve::Destroy()
 {
-  if (phi_alt_) f3d_free(phi_alt_);
-  if (ksi_alt_) f3d_free(ksi_alt_);
-  phi_alt_ = ksi_alt_ = 0;
-  for (DevicePtr& p : fder_) {
-    if (p) f3d_free(p);
-    p = 0;
-  }
+  FreeScratch();
   CudaOperationBase::Destroy();
 }
 
@@ -359,6 +392,12 @@ void CudaOperationSolve::Execute(OperationParameters& params)
   const bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && inner_iterations_count % 2 == 1 &&
                             outer_iterations_count > 1 && dev_container_size_.pitch % 256 == 0 && EnsureWeightScratch();
   DevicePtr phi_cur = dev_phi, ksi_cur = dev_ksi, phi_nxt = phi_alt_, ksi_nxt = ksi_alt_;
+  // every outer iteration but the last hands the weights to the other pair: with an odd number of hand-overs start in the
+  // operator's pair, so that the weights of the LAST outer iteration end in the caller's dev_phi / dev_ksi as in the reference
+  if (fuse_weights && (outer_iterations_count - 1) % 2 == 1) {
+    std::swap(phi_cur, phi_nxt);
+    std::swap(ksi_cur, ksi_nxt);
+  }
   bool weights_ready = false;
   // The frame derivatives fx, fy, fz, ft depend on the two frames only: computed once here, read by every fused launch of the level
   // instead of the frames (the reference recomputes them for every voxel in each of its 240 launches per level).

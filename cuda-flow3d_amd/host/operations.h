@@ -107,11 +107,20 @@ class CudaOperationResample : public CudaOperationBase {
 class CudaOperationSolve : public CudaOperationBase {
  public:
   CudaOperationSolve() : CudaOperationBase("CUDA Solve") {}
-  bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
+  ~CudaOperationSolve() override { FreeScratch(); }   // a Solve operator dropped without Destroy() still returns its volumes
+  // (Re-)initialisation with another container size or pitch releases the scratch volumes of the old one: they are allocated
+  // again, at the new size, by the first Execute that wants them.
+  bool Initialize(const OperationParameters* params = nullptr) override;
+  // After Execute dev_phi / dev_ksi hold the weights of the LAST outer iteration, as in the reference
+  // (cuda_operation_solve.cpp:215-221 writes them in place): the ping-pong with the operator's second pair starts on the side
+  // that makes it end in the caller's buffers.
   void Execute(OperationParameters& params) override;
   void Destroy() override;
 
   bool silent = false;
+  // container-sized device volumes the operator owns beyond what the caller lends it (0, 2, 4 or 6): the driver adds them to
+  // its memory estimate
+  static size_t ScratchVolumes();
 
  private:
   // second phi / ksi pair for the fused "last sweep + next phi/ksi" launch (f3d_solve_sweep_phi_ksi writes the weights of the
@@ -122,6 +131,10 @@ class CudaOperationSolve : public CudaOperationBase {
   // volumes owned by the operator
   bool EnsureDerivativeScratch();
   DevicePtr fder_[4] = {0, 0, 0, 0};
+  // the container the scratch above was allocated for; anything else makes Ensure*Scratch start over
+  DataSize4 scratch_size_ = {0, 0, 0, 0};
+  bool ScratchFits() const;
+  void FreeScratch();
 };
 
 #endif

@@ -90,7 +90,10 @@ bool OpticalFlowE::InitCudaMemory()
   const size_t row_bytes = dev_container_size_.width * sizeof(float);
   const size_t pitch_guess = (row_bytes + 255) / 256 * 256;
   const size_t needed_memory = pitch_guess * rows * kContainers;
-  std::printf("Needed (approx.):\t%.0fMB\n", needed_memory / mb);
+  // the solve operator allocates up to six more container-sized volumes on first use (second weight pair of the fused last
+  // sweep, frame derivatives); it runs the unfused schedule when they do not fit, so they are reported, not required
+  const size_t optional_memory = pitch_guess * rows * CudaOperationSolve::ScratchVolumes();
+  std::printf("Needed (approx.):\t%.0fMB (+ %.0fMB optional solver scratch)\n", needed_memory / mb, optional_memory / mb);
   if (needed_memory >= free_memory) return false;
 
   size_t allocated_memory = 0;

@@ -64,6 +64,38 @@ CASE = textwrap.dedent('''
         got = flow.compute(f0, f1, silent=True, **kw); passes, streamed, resident = flow.stats(); flow.destroy()
         assert streamed >= 1, (passes, streamed, resident)
         assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), "OpticalFlowP --full on the host backend differs from the oracle"
+    elif what == "reinit":
+        # a solve operator initialised twice WITHOUT Destroy in between, the second time for a bigger container: the second weight
+        # pair of the fused last sweep must follow the container (under the sanitizers a stale, smaller buffer is a heap overflow),
+        # and the weights of the last outer iteration must end in the caller's dev_phi / dev_ksi for odd and even hand-over counts
+        op = pkg.Operation("solve")
+        rng = np.random.default_rng(3)
+        for cdims, dims, outer in (((64, 12, 6), (30, 11, 6), 3), ((128, 24, 12), (70, 21, 9), 4), ((64, 12, 6), (30, 11, 6), 2)):
+            cw, ch, cd = cdims; w, h, d = dims
+            cont = pkg.Containers(*cdims)
+            def put(lo, hi):
+                c = np.zeros((cd, ch, cw), np.float32)
+                c[:d, :h, :w] = rng.uniform(lo, hi, size=(d, h, w)).astype(np.float32)
+                return c, cont.new(c)
+            hosts, ptrs = zip(*[put(*r) for r in [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2)]])
+            names = ["dev_flow_du", "dev_flow_dv", "dev_flow_dw", "dev_phi", "dev_ksi", "dev_temp_du", "dev_temp_dv", "dev_temp_dw"]
+            extra = {n: cont.new() for n in names}
+            assert op.initialize(cont)
+            sp = (1.5, 1.2, 2.0)
+            vals = op.execute(dev_frame_0=ptrs[0], dev_frame_1=ptrs[1], dev_flow_u=ptrs[2], dev_flow_v=ptrs[3], dev_flow_w=ptrs[4],
+                              outer_iterations_count=outer, inner_iterations_count=5, equation_alpha=7.5, equation_smoothness=0.001,
+                              equation_data=0.001, hx=sp[0], hy=sp[1], hz=sp[2], data_size=dims, **extra)
+            pkg.sync()
+            du = np.zeros_like(hosts[0]); dv, dw = du.copy(), du.copy()
+            for _ in range(outer):
+                phi, ksi = orc.phi_ksi(*hosts, du, dv, dw, dims, sp, 0.001, 0.001)
+                for _ in range(5):
+                    du, dv, dw = orc.solve_sweep(*hosts, du, dv, dw, phi, ksi, dims, sp, 7.5)
+            for key, e in (("dev_flow_du", du), ("dev_flow_dv", dv), ("dev_flow_dw", dw), ("dev_phi", phi), ("dev_ksi", ksi)):
+                g = cont.download(vals[key], cdims)
+                assert same(g[:d, :h, :w], e[:d, :h, :w]), (cdims, key)
+            cont.free()
+        op.destroy()
     pkg.shutdown()
     print("ok", what)
 ''')
@@ -88,11 +120,11 @@ def run_case(what, libdir, sanitized):
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit"])
 def test_host_drivers_equal_the_oracle_on_the_cpu_backend(what):
     run_case(what, build("all"), sanitized=False)
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit"])
 def test_host_drivers_are_clean_under_asan_and_ubsan(what):
     run_case(what, build("asan"), sanitized=True)
