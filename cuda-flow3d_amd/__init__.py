@@ -76,6 +76,7 @@ def hip():
     L.f3d_last_error.restype = C.c_char_p
     sig = {
         "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_is_initialized": [], "f3d_device_count": [C.POINTER(C.c_int)],
+        "f3d_crash_maps_enable": [C.c_char_p],
         "f3d_device_name": [C.c_char_p, _sz], "f3d_mem_info": [C.POINTER(_sz), C.POINTER(_sz)],
         "f3d_lds_per_workgroup": [C.POINTER(C.c_int)],
         "f3d_alloc_pitched": [C.POINTER(_dp), C.POINTER(_sz), _sz, _sz], "f3d_free": [_dp],
@@ -139,7 +140,22 @@ def hip():
         fn.argtypes = args
         fn.restype = C.c_int
     _hip = L
+    _arm_crash_maps(L)
     return L
+
+
+def _arm_crash_maps(L):
+    """F3D_CRASH_MAPS=<file> (or any run under a rocprofiler tool): a fatal signal leaves /proc/self/maps in <file> before the
+    usual handlers run, so the anonymous frames of a native stack trace can be put into libraries (include/f3d.h,
+    f3d_crash_maps_enable; the one crash on record happened under `rocprofv3 --pmc` and could only be resolved after the fact)."""
+    path = os.environ.get("F3D_CRASH_MAPS")
+    if not path:
+        blob = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        if "rocprof" not in blob:
+            return
+        base = os.environ.get("F3D_OUT") or os.getcwd()
+        path = os.path.join(base, f"f3d_crash_maps.{os.getpid()}.txt")
+    L.f3d_crash_maps_enable(path.encode())
 
 
 def host():

@@ -5,7 +5,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <algorithm>
+#include <csignal>
+#include <fcntl.h>
 #include <map>
+#include <unistd.h>
 #include <vector>
 
 #include "f3d_internal.h"
@@ -243,6 +247,66 @@ int f3d_range_pop(void)
   return 0;
 }
 
+// ---- load map on a fatal signal ------------------------------------------------------------------------------------------
+// A native stack trace without the load addresses of the libraries is a list of numbers (profiles/r02_pmc_only_crash_stack.txt
+// had to be resolved after the fact by fingerprinting return sites, tools/resolve_frames.py).  With this switched on, a fatal
+// signal first copies /proc/self/maps into a file -- open / read / write only, all async-signal-safe -- then puts the previous
+// handler back and returns, so the faulting instruction faults again into whoever was there before (Python's faulthandler, a
+// profiler's handler, the default action).
+namespace {
+char g_maps_path[512];
+struct sigaction g_prev_action[NSIG];
+const int kFatal[] = {SIGSEGV, SIGBUS, SIGILL, SIGFPE, SIGABRT};
+
+void put_hex(int fd, const char* label, unsigned long long v)
+{
+  char buf[96];
+  int n = 0;
+  while (label[n] && n < 60) { buf[n] = label[n]; ++n; }
+  buf[n++] = '0'; buf[n++] = 'x';
+  for (int shift = 60; shift >= 0; shift -= 4) buf[n++] = "0123456789abcdef"[(v >> shift) & 0xf];
+  buf[n++] = '\n';
+  (void)!write(fd, buf, n);
+}
+
+void maps_on_fatal_signal(int sig, siginfo_t* info, void*)
+{
+  const int out = open(g_maps_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (out >= 0) {
+    put_hex(out, "signal ", static_cast<unsigned long long>(sig));
+    put_hex(out, "fault address ", reinterpret_cast<unsigned long long>(info ? info->si_addr : nullptr));
+    const int in = open("/proc/self/maps", O_RDONLY);
+    if (in >= 0) {
+      char buf[4096];
+      for (;;) {
+        const ssize_t n = read(in, buf, sizeof(buf));
+        if (n <= 0) break;
+        (void)!write(out, buf, static_cast<size_t>(n));
+      }
+      close(in);
+    }
+    close(out);
+  }
+  sigaction(sig, &g_prev_action[sig], nullptr);
+  if (!info || info->si_code <= 0 || sig == SIGABRT) raise(sig);  // sent, not faulted: deliver it to the previous handler now
+}
+}  // namespace
+
+int f3d_crash_maps_enable(const char* path)
+{
+  if (!path || !path[0] || std::strlen(path) >= sizeof(g_maps_path)) return f3d::fail("f3d_crash_maps_enable: bad path");
+  const bool first = g_maps_path[0] == 0;
+  std::strcpy(g_maps_path, path);
+  if (!first) return 0;  // handlers are in place, only the file name changed
+  struct sigaction sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = maps_on_fatal_signal;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  for (int sig : kFatal) sigaction(sig, &sa, &g_prev_action[sig]);
+  return 0;
+}
+
 int f3d_device_name(char* name, size_t capacity)
 {
   F3D_REQUIRE_READY("f3d_device_name");
@@ -324,20 +388,42 @@ int f3d_memset2d(f3d_devptr ptr, size_t pitch, int value, size_t width_bytes, si
   return 0;
 }
 
+// Dense host volume <-> pitched container.  A volume as wide as the pitch is one contiguous range and moves with a plain 1-D
+// copy; otherwise the rows move as 2-D copies of at most kRowsPerCopy rows -- one 2-D copy of height x depth rows (262 144 at
+// 512^3) into pageable memory is the call under which the one recorded crash of this library happened (profiles/
+// r03_crash_frames.md: inside the packet interceptor a profiler had registered with the HSA runtime, reached from the blit
+// dispatch of exactly such a copy), and nothing is gained by handing the runtime the whole volume as a single rectangle.
+namespace {
+constexpr size_t kRowsPerCopy = 32768;
+int copy_dense(char* dev, size_t dev_pitch, size_t dev_height, char* host, size_t width, size_t height, size_t depth, bool to_device)
+{
+  const size_t wb = width * sizeof(float);
+  const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+  if (height == dev_height && wb == dev_pitch) {
+    const size_t bytes = wb * height * depth;
+    F3D_HIP(to_device ? hipMemcpyAsync(dev, host, bytes, kind, S.stream) : hipMemcpyAsync(host, dev, bytes, kind, S.stream));
+    return 0;
+  }
+  // planes per call: whole planes, at most kRowsPerCopy rows (sub-boxes lower than the container go plane by plane)
+  const size_t per_call = height == dev_height ? std::max<size_t>(1, kRowsPerCopy / height) : 1;
+  for (size_t z = 0; z < depth; z += per_call) {
+    const size_t n = std::min(per_call, depth - z);
+    char* d = dev + z * dev_height * dev_pitch;
+    char* h = host + z * height * wb;
+    if (to_device) F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, h, wb, wb, height * n, kind, S.stream));
+    else F3D_HIP(hipMemcpy2DAsync(h, wb, d, dev_pitch, wb, height * n, kind, S.stream));
+  }
+  return 0;
+}
+}  // namespace
+
 int f3d_copy3d_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
                    size_t width, size_t height, size_t depth)
 {
   F3D_REQUIRE_READY("f3d_copy3d_h2d");
   if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_h2d: volume exceeds container");
   char* d = f3d_ptr<char>(dst) + dev_plane0 * dev_height * dev_pitch;
-  const size_t wb = width * sizeof(float);
-  if (height == dev_height) {
-    F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, src, wb, wb, height * depth, hipMemcpyHostToDevice, S.stream));
-  } else {
-    for (size_t z = 0; z < depth; ++z)
-      F3D_HIP(hipMemcpy2DAsync(d + z * dev_height * dev_pitch, dev_pitch, src + z * height * width, wb, wb, height,
-                               hipMemcpyHostToDevice, S.stream));
-  }
+  if (copy_dense(d, dev_pitch, dev_height, reinterpret_cast<char*>(const_cast<float*>(src)), width, height, depth, true)) return 1;
   F3D_HIP(hipStreamSynchronize(S.stream));
   return 0;
 }
@@ -347,15 +433,8 @@ int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_de
 {
   F3D_REQUIRE_READY("f3d_copy3d_d2h");
   if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_d2h: volume exceeds container");
-  const char* s = f3d_ptr<const char>(src) + dev_plane0 * dev_height * dev_pitch;
-  const size_t wb = width * sizeof(float);
-  if (height == dev_height) {
-    F3D_HIP(hipMemcpy2DAsync(dst, wb, s, dev_pitch, wb, height * depth, hipMemcpyDeviceToHost, S.stream));
-  } else {
-    for (size_t z = 0; z < depth; ++z)
-      F3D_HIP(hipMemcpy2DAsync(dst + z * height * width, wb, s + z * dev_height * dev_pitch, dev_pitch, wb, height,
-                               hipMemcpyDeviceToHost, S.stream));
-  }
+  char* s = f3d_ptr<char>(src) + dev_plane0 * dev_height * dev_pitch;
+  if (copy_dense(s, dev_pitch, dev_height, reinterpret_cast<char*>(dst), width, height, depth, false)) return 1;
   F3D_HIP(hipStreamSynchronize(S.stream));
   return 0;
 }

@@ -59,6 +59,11 @@ int f3d_init(int device);
 int f3d_shutdown(void);
 /* 1 between a successful f3d_init() and f3d_shutdown(), else 0 (exit-time code asks before it touches the device) */
 int f3d_is_initialized(void);
+/* Diagnostics (no reference counterpart): from now on a fatal signal (SIGSEGV, SIGBUS, SIGILL, SIGFPE, SIGABRT) first writes
+ * the signal number, the fault address and /proc/self/maps to `path`, then hands the signal to the handler that was installed
+ * before (Python's faulthandler, a profiler's, the default action), so that the frames of a native stack trace can be resolved
+ * to libraries.  Needs no device; calling it again only changes the file name. */
+int f3d_crash_maps_enable(const char* path);
 /* cuDeviceGetCount / cuDeviceGetName: src/utils/cuda_utils.cpp:27,44 */
 int f3d_device_count(int* count);
 int f3d_device_name(char* name, size_t capacity);

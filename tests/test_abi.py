@@ -68,3 +68,22 @@ def test_struct_layouts_match_the_header(f3d):
     got = {k: getattr(p, k) for k, _ in f3d.FlowParams._fields_}
     for k, v in f3d.DEFAULT_PARAMS.items():
         assert got[k] == pytest.approx(v), k
+
+
+def test_a_fatal_signal_leaves_the_load_map_and_still_reaches_the_previous_handler(tmp_path):
+    """F3D_CRASH_MAPS: /proc/self/maps is written before Python's faulthandler (installed earlier) reports the fault"""
+    import subprocess
+    import sys
+    maps = tmp_path / "maps.txt"
+    code = ("import ctypes, faulthandler, importlib, sys\n"
+            "faulthandler.enable()\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "pkg = importlib.import_module('cuda-flow3d_amd')\n"
+            "pkg.hip()\n"
+            "ctypes.string_at(16)\n")
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, F3D_CRASH_MAPS=str(maps)), capture_output=True, timeout=120)
+    assert p.returncode != 0
+    assert b"Fatal Python error: Segmentation fault" in p.stderr         # the handler that was there before still ran
+    text = maps.read_text()
+    assert text.startswith("signal 0x000000000000000b\nfault address 0x0000000000000010\n")
+    assert "libf3d_hip.so" in text and "[stack]" in text

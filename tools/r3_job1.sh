@@ -2,8 +2,8 @@
 # round 3, GPU job 1: baseline kernel numbers, kernel traces of BASELINE configs 2 and 3 with per-level tables, and the
 # 8-slab decomposition of the 1024^3 run on one GPU against the unsplit run (per level).
 set -e
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r3/job1
+R=$(pwd)
+O=${F3D_OUT:-$R/gpurun_out}/r3/job1
 mkdir -p $O
 cd $R
 python3 tools/kbench.py --size 512 --reps 10 --kernel sweep2 > $O/kb512.log 2>&1
@@ -29,3 +29,6 @@ for side in slabs unsplit; do
   rm -f $O/s1024_$side/*/*_kernel_trace.csv
 done
 ls -la $O
+cd $R
+python3 -X faulthandler -m pytest tests/test_bench_launcher.py tests/test_gpu_pipeline.py -q -m gpu -k "bare or bag" > $O/tests.log 2>&1 || true
+tail -5 $O/tests.log
