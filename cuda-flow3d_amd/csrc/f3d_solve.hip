@@ -117,7 +117,7 @@ __device__ __forceinline__ FDivs make_f_divs(float hx, float hy, float hz)
 }
 __device__ __forceinline__ void f_derivatives(float (&q)[3], const FDivs& dv)
 {
-  if (dv.ok && udiv_all_safe(q)) {
+  if (__builtin_expect(dv.ok && udiv_all_safe(q), 1)) {
     q[0] = udiv(q[0], dv.x4);
     q[1] = udiv(q[1], dv.y4);
     q[2] = udiv(q[2], dv.z4);
@@ -803,10 +803,13 @@ __device__ __forceinline__ void sweep_stage1(const Face6& xm, const Face6& xp, c
   const float hz_2 = XSEL ? w_z : alpha / (hz * hz);
   const float wxp = XSEL ? hx_2 : static_cast<float>(has_xp) * hx_2;
   const float wxm = XSEL ? hx_2 : static_cast<float>(has_xm) * hx_2;
-  const float wyp = static_cast<float>(has_yp) * hy_2;
-  const float wym = static_cast<float>(has_ym) * hy_2;
-  const float wzp = static_cast<float>(has_zp) * hz_2;
-  const float wzm = static_cast<float>(has_zm) * hz_2;
+  // XSEL (k_pair8): the y / z face flags are the same for every lane of a row wave, and alpha / h^2 arrives in a scalar register:
+  // (float)(flag) * w is w or +0 for the finite positive w the host checked (pair_consts), i.e. a SCALAR select instead of a
+  // vector select and a vector multiply per face (the column wave, whose rows differ by lane, makes one vector select)
+  const float wyp = XSEL ? (has_yp ? hy_2 : 0.f) : static_cast<float>(has_yp) * hy_2;
+  const float wym = XSEL ? (has_ym ? hy_2 : 0.f) : static_cast<float>(has_ym) * hy_2;
+  const float wzp = XSEL ? (has_zp ? hz_2 : 0.f) : static_cast<float>(has_zp) * hz_2;
+  const float wzm = XSEL ? (has_zm ? hz_2 : 0.f) : static_cast<float>(has_zm) * hz_2;
 
   // phi_f * w_f: the product the reference forms first in every term of sumU/V/W and (commuted) in sumH
   k.pw[0] = (xp.v[LPHI] + c[LPHI]) / 2.f * wxp;
@@ -1410,6 +1413,7 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
 {
   const Tuning& t = tuning();
   if (pair8_enabled() && g.pitch % kLanes == 0) {  // the loader fetches whole 64-float row segments in 16-byte pieces
+    if (launch_pair8_ymarch<PAIR_SS>(pair_args(a), g, t.zchunk, t.xcd_remap)) return;
     const int ty = pair8_rows(g);
     if (ty == 4) launch_pair8<PAIR_SS, 4>(pair_args(a), g, t.zchunk, t.xcd_remap);
     else if (ty == 12) launch_pair8<PAIR_SS, 12>(pair_args(a), g, t.zchunk, t.xcd_remap);
@@ -1533,6 +1537,8 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep2")) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep2: every dimension must be at least 2");
+  if (!pair_weights_finite(hx, hy, hz, equation_alpha))
+    return f3d::fail("f3d_solve_sweep2: alpha / h^2 is not finite (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 2, "f3d_solve_sweep2")) return 1;
   SolveArgs a;
@@ -1564,6 +1570,8 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep_phi_ksi")) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep_phi_ksi: every dimension must be at least 2");
+  if (!pair_weights_finite(hx, hy, hz, equation_alpha))
+    return f3d::fail("f3d_solve_sweep_phi_ksi: alpha / h^2 is not finite (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
   if (phi_next == phi || ksi_next == ksi || phi_next == ksi || ksi_next == phi)
     return f3d::fail("f3d_solve_sweep_phi_ksi: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)");
   if (g.pitch % kLanes != 0)
@@ -1587,7 +1595,8 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
   a.eps_s = equation_smoothness;
   a.eps_d = equation_data;
   f3d::prof_begin(F3D_K_SWEEP_PHI_KSI, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  if (pair8_rows(g) == 4) launch_pair8<PAIR_SP, 4>(a, g, tuning().zchunk, tuning().xcd_remap);
+  if (!a.keep_below && !a.keep_above && launch_pair8_ymarch<PAIR_SP>(a, g, tuning().zchunk, tuning().xcd_remap)) {}
+  else if (pair8_rows(g) == 4) launch_pair8<PAIR_SP, 4>(a, g, tuning().zchunk, tuning().xcd_remap);
   else if (pair8_rows(g) == 12) launch_pair8<PAIR_SP, 12>(a, g, tuning().zchunk, tuning().xcd_remap);
   else launch_pair8<PAIR_SP, 8>(a, g, tuning().zchunk, tuning().xcd_remap);
   f3d::prof_end(F3D_K_SWEEP_PHI_KSI);
@@ -1632,6 +1641,7 @@ int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], siz
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("%s: every dimension must be at least 2", who);
+  if (!pair_weights_finite(hx, hy, hz, alpha)) return f3d::fail("%s: alpha / h^2 is not finite (alpha %g, h %g %g %g)", who, alpha, hx, hy, hz);
   if (g.pitch % kLanes != 0) return f3d::fail("%s: the container pitch must be a multiple of 256 bytes (f3d_alloc_pitched gives that)", who);
   if (with_weights && (out[3] == in[8] || out[4] == in[9] || out[3] == in[9] || out[4] == in[8]))
     return f3d::fail("%s: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)", who);

@@ -37,6 +37,14 @@
 // the x-face weights are applied by selection in tiles that touch a face, the lane number is re-made per step where registers
 // are short -- formed per wave they cost 11-22 VGPRs of loop-invariant values and with them the fourth wave per SIMD.
 //
+// Thin volumes march along y (YM).  A volume of 4 or 5 planes -- BASELINE config 3, 584 x 388 x 5 -- leaves a z march nothing to
+// march over: three prologue planes for four or five steps, and the tile rows cut the one long axis that is left.  With YM the
+// roles of y and z are exchanged in the DATA MOVEMENT only: the "rows" of a tile are the volume's z planes (all of them: TY = 4, 5
+// or 8), the march runs along y (388 steps), rows are Hc * pitch apart and march steps one pitch -- the loader, the ring, the
+// images and the registers never know.  The ARITHMETIC keeps its geometry: where the stages are called the neighbours held as
+// planes (M, P, hM, sN) are handed in as the y neighbours and the tile's row neighbours as the z neighbours, the y / z face flags
+// and mirror rules swap with them, so every expression sees the operands the z-marching kernel (and the reference) gives it.
+//
 // x faces.  A 16-byte DMA piece cannot mirror inside itself, so lanes beyond the volume (x >= W) hold whatever the padded
 // row holds and the reference's mirror rule is applied where it matters: at x = 0 the left neighbour IS the right one
 // (index -1 -> 1) and at x = W-1 the right one is the left one, so stage 1 substitutes the whole neighbour there (rows and
@@ -67,6 +75,16 @@ struct PairArgs {
   int fdivs_ok, sdivs_ok;
 };
 
+// The fused kernels apply the face weights alpha / h^2 by selection ((float)(flag) * w is w or +0 only for a finite w: 0 * inf is
+// NaN), so their entry points refuse spacings and alphas that do not give finite weights -- the reference would return NaN there.
+inline bool pair_weights_finite(float hx, float hy, float hz, float alpha)
+{
+  for (float h : {hx, hy, hz}) {
+    const float w = alpha / (h * h);
+    if (!(w - w == 0.f)) return false;
+  }
+  return true;
+}
 inline bool host_divisor_ok(float d) { return d >= 0x1p-20f && d <= 0x1p20f; }  // udiv_divisor_ok
 inline void pair_consts(PairArgs& a)
 {
@@ -158,7 +176,7 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
   float q[9] = {k.D[0] + xp.u - xm.u, k.D[1] + yp.u - ym.u, k.D[2] + zp.u - zm.u,
                 k.D[3] + xp.v - xm.v, k.D[4] + yp.v - ym.v, k.D[5] + zp.v - zm.v,
                 k.D[6] + xp.w - xm.w, k.D[7] + yp.w - ym.w, k.D[8] + zp.w - zm.w};
-  if (dv.ok && udiv_all_safe(q)) {
+  if (__builtin_expect(dv.ok && udiv_all_safe(q), 1)) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       q[3 * c + 0] = udiv(q[3 * c + 0], dv.x2);
@@ -191,10 +209,15 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
 // FD: the kernel reads the frame derivatives fx, fy, fz, ft (k_frame_derivatives, once per level) instead of the frames: they
 // are centre values, so the frame entries of every neighbour -- their LDS reads, lane shifts, differences and the three
 // divisions by 4h -- drop out of stage 1 (a seventh of its arithmetic), for two more arrays to stream.
-template <int MODE, int TY, int ABL = 0, bool FD = false>
+template <int MODE, int TY, int ABL = 0, bool FD = false, bool YM = false>
 __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
                                                            int xcd_remap)
 {
+  static_assert(!(YM && FD), "the frame-derivative launchers march along z only");
+  // rows of a tile / march direction: (y, z) or, for thin volumes, (z, y).  YM launches cover the whole volume (no slab window).
+  const int RDIM = YM ? g.D : g.H;   // extent along the tile's rows
+  const int MDIM = YM ? g.H : g.D;   // extent along the march
+  const int m_lo = YM ? 0 : g.z_lo, m_hi = YM ? g.H : g.z_hi;
   constexpr int NA = FD ? 12 : 10;
   using L = Pair8Lds<TY, NA>;
   constexpr int NR = L::NR, NJ = L::NJ, NK = L::NK, NJP = L::NJP, NH = L::NH;
@@ -217,11 +240,11 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const int r = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const bool colw = r == NR;
   const bool loader = r == NR + 1;
-  const int z0 = g.z_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, g.z_hi);
+  const int z0 = m_lo + tz * zchunk;
+  const int z1 = min(z0 + zchunk, m_hi);
   const int qs = z0 > 0 ? z0 - 1 : 0;        // first and last plane of stage 1
-  const int qe = z1 < g.D ? z1 : g.D - 1;
-  const int q_end = z1 < g.D ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
+  const int qe = z1 < MDIM ? z1 : MDIM - 1;
+  const int q_end = z1 < MDIM ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
   const int p_last = qe + 1;                 // last plane the ring ever holds (mirrored when it is D)
   const int x0 = tx * kLanes;
   const int y0 = ty * TY;
@@ -231,10 +254,15 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   // the column wave's right halo column is the last column of the volume when W = 64 k + 1
   const bool col_at_x_face = __builtin_amdgcn_readfirstlane(static_cast<int>(left_face || right_face || x0 + kLanes == g.W - 1)) != 0;
 
+  // PAIR_SP: planes whose sweep result this chunk stores -- its own, and at the ends of a window that keeps its edge planes one more
+  const int st_lo = (a.keep_below && z0 == m_lo) ? z0 - 1 : z0;
+  const int st_hi = (a.keep_above && z1 == m_hi) ? z1 + 1 : z1;
   const int zb = qs > 0 ? qs - 1 : 0;  // lowest plane touched: byte offsets inside the chunk stay small and positive
-  const size_t base_off = f3d_row(g, 0, zb);
-  const unsigned plane_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
-  const unsigned row_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned z_stride_b = static_cast<unsigned>(g.Hc) * static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned y_stride_b = static_cast<unsigned>(g.pitch) * 4u;
+  const unsigned plane_b = YM ? y_stride_b : z_stride_b;   // one march step
+  const unsigned row_b = YM ? z_stride_b : y_stride_b;     // one tile row
+  const size_t base_off = YM ? static_cast<size_t>(zb) * static_cast<size_t>(g.pitch) : f3d_row(g, 0, zb);
 
   // ================================================== loader wave ==================================================
   if (loader) {
@@ -250,7 +278,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     for (int k = 0; k < NK; ++k) {
       const int j = 4 * k + (lane >> 4);
       rowv[k] = j < NJ;
-      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + (rowv[k] ? j : 0), g.H), 0, g.H - 1);
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + (rowv[k] ? j : 0), RDIM), 0, RDIM - 1);
       rowb[k] = static_cast<unsigned>(yrow) * row_b + static_cast<unsigned>(x0 + 4 * (lane & 15)) * 4u;
     }
     // halo pieces: lane' = 64 h + lane -> [array][side][row]; four floats left of the tile (x0-4 ..) or right of it (x0+64 ..)
@@ -268,14 +296,14 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 #pragma unroll
       for (int i = 1; i < NA; ++i)
         if (arr == i) b = base[i];
-      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, g.H), 0, g.H - 1);
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, RDIM), 0, RDIM - 1);
       // tiles at an x face fetch a piece from inside the row instead (never used: the mirror rule substitutes there)
       const int xc = s == 0 ? (left_face ? 0 : x0 - 4) : (right_face ? x0 + kLanes - 4 : x0 + kLanes);
-      hptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(g.pitch) + xc;
+      hptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(row_b >> 2) + xc;
     }
     auto issue = [&](int p) {  // plane p (mirrored for the address) into slot (p - (qs-1)) mod 3
       float* slot = &ring[(p - qs + 1) % L::kSlots][0];
-      const int zz = f3d_mir(p, g.D);
+      const int zz = f3d_mir(p, MDIM);
       const unsigned poff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b)));
       unsigned off[NK];
 #pragma unroll
@@ -326,17 +354,17 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 
   // row waves
   const int y = y0 - 1 + r;
-  const int yy = f3d_clampi(f3d_mir(y, g.H), 0, g.H - 1);
+  const int yy = f3d_clampi(f3d_mir(y, RDIM), 0, RDIM - 1);
   const int x = x0 + lane;
   const bool core = r >= 1 && r <= TY;
-  const bool owner = core && x < g.W && y < g.H;
+  const bool owner = core && x < g.W && y < RDIM;
   const int side = lane < 32 ? 0 : 1;
   const int jr = r + 1;  // ring row of this wave's row
   // Stage 2 reads the stage-1 results of rows y-1 and y+1 from the LDS image; at a y face of the volume the missing neighbour is
   // the opposite one (mirror rule), which for a row wave is simply the other image row: chosen here, once, by a scalar select
   // instead of six vector selects per step.
   const int r_ym = y == 0 ? r + 1 : r - 1;
-  const int r_yp = y == g.H - 1 ? r - 1 : r + 1;
+  const int r_yp = y == RDIM - 1 ? r - 1 : r + 1;
   const unsigned xb = static_cast<unsigned>(x) * 4u;
   // column wave: lane = side * 32 + core row (lanes beyond TY rows repeat the last row and publish nothing)
   const bool cactive = (lane & 31) < TY;
@@ -524,13 +552,23 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         r_dw = xm.v[2] + xp.v[3] + ym.v[4] + yp.v[5] + M.phi + P.phi + C.dv + C.dw + C.v + C.w;
         kN.J12 = r_du; kN.d1 = r_dv; kN.pw[0] = r_dw;
       } else
-      sweep_stage1<FD, true>(xm, xp, ym, yp, plane_face(M), plane_face(P), cfc.v, C.u, C.v, C.w, C.dv, C.dw, C.ksi, a.hx, a.hy,
-                             a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, vy < g.H - 1, vy > 0, q < g.D - 1, q > 0, r_du, r_dv, r_dw,
-                             kN, C.f0, C.f1, C.fz, C.ft, CW ? col_at_x_face : tile_at_x_face, a.w[0], a.w[1], a.w[2]);
+      {
+        // the tile's row neighbours (ym, yp here) and the march neighbours (M, P) in their geometric roles
+        const Face6 fM = plane_face(M), fP = plane_face(P);
+        const bool row_p = vy < RDIM - 1, row_m = vy > 0, mar_p = q < MDIM - 1, mar_m = q > 0;
+        sweep_stage1<FD, true>(xm, xp, YM ? fM : ym, YM ? fP : yp, YM ? ym : fM, YM ? yp : fP, cfc.v, C.u, C.v, C.w, C.dv, C.dw,
+                               C.ksi, a.hx, a.hy, a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, YM ? mar_p : row_p, YM ? mar_m : row_m,
+                               YM ? row_p : mar_p, YM ? row_m : mar_m, r_du, r_dv, r_dw, kN, C.f0, C.f1, C.fz, C.ft,
+                               CW ? col_at_x_face : tile_at_x_face, a.w[0], a.w[1], a.w[2]);
+      }
       pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
-      pN.D[0] = rxp.u - rxm.u; pN.D[1] = nDy.u; pN.D[2] = P.u - M.u;
-      pN.D[3] = rxp.v - rxm.v; pN.D[4] = nDy.v; pN.D[5] = P.v - M.v;
-      pN.D[6] = rxp.w - rxm.w; pN.D[7] = nDy.w; pN.D[8] = P.w - M.w;
+      {
+        const S3 dRow = nDy, dMar = {P.u - M.u, P.v - M.v, P.w - M.w};   // U[+1] - U[-1] along the rows / the march
+        const S3 dY = YM ? dMar : dRow, dZ = YM ? dRow : dMar;
+        pN.D[0] = rxp.u - rxm.u; pN.D[1] = dY.u; pN.D[2] = dZ.u;
+        pN.D[3] = rxp.v - rxm.v; pN.D[4] = dY.v; pN.D[5] = dZ.v;
+        pN.D[6] = rxp.w - rxm.w; pN.D[7] = dY.w; pN.D[8] = dZ.w;
+      }
     }
     // what a neighbour reads of this voxel in stage 2: SS U + dU', SP dU'
     const S3 sN = MODE == PAIR_SS ? S3{C.u + r_du, C.v + r_dv, C.w + r_dw} : S3{r_du, r_dv, r_dw};
@@ -548,8 +586,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       }
     }
     // PAIR_SP: the sweep's result is final -- store it for the planes this chunk owns
-    if (MODE == PAIR_SP && do1 && owner && (q >= z0 || (a.keep_below && q == g.z_lo - 1)) &&
-        (q < z1 || (a.keep_above && q == g.z_hi))) {
+    if (MODE == PAIR_SP && do1 && owner && q >= st_lo && q < st_hi) {
       const unsigned off = xb + rowoff(yy, q);
       gst(obase[0], off, r_du);
       gst(obase[1], off, r_dv);
@@ -585,15 +622,16 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       }
       // (y faces: r_ym / r_yp already name the opposite row there)
       if (t == 0) zm = zp;
-      if (t == g.D - 1) zp = zm;
+      if (t == MDIM - 1) zp = zm;
       if (ABL & 2) {
         o0 = xm.u + xp.v + ym.w + kC.J12;
         o1 = yp.u + zm.v + zp.w + kC.d1;
         o2 = xm.w + yp.v + zp.u + kC.pw[0] + hC_dv + hC_dw;
-      } else if (MODE == PAIR_SS)
-        sweep_stage2(kC, xm, xp, ym, yp, zm, zp, hC_dv, hC_dw, o0, o1, o2);
+      } else if (MODE == PAIR_SS)   // (ym, yp) = row neighbours, (zm, zp) = march neighbours: handed over in their geometric roles
+        sweep_stage2(kC, xm, xp, YM ? zm : ym, YM ? zp : yp, YM ? ym : zm, YM ? yp : zp, hC_dv, hC_dw, o0, o1, o2);
       else
-        phi_ksi_stage2(pC, xm, xp, ym, yp, zm, zp, hC.u, hC.v, hC.w, sdivs, a.eps_s2, a.eps_d2, o0, o1);
+        phi_ksi_stage2(pC, xm, xp, YM ? zm : ym, YM ? zp : yp, YM ? ym : zm, YM ? yp : zp, hC.u, hC.v, hC.w, sdivs, a.eps_s2,
+                       a.eps_d2, o0, o1);
     }
     asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(sN.u), "v"(sN.v), "v"(sN.w));
     hM = hC;
@@ -659,12 +697,11 @@ struct Pair8Plan {
   long cost;
   long wgs = 0;
 };
-inline Pair8Plan pair8_plan(const F3dGeo& g, int ty, long per_round = 256)
+// `rows` / `planes`: extent along the tile rows and along the march (H and the z window; D and H for a y march)
+inline Pair8Plan pair8_plan_dims(int width, int rows, int planes, int ty, int zc_limit, long per_round = 256)
 {
-  const int planes = g.z_hi - g.z_lo;
-  const long tiles = static_cast<long>((g.W + kLanes - 1) / kLanes) * ((g.H + ty - 1) / ty);
+  const long tiles = static_cast<long>((width + kLanes - 1) / kLanes) * ((rows + ty - 1) / ty);
   const int max_chunks = planes > 0 ? planes : 1;  // down to one plane per chunk: three steps instead of four where one round covers it
-  const int zc_limit = max_planes_per_chunk(g);
   Pair8Plan p = {std::min(planes, zc_limit), -1};
   for (int nzc = 1; nzc <= max_chunks; ++nzc) {
     const int zc = (planes + nzc - 1) / nzc;
@@ -683,17 +720,41 @@ inline Pair8Plan pair8_plan(const F3dGeo& g, int ty, long per_round = 256)
   }
   return p;
 }
+inline Pair8Plan pair8_plan(const F3dGeo& g, int ty, long per_round = 256)
+{
+  return pair8_plan_dims(g.W, g.H, g.z_hi - g.z_lo, ty, max_planes_per_chunk(g), per_round);
+}
 
-template <int MODE, int TY, bool FD = false>
+// Thin volumes march along y (YM, see the top of this file): the whole level in one launch, no slab window, every byte offset
+// inside the container below 4 GiB.  Returns the tile height (4, 5 or 8 = the number of z planes a tile holds) or 0.
+// F3D_PAIR8_YMARCH=0 keeps the z march, =1 takes the y march wherever it is possible (read per call: the tests run both).
+inline int pair8_ymarch_rows(const F3dGeo& g)
+{
+  const char* e = std::getenv("F3D_PAIR8_YMARCH");
+  const int mode = e ? std::atoi(e) : -1;
+  if (mode == 0) return 0;
+  if (g.z_base != 0 || g.z_lo != 0 || g.z_hi != g.D || g.D > 8 || g.D < 2 || g.H < 2) return 0;
+  const unsigned long long bytes = static_cast<unsigned long long>(g.Hc) * static_cast<unsigned long long>(g.pitch) * 4ull *
+                                   static_cast<unsigned long long>(g.D + 1);
+  if (bytes >= 0xf0000000ull) return 0;
+  // Measured (tools/r3_job2.sh, two sweeps / sweep + phi/ksi): 584 x 388 x 5 34.2 -> 33.8 / 40.4 -> 39.2 us, 555 x 369 x 5 32.6 -> 31.0 /
+  // 38.5 -> 36.2 us, but 501 x 333 x 4 21.4 -> 23.0 / 24.7 -> 26.8 us: a level of ~1 M voxels is a handful of steps per CU either way
+  // and bound by the latency of a step, not by the march direction.  By default only five planes and more, where it wins.
+  if (mode != 1 && (g.D < 5 || g.H < 8 * g.D)) return 0;
+  return g.D <= 4 ? 4 : (g.D == 5 ? 5 : 8);
+}
+
+template <int MODE, int TY, bool FD = false, bool YM = false>
 void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
   PairArgs a = args;
   pair_consts(a);
-  const int planes = g.z_hi - g.z_lo;
+  const int rows = YM ? g.D : g.H;
+  const int planes = YM ? g.H : g.z_hi - g.z_lo;
   const int ntx = (g.W + kLanes - 1) / kLanes;
-  const int nty = (g.H + TY - 1) / TY;
-  const int zc_limit = max_planes_per_chunk(g);
-  int zchunk = pair8_plan(g, TY).zchunk;
+  const int nty = (rows + TY - 1) / TY;
+  const int zc_limit = YM ? planes : max_planes_per_chunk(g);
+  int zchunk = pair8_plan_dims(g.W, rows, planes, TY, zc_limit).zchunk;
   if (force_zchunk > 0) zchunk = force_zchunk;
   zchunk = std::min(zchunk, zc_limit);
   const int nz = (planes + zchunk - 1) / zchunk;
@@ -703,13 +764,28 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
   const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
   static const int abl = std::getenv("F3D_ABLATE8") ? std::atoi(std::getenv("F3D_ABLATE8")) : 0;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
-  if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
-  if constexpr (MODE == PAIR_SS) {
-    if (abl == 1) return go(k_pair8<MODE, TY, 1>);
-    if (abl == 2) return go(k_pair8<MODE, TY, 2>);
-    if (abl == 3) return go(k_pair8<MODE, TY, 3>);
-    if (abl == 4) return go(k_pair8<MODE, TY, 4>);
-    if (abl == 8) return go(k_pair8<MODE, TY, 8>);
+  if constexpr (YM) return go(k_pair8<MODE, TY, 0, false, true>);
+  else if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
+  else {
+    if constexpr (MODE == PAIR_SS) {
+      if (abl == 1) return go(k_pair8<MODE, TY, 1>);
+      if (abl == 2) return go(k_pair8<MODE, TY, 2>);
+      if (abl == 3) return go(k_pair8<MODE, TY, 3>);
+      if (abl == 4) return go(k_pair8<MODE, TY, 4>);
+      if (abl == 8) return go(k_pair8<MODE, TY, 8>);
+    }
+    go(k_pair8<MODE, TY, 0>);
   }
-  go(k_pair8<MODE, TY, 0>);
+}
+
+// thin volume: the y-marching build whose tile holds all z planes
+template <int MODE>
+bool launch_pair8_ymarch(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
+{
+  switch (pair8_ymarch_rows(g)) {
+    case 4: launch_pair8<MODE, 4, false, true>(a, g, force_zchunk, xcd_remap); return true;
+    case 5: launch_pair8<MODE, 5, false, true>(a, g, force_zchunk, xcd_remap); return true;
+    case 8: launch_pair8<MODE, 8, false, true>(a, g, force_zchunk, xcd_remap); return true;
+    default: return false;
+  }
 }

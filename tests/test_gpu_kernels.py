@@ -743,3 +743,50 @@ def test_solver_launchers_on_random_shapes(f3d, oracle, dims, cdims, h):
             assert bit_same(box(g), cut(e))
     finally:
         dev.close()
+
+
+# thin volumes: the fused launches march along y with all z planes in the tile (k_pair8 with YM, csrc/f3d_solve_pair8.h)
+THIN_CASES = [
+    ((70, 40, 5), (128, 40, 5)),      # the shape class of BASELINE config 3: five planes, tile height 5
+    ((129, 33, 4), (192, 36, 4)),     # four planes (the coarse levels of config 3), W = 64 k + 1, container higher than the level
+    ((37, 21, 2), (64, 32, 8)),       # two planes in a deeper container: every z neighbour is a mirror
+    ((64, 50, 3), (64, 50, 3)),
+    ((66, 19, 6), (128, 19, 6)),      # six, seven, eight planes: tile height 8, rows beyond the volume idle
+    ((31, 64, 7), (64, 64, 8)),
+    ((200, 17, 8), (256, 20, 8)),
+    ((5, 9, 4), (16, 9, 4)),
+]
+
+
+@pytest.mark.parametrize("dims,cdims", THIN_CASES)
+@pytest.mark.parametrize("h", SPACINGS)
+@pytest.mark.parametrize("ymarch", ["1", "0"])
+def test_fused_launches_on_thin_volumes_march_along_y(f3d, oracle, dims, cdims, h, ymarch, monkeypatch):
+    """Two fused sweeps and sweep + next phi/ksi on volumes of 2 ... 8 planes, forced through the y-marching build (F3D_PAIR8_YMARCH=1,
+    whatever the H / D ratio) and through the ordinary z march (=0): both equal the oracle bit for bit."""
+    monkeypatch.setenv("F3D_PAIR8_YMARCH", ymarch)
+    rng = np.random.default_rng(hash((dims, h, 9)) % 2**32)
+    W, H, D = dims
+    arrs = solver_inputs(rng, dims, cdims)
+    alpha, eps_s, eps_d = 7.5, 0.001, 0.002
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, eps_s, eps_d)
+    dev = Dev(f3d, cdims)
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(f3d.hip().f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, alpha, *outs[:3], None))
+        for name, g, e in zip(("du", "dv", "dw"), outs, s2):
+            got = dev.get(g)[:D, :H, :W]
+            assert bit_same(got, e[:D, :H, :W]), \
+                f"two sweeps, {name}: {np.count_nonzero(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))} voxels differ"
+        f3d.check(f3d.hip().f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs, None))
+        for name, g, e in zip(("du", "dv", "dw", "phi", "ksi"), outs, list(s1) + [phi_n, ksi_n]):
+            got = dev.get(g)[:D, :H, :W]
+            assert bit_same(got, e[:D, :H, :W]), \
+                f"sweep + phi/ksi, {name}: {np.count_nonzero(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))} voxels differ"
+    finally:
+        dev.close()

@@ -46,7 +46,9 @@ def test_the_scanner_sees_a_premature_copy():
 
 # ---- k_pair8: the loader wave's DMA instructions, its counted wait and the barrier that publishes a plane --------------------
 
-SHIPPED_PAIR8 = [(mode, ty, fd) for mode in (0, 1) for ty in (4, 8, 12) for fd in (0,)] + [(0, 8, 1), (1, 8, 1)]
+# (MODE, TY, FD, YM): two sweeps / sweep + phi/ksi on 4-, 8-, 12-row tiles; on frame derivatives; marching along y (thin volumes)
+SHIPPED_PAIR8 = ([(mode, ty, 0, 0) for mode in (0, 1) for ty in (4, 8, 12)] + [(0, 8, 1, 0), (1, 8, 1, 0)] +
+                 [(mode, ty, 0, 1) for mode in (0, 1) for ty in (4, 5, 8)])
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
@@ -66,7 +68,7 @@ def test_pair8_loader_waits_barriers_and_scratch(tmp_path):
     assert len(scratch) >= len(SHIPPED_PAIR8)
     for name, size in scratch.items():
         assert size == 0, f"{name} uses {size} bytes of scratch per lane"
-    for mode, ty, fd in SHIPPED_PAIR8:
+    for mode, ty, fd, ym in SHIPPED_PAIR8:
         assert tool.pair8_per_plane(ty, fd) <= 63
     assert tool.pair8_per_plane(12, 0) == 45 and tool.pair8_per_plane(8, 0) == 34 and tool.pair8_per_plane(4, 0) == 23
 

@@ -154,8 +154,8 @@ VMEM_PREFIXES = ("global_", "buffer_", "flat_", "scratch_")
 
 
 def pair8_params(name):
-    """(MODE, TY, ABL, FD) from the mangled name ..k_pair8ILi<MODE>ELi<TY>ELi<ABL>ELb<FD>EE.."""
-    m = re.search(r"k_pair8ILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+    """(MODE, TY, ABL, FD, YM) from the mangled name ..k_pair8ILi<MODE>ELi<TY>ELi<ABL>ELb<FD>ELb<YM>EE.."""
+    m = re.search(r"k_pair8ILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
     return tuple(int(g) for g in m.groups()) if m else None
 
 

@@ -47,6 +47,36 @@ __global__ void k_own(unsigned* buf, unsigned* out, unsigned* counter, unsigned*
   if (threadIdx.x == 0) out[me] = acc;
 }
 
+// flags: every workgroup publishes its arrival in a slot of its own (a plain release store, no read-modify-write), the first wave
+// of workgroup 0 watches all slots with one load per poll (one lane per slot, n <= 64) and then raises the go word the others
+// poll: two trips through the fabric whatever n is, no serialised atomics
+__global__ void k_flags(unsigned* buf, unsigned* out, unsigned* slots, unsigned* go, int rounds)
+{
+  const unsigned n = gridDim.x, me = blockIdx.x;
+  unsigned acc = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const unsigned gen = r + 1;
+    if (threadIdx.x == 0) __hip_atomic_store(&buf[(r & 1) * n + me], r * 977u + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&slots[me * 16], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (me == 0) {
+      if (threadIdx.x < 64) {
+        const unsigned lane = threadIdx.x;
+        for (;;) {
+          const unsigned v = lane < n ? __hip_atomic_load(&slots[lane * 16], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : gen;
+          if (__builtin_amdgcn_ballot_w64(v != gen) == 0) break;
+        }
+        if (lane == 0) __hip_atomic_store(go, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (threadIdx.x == 0) {
+      while (__hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {}
+    }
+    __syncthreads();
+    acc += __hip_atomic_load(&buf[(r & 1) * n + (me + 9) % n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) out[me] = acc;
+}
+
 __global__ void k_trivial(unsigned* buf) { if (threadIdx.x == 0) buf[blockIdx.x] += 1; }
 
 int main()
@@ -56,22 +86,29 @@ int main()
   CK(hipMemset(buf, 0, 4096 * 4)); CK(hipMemset(ctr, 0, 256));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int rounds = 2000;
-  for (int threads : {256, 768}) for (int wgs : {64, 128, 256}) {
-    for (int which = 0; which < 2; ++which) {
+  unsigned *slots, *go;
+  CK(hipMalloc(&slots, 64 * 64)); CK(hipMalloc(&go, 256));
+  for (int threads : {256, 768}) for (int wgs : {8, 16, 32, 64, 128, 256}) {
+    for (int which = 0; which < 3; ++which) {
+      if (which == 2 && wgs > 64) continue;
+      CK(hipMemset(slots, 0, 64 * 64)); CK(hipMemset(go, 0, 256));
       int r = rounds; unsigned* gen = ctr + 16;
       void* a_cg[] = {&buf, &out, &r};
       void* a_own[] = {&buf, &out, &ctr, &gen, &r};
+      void* a_flags[] = {&buf, &out, &slots, &go, &r};
       float best = 1e30f;
       for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
         if (which == 0) CK(hipLaunchCooperativeKernel((void*)k_cg, dim3(wgs), dim3(threads), a_cg, 0, 0));
-        else CK(hipLaunchCooperativeKernel((void*)k_own, dim3(wgs), dim3(threads), a_own, 0, 0));
+        else if (which == 1) CK(hipLaunchCooperativeKernel((void*)k_own, dim3(wgs), dim3(threads), a_own, 0, 0));
+        else { CK(hipMemset(slots, 0, 64 * 64)); CK(hipMemset(go, 0, 256)); CK(hipEventRecord(e0));
+               CK(hipLaunchCooperativeKernel((void*)k_flags, dim3(wgs), dim3(threads), a_flags, 0, 0)); }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
       }
       unsigned h[256]; CK(hipMemcpy(h, out, wgs * 4, hipMemcpyDeviceToHost));
       unsigned exp = 0; for (int q = 0; q < rounds; ++q) exp += q * 977u + (0 + 9) % wgs;
-      std::printf("%s  %3d workgroups x %3d lanes: %.2f us per barrier round%s\n", which ? "own" : "cg ", wgs, threads,
+      std::printf("%s  %3d workgroups x %3d lanes: %.2f us per barrier round%s\n", which == 0 ? "cg   " : which == 1 ? "own  " : "flags", wgs, threads,
                   best * 1e3f / rounds, h[0] == exp ? "" : "  (WRONG DATA)");
     }
   }
