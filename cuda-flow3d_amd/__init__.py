@@ -77,6 +77,8 @@ def hip():
     sig = {
         "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_is_initialized": [], "f3d_device_count": [C.POINTER(C.c_int)],
         "f3d_crash_maps_enable": [C.c_char_p],
+        "f3d_selftest_weights": [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
+                                 C.POINTER(C.c_uint)],
         "f3d_device_name": [C.c_char_p, _sz], "f3d_mem_info": [C.POINTER(_sz), C.POINTER(_sz)],
         "f3d_lds_per_workgroup": [C.POINTER(C.c_int)],
         "f3d_alloc_pitched": [C.POINTER(_dp), C.POINTER(_sz), _sz, _sz], "f3d_free": [_dp],
@@ -194,6 +196,7 @@ def host():
         "f3d_slabflow_download": [C.c_void_p, _fp, _fp, _fp],
         "f3d_slabflow_overlapped_iterations": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_batched_exchanges": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_slabflow_gathered_warps": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_destroy": [C.c_void_p],
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
@@ -812,6 +815,12 @@ class SlabOpticalFlow:
     def overlapped_iterations(self):
         n = _sz()
         check(host().f3d_slabflow_overlapped_iterations(self._h, C.byref(n)))
+        return n.value
+
+    def gathered_warps(self):
+        """pyramid levels of the last compute whose warp needed frame 1 gathered beyond the halo room"""
+        n = _sz()
+        check(host().f3d_slabflow_gathered_warps(self._h, C.byref(n)))
         return n.value
 
     def batched_exchanges(self):

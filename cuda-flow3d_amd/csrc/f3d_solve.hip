@@ -1615,6 +1615,56 @@ int f3d_solve_sweep_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr f
                                        temp_dw, phi_next, ksi_next, slab, 0, 0);
 }
 
+namespace {
+struct WeightTally {
+  unsigned long long checked, excluded, mismatches;
+  unsigned first[4];
+};
+// every bit pattern in [lo, hi]: weight_fast (where weight_fast_ok lets it through) against the IEEE chain the reference's
+// expression compiles to -- the same device functions the fused kernel calls, in the same translation unit
+__global__ __launch_bounds__(256) void k_selftest_weights(unsigned lo, unsigned hi, WeightTally* t)
+{
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+  unsigned long long checked = 0, excluded = 0;
+  for (unsigned long long i = lo + static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i <= hi; i += stride) {
+    const float a = __uint_as_float(static_cast<unsigned>(i));
+    float s;
+    const float fast = weight_fast(a, s);
+    if (!weight_fast_ok(a, s)) {
+      ++excluded;
+      continue;
+    }
+    ++checked;
+    if (__float_as_uint(fast) != __float_as_uint(weight_ieee(a))) {
+      const unsigned long long n = atomicAdd(&t->mismatches, 1ull);
+      if (n < 4) t->first[n] = static_cast<unsigned>(i);
+    }
+  }
+  atomicAdd(&t->checked, checked);
+  atomicAdd(&t->excluded, excluded);
+}
+}  // namespace
+
+int f3d_selftest_weights(unsigned lo_bits, unsigned hi_bits, unsigned long long* checked, unsigned long long* excluded,
+                         unsigned long long* mismatches, unsigned* first_mismatch)
+{
+  F3D_REQUIRE_READY("f3d_selftest_weights");
+  if (lo_bits > hi_bits) return f3d::fail("f3d_selftest_weights: empty range");
+  WeightTally* d = nullptr;
+  F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(WeightTally)));
+  F3D_HIP(hipMemsetAsync(d, 0, sizeof(WeightTally), f3d::stream()));
+  hipLaunchKernelGGL(k_selftest_weights, dim3(256 * 16), dim3(256), 0, f3d::stream(), lo_bits, hi_bits, d);
+  WeightTally h;
+  F3D_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, f3d::stream()));
+  F3D_HIP(hipStreamSynchronize(f3d::stream()));
+  F3D_HIP(hipFree(d));
+  if (checked) *checked = h.checked;
+  if (excluded) *excluded = h.excluded;
+  if (mismatches) *mismatches = h.mismatches;
+  if (first_mismatch) *first_mismatch = h.mismatches ? h.first[0] : 0u;
+  return 0;
+}
+
 int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, size_t height, size_t depth, float hx, float hy,
                           float hz, f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, const f3d_slab* slab)
 {

@@ -168,10 +168,43 @@ struct CarryP {  // PAIR_SP: what phi/ksi of a voxel reuses from its sweep
   float D[9];  // U[x+1]-U[x-1], U[y+1]-U[y-1], U[z+1]-U[z-1], then V, W: the first operation of the nine flow derivatives
 };
 
+// ---- the weights 1 / (2 sqrt(a)) without the IEEE square root and division sequences ----------------------------------------
+// The reference's phi = 1.f / (2.f * sqrtf(a)) (solve_3d.cu:203-204, 259-260) costs two of the longest sequences the compiler
+// emits: a correctly rounded square root (v_sqrt_f32 and two fused corrections with their selects and range scaling, ~17 issue
+// slots) and a correctly rounded division (v_div_scale x 2, v_rcp_f32, five fused multiply-adds, v_div_fmas, v_div_fixup, ~14).
+// It is a function of ONE binary32 argument, so another way to the same float can be checked against it for every argument
+// there is -- not by sampling.  weight_fast():
+//     y = v_rsq_f32(a); h = y / 2; s0 = a y; s = fma(fma(-s0, s0, a), h, s0)      s = RN(sqrt(a))
+//     t = s + s;                   r = fma(fma(-t, h, 1), h, h)                    r = RN(1 / t)
+// (explicit v_fma_f32: single correctly rounded operations, so the result is a deterministic function of the bits of a on this
+// chip).  tools/lab/phi_exact_lab and, in the test suite, f3d_selftest_weights sweep all 1 677 721 601 arguments in
+// [2^-100, 2^100]: s equals sqrtf(a) everywhere, and r equals the IEEE chain except where the significand of s is all ones (two
+// arguments per binade: the one case in which the fused correction of a reciprocal lands on a tie).  weight_fast_ok() excludes those and
+// everything outside the range (zero, subnormal, negative, infinite, NaN) with integer compares; a wave with such a lane that counts
+// takes the IEEE sequences for all its lanes.  11 issue slots + 4 for the guard instead of ~32 per weight.
+constexpr unsigned kWeightLo = 0x0d800000u, kWeightHi = 0x71800000u;   // 2^-100 .. 2^100
+__device__ __forceinline__ float weight_fast(float a, float& s_out)
+{
+  const float y = __builtin_amdgcn_rsqf(a);
+  const float h = 0.5f * y;
+  const float s0 = a * y;
+  const float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, a), h, s0);
+  s_out = s;
+  const float t = s + s;
+  return __builtin_fmaf(__builtin_fmaf(-t, h, 1.f), h, h);
+}
+__device__ __forceinline__ bool weight_fast_ok(float a, float s)
+{
+  return (__float_as_uint(a) - kWeightLo) <= (kWeightHi - kWeightLo) && (__float_as_uint(s) & 0x7fffffu) != 0x7fffffu;
+}
+__device__ __forceinline__ float weight_ieee(float a) { return 1.f / (2.f * sqrtf(a)); }
+
 // A.3 for one voxel from the increments after the sweep: n?.{u,v,w} = dU, dV, dW of the six neighbours
+// counts: the lane's result is stored (lanes beyond the volume hold padding: they must not send the wave down the slow roads)
 __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, const S3& xp, const S3& ym, const S3& yp,
                                                const S3& zm, const S3& zp, float du, float dv_c, float dw,
-                                               const SolveDivs& dv, float eps_s2, float eps_d2, float& phi, float& ksi)
+                                               const SolveDivs& dv, float eps_s2, float eps_d2, float& phi, float& ksi,
+                                               bool counts = true, bool fast_weights = true)
 {
   float q[9] = {k.D[0] + xp.u - xm.u, k.D[1] + yp.u - ym.u, k.D[2] + zp.u - zm.u,
                 k.D[3] + xp.v - xm.v, k.D[4] + yp.v - ym.v, k.D[5] + zp.v - zm.v,
@@ -192,8 +225,7 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
     }
   }
   const float dux = q[0], duy = q[1], duz = q[2], dvx = q[3], dvy = q[4], dvz = q[5], dwx = q[6], dwy = q[7], dwz = q[8];
-  phi = 1.f / (2.f * sqrtf(dux * dux + duy * duy + duz * duz + dvx * dvx + dvy * dvy + dvz * dvz + dwx * dwx +
-                           dwy * dwy + dwz * dwz + eps_s2));
+  const float a_phi = dux * dux + duy * duy + duz * duz + dvx * dvx + dvy * dvy + dvz * dvz + dwx * dwx + dwy * dwy + dwz * dwz + eps_s2;
   const float fx = k.fx, fy = k.fy, fz = k.fz, ft = k.ft;
   const float J11 = fx * fx, J22 = fy * fy, J33 = fz * fz;
   const float J12 = fx * fy, J13 = fx * fz, J23 = fy * fz;
@@ -201,7 +233,17 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
   float s = (J11 * du + J12 * dv_c + J13 * dw + J14) * du + (J12 * du + J22 * dv_c + J23 * dw + J24) * dv_c +
             (J13 * du + J23 * dv_c + J33 * dw + J34) * dw + (J14 * du + J24 * dv_c + J34 * dw + J44);
   s = static_cast<float>(s > 0) * s;
-  ksi = 1.f / (2.f * sqrtf(s + eps_d2));
+  const float a_ksi = s + eps_d2;
+  float s_phi, s_ksi;
+  const float w_phi = weight_fast(a_phi, s_phi), w_ksi = weight_fast(a_ksi, s_ksi);
+  const bool lane_ok = !counts || (weight_fast_ok(a_phi, s_phi) && weight_fast_ok(a_ksi, s_ksi));
+  if (__builtin_expect(fast_weights && __builtin_amdgcn_ballot_w64(!lane_ok) == 0, 1)) {
+    phi = w_phi;
+    ksi = w_ksi;
+  } else {
+    phi = weight_ieee(a_phi);
+    ksi = weight_ieee(a_ksi);
+  }
 }
 
 // ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
@@ -631,7 +673,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         sweep_stage2(kC, xm, xp, YM ? zm : ym, YM ? zp : yp, YM ? ym : zm, YM ? yp : zp, hC_dv, hC_dw, o0, o1, o2);
       else
         phi_ksi_stage2(pC, xm, xp, YM ? zm : ym, YM ? zp : yp, YM ? ym : zm, YM ? yp : zp, hC.u, hC.v, hC.w, sdivs, a.eps_s2,
-                       a.eps_d2, o0, o1);
+                       a.eps_d2, o0, o1, owner, a.plain_division == 0);
     }
     asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(sN.u), "v"(sN.v), "v"(sN.w));
     hM = hC;

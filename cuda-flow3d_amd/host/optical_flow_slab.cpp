@@ -87,7 +87,125 @@ void OpticalFlowSlab::Destroy()
   if (stage_send_) f3d_free(stage_send_);
   if (stage_recv_) f3d_free(stage_recv_);
   stage_send_ = stage_recv_ = 0;
+  if (f1_wide_) f3d_free(f1_wide_);
+  f1_wide_ = 0;
+  wide_planes_ = 0;
   initialized_ = false;
+}
+
+// ---- warp reach beyond the halo room ------------------------------------------------------------------------------------------
+// The wide buffers hold, per local rank, planes [own.lo - need, own.lo - need + wide_planes_) of ONE field of the level, laid out
+// like a local container (same pitch and height, only deeper).
+bool OpticalFlowSlab::GatherPlanes(int depth, size_t width, size_t height, Role src_role, int need)
+{
+  const size_t plane_bytes = local_container_.pitch * local_container_.height;
+  auto wide_of = [&](size_t local_index) { return f1_wide_ + static_cast<DevicePtr>(local_index * wide_planes_ * plane_bytes); };
+  // pack / unpack / plane copies check their plane numbers against the current container: make it as deep as the deeper of the two
+  f3d_size4 deep = {local_container_.width, local_container_.height, std::max(local_container_.depth, wide_planes_), local_container_.pitch};
+  f3d_size4 normal = {local_container_.width, local_container_.height, local_container_.depth, local_container_.pitch};
+  if (!Check(f3d_set_container(&deep))) return false;
+  bool ok = true;
+  for (size_t i = 0; ok && i < locals_.size(); ++i) {  // own planes: local container -> wide buffer
+    const PlaneRange own = OwnedPlanes(depth, locals_[i].rank, n_ranks_);
+    if (own.empty()) continue;
+    ok = Check(f3d_copy_planes(wide_of(i), need, locals_[i].buf[src_role], halo_, own.size(), width, height));
+  }
+  if (ok && locals_.size() > 1) {  // every rank lives here
+    for (size_t i = 0; ok && i < locals_.size(); ++i) {
+      const Local& me = locals_[i];
+      const int wide_base = OwnedPlanes(depth, me.rank, n_ranks_).lo - need;
+      for (const HaloTransfer& t : PlanHaloExchange(depth, me.rank, n_ranks_, need, need)) {
+        if (t.recv.empty()) continue;
+        const Local& peer = locals_[t.peer];
+        ok = Check(f3d_copy_planes(wide_of(i), t.recv.lo - wide_base, peer.buf[src_role], t.recv.lo - ZBase(depth, peer.rank), t.recv.size(),
+                                   width, height));
+        if (!ok) break;
+      }
+    }
+  } else if (ok && n_ranks_ > 1) {  // one rank per process: pack own planes, grouped send / recv, unpack into the wide buffer
+    const size_t plane = width * height;
+    Local& me = locals_[0];
+    const int my_base = ZBase(depth, me.rank);
+    const int wide_base = OwnedPlanes(depth, me.rank, n_ranks_).lo - need;
+    std::vector<size_t> s_off, s_cnt, r_off, r_cnt;
+    std::vector<int> peers;
+    size_t s_pos = 0, r_pos = 0;
+    struct Seg { int plane, count; size_t off; };
+    std::vector<Seg> packs, unpacks;
+    for (const HaloTransfer& t : PlanHaloExchange(depth, me.rank, n_ranks_, need, need)) {
+      peers.push_back(t.peer);
+      s_off.push_back(s_pos);
+      r_off.push_back(r_pos);
+      if (!t.send.empty()) {
+        packs.push_back({t.send.lo - my_base, t.send.size(), s_pos});
+        s_pos += static_cast<size_t>(t.send.size()) * plane;
+      }
+      if (!t.recv.empty()) {
+        unpacks.push_back({t.recv.lo - wide_base, t.recv.size(), r_pos});
+        r_pos += static_cast<size_t>(t.recv.size()) * plane;
+      }
+      s_cnt.push_back(s_pos - s_off.back());
+      r_cnt.push_back(r_pos - r_off.back());
+    }
+    if (s_pos > stage_floats_ || r_pos > stage_floats_) {
+      std::printf("'%s': staging buffer too small to gather %d planes of frame 1 on either side.\n", GetName(), need);
+      failed_ = true;
+      ok = false;
+    }
+    for (size_t k = 0; ok && k < packs.size(); ++k)
+      ok = Check(f3d_pack_planes(me.buf[src_role], packs[k].plane, packs[k].count, width, height, stage_send_, packs[k].off));
+    ok = ok && Check(f3d_comm_sendrecv(stage_send_, s_off.data(), s_cnt.data(), stage_recv_, r_off.data(), r_cnt.data(), peers.data(),
+                                       static_cast<int>(peers.size())));
+    for (size_t k = 0; ok && k < unpacks.size(); ++k)
+      ok = Check(f3d_unpack_planes(wide_of(0), unpacks[k].plane, unpacks[k].count, width, height, stage_recv_, unpacks[k].off));
+  }
+  return Check(f3d_set_container(&normal)) && ok;
+}
+
+bool OpticalFlowSlab::WarpWithGatheredFrame(int D, size_t W, size_t H, float hx, float hy, float hz, int wide, int need)
+{
+  int max_slab = 0;
+  for (int r = 0; r < n_ranks_; ++r) max_slab = std::max(max_slab, OwnedPlanes(D, r, n_ranks_).size());
+  const size_t planes = static_cast<size_t>(max_slab) + 2 * static_cast<size_t>(need);
+  const size_t plane_bytes = local_container_.pitch * local_container_.height;
+  if (planes > wide_planes_) {  // grows with the largest reach seen; released in Destroy()
+    if (f1_wide_) f3d_free(f1_wide_);
+    f1_wide_ = 0;
+    wide_planes_ = 0;
+    size_t pitch = 0;
+    if (!Check(f3d_alloc_pitched(&f1_wide_, &pitch, local_container_.width * sizeof(float), local_container_.height * planes * locals_.size())) ||
+        pitch != local_container_.pitch) {
+      std::printf("'%s': no room for %zu planes of frame 1 (warp reach %d beyond the halo capacity %d).\n", GetName(), planes, need - wide,
+                  halo_);
+      failed_ = true;
+      return false;
+    }
+    wide_planes_ = planes;
+  }
+  if (!GatherPlanes(D, W, H, F1R, need)) return false;
+  // the warp on the wide container: frame 1 from it, the other operands through pointers that make THEIR first plane
+  // (own.lo - halo_) appear at the plane number it has in the wide geometry (whose first plane is own.lo - need)
+  f3d_size4 deep = {local_container_.width, local_container_.height, wide_planes_, local_container_.pitch};
+  f3d_size4 normal = {local_container_.width, local_container_.height, local_container_.depth, local_container_.pitch};
+  if (!Check(f3d_set_container(&deep))) return false;
+  bool ok = true;
+  // (need may be smaller than halo_ on a level shallower than the reach: the shift is then negative; two's complement does it)
+  const DevicePtr shift = static_cast<DevicePtr>(static_cast<long long>(need - halo_) * static_cast<long long>(plane_bytes));
+  for (size_t i = 0; ok && i < locals_.size(); ++i) {
+    Local& l = locals_[i];
+    const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+    if (own.empty()) continue;
+    f3d_slab win;
+    win.z_base = own.lo - need;
+    win.z_lo = std::max(0, own.lo - wide);
+    win.z_hi = std::min(D, own.hi + wide);
+    const DevicePtr f1 = f1_wide_ + static_cast<DevicePtr>(i * wide_planes_ * plane_bytes);
+    ok = Check(f3d_warp(l.buf[F0R] - shift, f1, l.buf[FU] - shift, l.buf[FV] - shift, l.buf[FW] - shift, W, H, D, hx, hy, hz,
+                        l.buf[TMP] - shift, &win));
+    if (ok) std::swap(l.buf[F1R], l.buf[TMP]);
+  }
+  ++wide_warps_;
+  return Check(f3d_set_container(&normal)) && ok;
 }
 
 f3d_slab OpticalFlowSlab::Window(int depth, int rank, int grow_lo, int grow_hi) const
@@ -423,6 +541,7 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
 {
   overlapped_iterations_ = 0;
   batched_exchanges_ = 0;
+  wide_warps_ = 0;
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
   GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
@@ -590,13 +709,17 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     }
     const int wide = n_ex * (K + 1);
     if (!Exchange(D, W, H, {FU, FV, FW, F0R}, wide, wide)) return false;
-    if (!Exchange(D, W, H, {F1R}, wide + reach, wide + reach)) return false;
-
-    // warp on the widened slab
-    for (Local& l : locals_) {
-      const f3d_slab win = Window(D, l.rank, wide, wide);
-      if (!Check(f3d_warp(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], W, H, D, hx, hy, hz, l.buf[TMP], &win))) return false;
-      std::swap(l.buf[F1R], l.buf[TMP]);
+    if (n_ranks_ > 1 && wide + reach > halo_) {
+      // the flow reaches further along z than the local containers have room for: frame 1 goes through a container of its own
+      if (!WarpWithGatheredFrame(D, W, H, hx, hy, hz, wide, std::min(D, wide + reach))) return false;
+    } else {
+      if (!Exchange(D, W, H, {F1R}, wide + reach, wide + reach)) return false;
+      // warp on the widened slab
+      for (Local& l : locals_) {
+        const f3d_slab win = Window(D, l.rank, wide, wide);
+        if (!Check(f3d_warp(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], W, H, D, hx, hy, hz, l.buf[TMP], &win))) return false;
+        std::swap(l.buf[F1R], l.buf[TMP]);
+      }
     }
 
     // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per n_ex outer iterations

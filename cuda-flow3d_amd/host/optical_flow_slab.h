@@ -82,6 +82,19 @@ class OpticalFlowSlab : public OpticalFlowBase {
   bool SweepAndNextWeights(Local& l, const Role (&in)[3], const Role (&out)[3], int sweep_lo, int sweep_hi, int D, size_t W, size_t H,
                            float hx, float hy, float hz, float equation_alpha, float equation_smoothness, float equation_data,
                            bool& launched);
+  // Warp whose z reach does not fit the halo room of the local containers ("fallback: gather f1_res"; the reference's
+  // dead GPU warp asked for max_mag planes the same way, optical_flow_p.cpp:206, cuda_operation_register_p.cpp:165-179): frame 1 of
+  // the level is gathered into a container of its own that holds the slab plus `need` planes on either side -- from as many ranks
+  // as that takes (PlanHaloExchange is multi-hop) --, the warp runs on that container with the other operands' pointers rebased to
+  // its first plane, and the result lands in TMP as usual.
+  bool WarpWithGatheredFrame(int D, size_t W, size_t H, float hx, float hy, float hz, int wide, int need);
+  bool GatherPlanes(int depth, size_t width, size_t height, Role src_role, int need);
+  DevicePtr f1_wide_ = 0;          // per process: one buffer per local rank, each wide_planes_ deep
+  size_t wide_planes_ = 0;
+  size_t wide_warps_ = 0;          // levels of the last solve that took this road
+ public:
+  size_t GatheredWarps() const { return wide_warps_; }
+ private:
   bool fused_weights_ = true;  // F3D_SLAB_FUSED_PHI_KSI=0 turns the fused last sweep off
   bool Check(int status);
 

@@ -247,6 +247,15 @@ int f3d_conv_slices(f3d_devptr dst, f3d_devptr src, size_t width, size_t height,
 int f3d_conv_rows_cols(f3d_devptr dst, f3d_devptr src, size_t width, size_t height, size_t depth, size_t kernel_radius,
                        const f3d_slab* slab);
 
+/* Self-test (no reference counterpart): the fused sweep + phi/ksi kernel forms the weights 1 / (2 sqrt(a)) of
+ * src/kernels/solve_3d.cu:203-204,259-260 by a shorter instruction sequence that has been checked against the IEEE square root and
+ * division for EVERY argument it is used on.  This entry point repeats that check on the device it runs on: all bit patterns in
+ * [lo_bits, hi_bits] (as floats), `excluded` = arguments the kernel sends down the IEEE road instead (outside 2^-100 .. 2^100, or
+ * a root with an all-ones significand), `checked` = the rest, `mismatches` = how many of those differ from the IEEE chain (0 on
+ * gfx950), first_mismatch = one such bit pattern.  tests/test_gpu_kernels.py sweeps the whole binary32 range. */
+int f3d_selftest_weights(unsigned lo_bits, unsigned hi_bits, unsigned long long* checked, unsigned long long* excluded,
+                         unsigned long long* mismatches, unsigned* first_mismatch);
+
 /* ---- profiler ranges (no reference counterpart; SURVEY.md section 5 "tracing") ---------------------------------
  * roctx ranges around operators and pyramid levels so that rocprofv3 --marker-trace attributes kernels to them.
  * librocprofiler-sdk-roctx is dlopen'ed on the first push and only when F3D_ROCTX=1 is set or a rocprofiler tool library

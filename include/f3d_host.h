@@ -164,6 +164,9 @@ int f3d_slabflow_overlapped_iterations(f3d_slabflow flow, size_t* count);
 /* groups of several outer iterations the last compute ran between two exchanges (thin slabs of small levels take
  * n (K + 1) halo planes at once; F3D_SLAB_OUTER_PER_EXCHANGE=n forces n, 1 = one exchange per outer iteration) */
 int f3d_slabflow_batched_exchanges(f3d_slabflow flow, size_t* count);
+/* pyramid levels of the last compute whose warp reached further along z than the halo room of the local containers: frame 1 was
+ * gathered into a container of its own from as many ranks as the reach spans (SURVEY.md 8e fallback) */
+int f3d_slabflow_gathered_warps(f3d_slabflow flow, size_t* count);
 int f3d_slabflow_destroy(f3d_slabflow flow);
 
 /* the decomposition plan (pure host arithmetic, usable without a device) */

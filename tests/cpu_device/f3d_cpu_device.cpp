@@ -442,6 +442,14 @@ int f3d_prof_select(unsigned) { return 0; }
 int f3d_prof_read(int, size_t, double* ms, uint64_t* n, double* vox) { *ms = 0; *n = 0; *vox = 0; return 0; }
 
 int f3d_crash_maps_enable(const char*) { return 0; }
+int f3d_selftest_weights(unsigned, unsigned, unsigned long long* checked, unsigned long long* excluded, unsigned long long* mismatches, unsigned* first)
+{
+  if (checked) *checked = 0;   // the host-memory backend computes the weights with the IEEE expression itself: nothing to check
+  if (excluded) *excluded = 0;
+  if (mismatches) *mismatches = 0;
+  if (first) *first = 0;
+  return 0;
+}
 int f3d_comm_unique_id(void* id128) { std::memset(id128, 0, 128); return 0; }
 int f3d_comm_init(const void*, int rank, int n_ranks) { return (rank == 0 && n_ranks == 1) ? 0 : fail("the host-memory backend serves one rank"); }
 int f3d_comm_destroy(void) { return 0; }

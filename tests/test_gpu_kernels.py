@@ -790,3 +790,18 @@ def test_fused_launches_on_thin_volumes_march_along_y(f3d, oracle, dims, cdims, 
                 f"sweep + phi/ksi, {name}: {np.count_nonzero(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))} voxels differ"
     finally:
         dev.close()
+
+
+def test_the_short_road_to_the_weights_is_exact_for_every_float(f3d):
+    """phi = 1 / (2 sqrt(a)) by v_rsq_f32 and four fused multiply-adds (csrc/f3d_solve_pair8.h, weight_fast) against the IEEE
+    square root and division the reference's expression compiles to, for ALL 2^32 bit patterns: wherever the kernel's guard
+    (weight_fast_ok) lets the short road through, the bits are those of the IEEE chain.  The guard passes the whole range
+    2^-100 .. 2^100 except the two arguments per binade whose root has an all-ones significand."""
+    hip = f3d.hip()
+    checked, excluded, bad = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+    first = C.c_uint()
+    f3d.check(hip.f3d_selftest_weights(0, 0xFFFFFFFF, C.byref(checked), C.byref(excluded), C.byref(bad), C.byref(first)))
+    assert bad.value == 0, f"{bad.value} arguments differ from the IEEE chain, e.g. bits 0x{first.value:08x}"
+    in_range = 0x71800000 - 0x0d800000 + 1
+    assert checked.value + excluded.value == 2 ** 32
+    assert checked.value == in_range - 200, (checked.value, in_range)    # 100 binades x 2 all-ones roots are left to the IEEE road

@@ -154,3 +154,25 @@ def test_exchange_legs_pack_rccl_self_unpack(f3d, split):
     for p in (stage_s.value, stage_r.value):
         f3d.check(hip.f3d_free(p))
     box.free()
+
+
+@pytest.mark.parametrize("n_ranks,halo", [(4, 16), (8, 16), (8, 8)])
+def test_warp_reach_beyond_the_halo_room_gathers_frame_1(f3d, n_ranks, halo):
+    """A pair that moves ~10 planes along z on slabs of 16 or 8 planes: the warp of the fine levels reads frame 1 further away than
+    the local containers have halo room (and, with 8 ranks, beyond the neighbouring slab).  The driver gathers frame 1 into a
+    container of its own from every rank the reach spans and warps from there (SURVEY 8e fallback; it used to stop with "raise
+    halo_capacity"): the single-GPU bits."""
+    f0, _ = f3d.synth_pair(48, 40, 64)
+    f1 = np.ascontiguousarray(np.roll(f0, 10, axis=0))
+    kw = dict(outer_iterations_count=6)
+    exp = single(f3d, f0, f1, **kw)
+    assert np.abs(exp[2]).max() > 8.0, f"the solver recovered only |w| <= {np.abs(exp[2]).max():.2f}: the case does not test the reach"
+    d, h, w = f0.shape
+    flow = f3d.SlabOpticalFlow(n_ranks, list(range(n_ranks)), halo_capacity=halo)
+    flow.initialize(w, h, d)
+    got = flow.compute(f0, f1, **kw)
+    gathered = flow.gathered_warps()
+    flow.destroy()
+    assert gathered >= 1
+    for g, e, n in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} slabs, halo {halo}: component {n} differs, max {np.abs(g - e).max():.3e}"

@@ -58,6 +58,22 @@ CASE = textwrap.dedent('''
         except pkg.F3dError:
             pass
         bad.destroy()
+    elif what == "gather":
+        # a pair that moves by ~7 planes along z: with 4 slabs of 8-10 planes and 8 planes of halo room the warp needs frame 1 from
+        # ranks beyond the neighbour -- the driver gathers it into a container of its own instead of giving up (SURVEY 8e fallback)
+        W2, H2, D2 = 24, 20, 40
+        g0, _ = pkg.synth_pair(W2, H2, D2)
+        g1 = np.ascontiguousarray(np.roll(g0, 7, axis=0))
+        kw3 = dict(warp_levels_count=12, outer_iterations_count=3, inner_iterations_count=5)
+        (xu, xv, xw), _ = orc.compute_flow(g0, g1, **kw3)
+        assert np.abs(xw).max() > 0.5, np.abs(xw).max()
+        # halo room 7 = the K + 1 = 6 planes of the widened sweeps + 1: any z motion makes the warp reach beyond it, and on the
+        # coarse levels (slabs of 5-6 planes) the gathered planes come from ranks beyond the neighbour
+        for ranks, halo in ((4, 7), (3, 7)):
+            flow = pkg.SlabOpticalFlow(ranks, list(range(ranks)), halo_capacity=halo); flow.initialize(W2, H2, D2)
+            got = flow.compute(g0, g1, **kw3); gathered = flow.gathered_warps(); flow.destroy()
+            assert gathered >= 1, "the reach never exceeded the halo room: the case does not test the gather"
+            assert all(same(g, e) for g, e in zip(got, (xu, xv, xw))), f"{ranks} slabs with a gathered frame differ from the oracle"
     elif what == "piecemeal":
         os.environ["F3D_P_BUDGET_MB"] = "1.3"             # the finest levels go through the "device" in chunks
         flow = pkg.PiecemealOpticalFlow(); flow.initialize(W, H, D); flow.set_full_pipeline(True)
@@ -120,11 +136,11 @@ def run_case(what, libdir, sanitized):
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather"])
 def test_host_drivers_equal_the_oracle_on_the_cpu_backend(what):
     run_case(what, build("all"), sanitized=False)
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather"])
 def test_host_drivers_are_clean_under_asan_and_ubsan(what):
     run_case(what, build("asan"), sanitized=True)
