@@ -138,11 +138,19 @@ def hip():
         "f3d_comm_allreduce_max_f32": [_fp],
     }
     for name, args in sig.items():
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            # an older build named by F3D_LIBDIR (A/B timing of two libraries in one GPU call) may lack the newest entry points;
+            # the library of the package itself must export every one of them
+            if os.environ.get("F3D_LIBDIR"):
+                continue
+            raise
         fn.argtypes = args
         fn.restype = C.c_int
     _hip = L
-    _arm_crash_maps(L)
+    if hasattr(L, "f3d_crash_maps_enable"):
+        _arm_crash_maps(L)
     return L
 
 
@@ -197,6 +205,7 @@ def host():
         "f3d_slabflow_overlapped_iterations": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_batched_exchanges": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_gathered_warps": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_slabflow_stage_exchanges": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_destroy": [C.c_void_p],
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
@@ -815,6 +824,12 @@ class SlabOpticalFlow:
     def overlapped_iterations(self):
         n = _sz()
         check(host().f3d_slabflow_overlapped_iterations(self._h, C.byref(n)))
+        return n.value
+
+    def stage_exchanges(self):
+        """exchanges of the last compute made after a solver stage (F3D_SLAB_EXCHANGE=stage)"""
+        n = _sz()
+        check(host().f3d_slabflow_stage_exchanges(self._h, C.byref(n)))
         return n.value
 
     def gathered_warps(self):

@@ -535,6 +535,13 @@ int f3d_slabflow_batched_exchanges(f3d_slabflow flow, size_t* count)
   return 0;
 }
 
+int f3d_slabflow_stage_exchanges(f3d_slabflow flow, size_t* count)
+{
+  if (!flow || !flow->driver || !count) return 1;
+  *count = flow->driver->StageExchanges();
+  return 0;
+}
+
 int f3d_slabflow_gathered_warps(f3d_slabflow flow, size_t* count)
 {
   if (!flow || !flow->driver || !count) return 1;

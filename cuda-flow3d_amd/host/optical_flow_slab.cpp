@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <string>
 #include <utility>
 
 #include "common_utils.h"
@@ -20,6 +21,7 @@ OpticalFlowSlab::OpticalFlowSlab(int n_ranks, std::vector<int> local_ranks, int 
   if (const char* f = std::getenv("F3D_SLAB_OUTER_PER_EXCHANGE")) forced_outer_per_exchange_ = std::atoi(f);
   if (const char* f = std::getenv("F3D_SLAB_SMALL_LEVEL_VOXELS")) small_level_voxels_ = std::atof(f);
   if (const char* f = std::getenv("F3D_SLAB_FUSED_PHI_KSI")) fused_weights_ = std::atoi(f) != 0;
+  if (const char* f = std::getenv("F3D_SLAB_EXCHANGE")) exchange_per_stage_ = std::string(f) == "stage";
 }
 
 OpticalFlowSlab::~OpticalFlowSlab() { Destroy(); }
@@ -542,6 +544,7 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
   overlapped_iterations_ = 0;
   batched_exchanges_ = 0;
   wide_warps_ = 0;
+  stage_exchanges_ = 0;
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
   float warp_scale_factor, equation_alpha, equation_smoothness, equation_data, gaussian_sigma;
   GET_PARAM_OR_RETURN_VALUE(params, size_t, warp_levels_count, "warp_levels_count", false);
@@ -707,7 +710,12 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       if (forced_outer_per_exchange_ > 0)
         n_ex = std::max(1, std::min(forced_outer_per_exchange_, std::min((halo_ - reach) / (K + 1), static_cast<int>(outer_iterations_count))));
     }
-    const int wide = n_ex * (K + 1);
+    // exchange after every solver stage: the deepest stage reads p_max planes of the increments and of the weights beyond the
+    // slab, the weights p_max + 1 planes of everything else
+    const bool per_stage = exchange_per_stage_ && n_ranks_ > 1;
+    const int p_max = (FusedSweepsEnabled() && K >= 2) ? 2 : 1;
+    if (per_stage) n_ex = 1;
+    const int wide = per_stage ? p_max + 1 : n_ex * (K + 1);
     if (!Exchange(D, W, H, {FU, FV, FW, F0R}, wide, wide)) return false;
     if (n_ranks_ > 1 && wide + reach > halo_) {
       // the flow reaches further along z than the local containers have room for: frame 1 goes through a container of its own
@@ -731,9 +739,54 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     // Overlapped order: one rank per process, a slab thick enough that zones and interior are distinct, and an exchange
     // to hide (not after the last outer iteration)
     const PlaneRange own_here = OwnedPlanes(D, locals_[0].rank, n_ranks_);
-    const bool can_overlap = n_ex == 1 && locals_.size() == 1 && n_ranks_ > 1 && overlap_min_planes_ > 0 &&
+    const bool can_overlap = !per_stage && n_ex == 1 && locals_.size() == 1 && n_ranks_ > 1 && overlap_min_planes_ > 0 &&
                              own_here.size() >= std::max(overlap_min_planes_, 4 * K + 4) && (own_here.lo > 0 || own_here.hi < D);
-    for (size_t i = 0; i < outer_iterations_count;) {
+    for (size_t i = 0; per_stage && i < outer_iterations_count; ++i) {
+      // ---- one exchange per solver stage (F3D_SLAB_EXCHANGE=stage): every launch on the slab itself ----
+      struct Stage { bool pair; };
+      std::vector<Stage> stages;
+      for (int s = 0; s < K;) {
+        const bool pair = FusedSweepsEnabled() && s + 2 <= K;
+        stages.push_back({pair});
+        s += pair ? 2 : 1;
+      }
+      const bool more = i + 1 < outer_iterations_count;
+      for (Local& l : locals_) {
+        const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+        if (own.empty()) continue;
+        if (!CompleteWeights(l, own.lo - p_max, own.hi + p_max, D, W, H, hx, hy, hz, equation_smoothness, equation_data)) return false;
+      }
+      for (size_t st = 0; st < stages.size(); ++st) {
+        const bool last = st + 1 == stages.size();
+        for (Local& l : locals_) {
+          const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+          if (own.empty()) continue;
+          const f3d_slab sw = Window(D, l.rank, 0, 0);
+          bool launched = false;
+          if (last && !stages[st].pair && more && fused_weights_ && FusedSweepsEnabled() && FusedPhiKsiEnabled()) {
+            if (!SweepAndNextWeights(l, {DU, DV, DW}, {TDU, TDV, TDW}, sw.z_lo, sw.z_hi, D, W, H, hx, hy, hz, equation_alpha,
+                                     equation_smoothness, equation_data, launched))
+              return false;
+          }
+          if (!launched) {
+            auto* fn = stages[st].pair ? f3d_solve_sweep2 : f3d_solve_sweep;
+            if (!Check(fn(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], l.buf[PHI], l.buf[KSI],
+                          W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV], l.buf[TDW], &sw)))
+              return false;
+          }
+          std::swap(l.buf[DU], l.buf[TDU]);
+          std::swap(l.buf[DV], l.buf[TDV]);
+          std::swap(l.buf[DW], l.buf[TDW]);
+        }
+        // as deep as what comes next reads: the sweeps of the next stage, or the weights of the next outer iteration
+        const int next = !last ? (stages[st + 1].pair ? 2 : 1) : (more ? p_max + 1 : 0);
+        if (next > 0) {
+          if (!Exchange(D, W, H, {DU, DV, DW}, next, next)) return false;
+          ++stage_exchanges_;
+        }
+      }
+    }
+    for (size_t i = per_stage ? outer_iterations_count : 0; i < outer_iterations_count;) {
       if (can_overlap && i + 1 < outer_iterations_count) {
         if (!SweepsOverlapped(locals_[0], D, W, H, K, hx, hy, hz, equation_alpha, equation_smoothness, equation_data)) return false;
         ++overlapped_iterations_;

@@ -94,7 +94,16 @@ class OpticalFlowSlab : public OpticalFlowBase {
   size_t wide_warps_ = 0;          // levels of the last solve that took this road
  public:
   size_t GatheredWarps() const { return wide_warps_; }
+  // exchanges of the last solve made after a solver STAGE (a fused pair or a single sweep) rather than once per outer iteration
+  size_t StageExchanges() const { return stage_exchanges_; }
  private:
+  // F3D_SLAB_EXCHANGE=stage: exchange the increments after every solver stage, as deep as the next stage reads (2 planes before a
+  // fused pair, 1 before a single sweep, 3 before the next weights), instead of K + 1 = 6 planes once per outer iteration with the
+  // sweeps on windows widened by up to K - 1 planes.  The same bytes travel in three messages instead of one; the redundant
+  // planes drop from 20 sweep-planes + 10 weight-planes per outer iteration and rank to 4 + 4.  Which order wins depends on what an
+  // exchange costs on the machine, hence a switch ("outer" = default) for the first run on a multi-GPU node to settle.
+  bool exchange_per_stage_ = false;
+  size_t stage_exchanges_ = 0;
   bool fused_weights_ = true;  // F3D_SLAB_FUSED_PHI_KSI=0 turns the fused last sweep off
   bool Check(int status);
 

@@ -167,6 +167,9 @@ int f3d_slabflow_batched_exchanges(f3d_slabflow flow, size_t* count);
 /* pyramid levels of the last compute whose warp reached further along z than the halo room of the local containers: frame 1 was
  * gathered into a container of its own from as many ranks as the reach spans (SURVEY.md 8e fallback) */
 int f3d_slabflow_gathered_warps(f3d_slabflow flow, size_t* count);
+/* exchanges of the last compute made after a solver stage (F3D_SLAB_EXCHANGE=stage: 2 / 1 / 3 planes after the fused pairs and the
+ * last sweep instead of 6 planes once per outer iteration; same bits, fewer redundant planes, three times the messages) */
+int f3d_slabflow_stage_exchanges(f3d_slabflow flow, size_t* count);
 int f3d_slabflow_destroy(f3d_slabflow flow);
 
 /* the decomposition plan (pure host arithmetic, usable without a device) */

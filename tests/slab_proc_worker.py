@@ -20,11 +20,15 @@ for a in sys.argv[8:]:
 f3d = importlib.import_module("cuda-flow3d_amd")
 f3d.comm_init(("f3dshm:" + session).encode(), rank, n, device=0)
 f0, f1 = f3d.synth_pair(W, H, D)
+roll = int(os.environ.get("F3D_TEST_ROLL", "0"))   # frame 1 = frame 0 moved by this many planes along z (warp reach tests)
+if roll:
+    f1 = np.ascontiguousarray(np.roll(f0, roll, axis=0))
 flow = f3d.SlabOpticalFlow(n, [rank], halo_capacity=int(os.environ.get("F3D_TEST_HALO_CAPACITY", "16")))
 flow.initialize(W, H, D)
 u, v, w = flow.compute(f0, f1, **kw)      # every rank fills the planes it owns, the rest stays zero
 overlapped = flow.overlapped_iterations()
 batched = flow.batched_exchanges()
+gathered = flow.gathered_warps()
 flow.destroy()
 f3d.comm_destroy()
-np.savez(out, u=u, v=v, w=w, overlapped=overlapped, batched=batched)
+np.savez(out, u=u, v=v, w=w, overlapped=overlapped, batched=batched, gathered=gathered)

@@ -176,3 +176,23 @@ def test_warp_reach_beyond_the_halo_room_gathers_frame_1(f3d, n_ranks, halo):
     assert gathered >= 1
     for g, e, n in zip(got, exp, "uvw"):
         assert same(g, e), f"{n_ranks} slabs, halo {halo}: component {n} differs, max {np.abs(g - e).max():.3e}"
+
+
+@pytest.mark.parametrize("n_ranks,dims", [(2, (48, 40, 44)), (4, (44, 36, 50)), (8, (40, 36, 64))])
+def test_exchange_after_every_solver_stage(f3d, monkeypatch, n_ranks, dims):
+    """F3D_SLAB_EXCHANGE=stage: the increments travel after every fused pair / last sweep, as deep as the next stage reads (2, 1, 3
+    planes), and every launch runs on the slab itself instead of on windows widened by up to four planes.  The other order of the
+    same arithmetic: single-GPU bits, on thick and on thin slabs (8 ranks: slabs thinner than the halo on the coarse levels)."""
+    monkeypatch.setenv("F3D_SLAB_EXCHANGE", "stage")
+    f0, f1 = f3d.synth_pair(*dims)
+    kw = dict(warp_levels_count=12, outer_iterations_count=5)
+    exp = single(f3d, f0, f1, **kw)
+    d, h, w = f0.shape
+    flow = f3d.SlabOpticalFlow(n_ranks, list(range(n_ranks)), halo_capacity=16)
+    flow.initialize(w, h, d)
+    got = flow.compute(f0, f1, **kw)
+    n_stage = flow.stage_exchanges()
+    flow.destroy()
+    assert n_stage == 12 * (5 * 3 - 1), n_stage
+    for g, e, n in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} slabs exchanging per stage: component {n} differs, max {np.abs(g - e).max():.3e}"

@@ -39,6 +39,7 @@ def run_ranks(n, dims, tmp_path, env=None, **kw):
     parts = [np.load(o) for o in outs]
     run_ranks.overlapped = [int(p["overlapped"]) for p in parts]
     run_ranks.batched = [int(p["batched"]) for p in parts]
+    run_ranks.gathered = [int(p["gathered"]) for p in parts]
     return [sum(p[c] for p in parts) for c in "uvw"]   # slabs are disjoint, the other planes are zero
 
 
@@ -95,3 +96,36 @@ def test_outer_iterations_per_exchange_across_processes(f3d, tmp_path, n_ranks, 
     assert run_ranks.batched == [expect] * n_ranks, run_ranks.batched
     for g, e, c in zip(got, exp, "uvw"):
         assert same(g, e), f"{n_ranks} processes, n = {forced}: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+def test_gathered_frame_across_processes(f3d, tmp_path):
+    """The warp reaching beyond the halo room with one rank per process: frame 1 is gathered from every rank the reach spans through
+    the transport (pack, grouped send / recv, unpack into the wide container) -- 4 processes, slabs of 10 planes and less, 7 planes
+    of halo room, a pair that moves 3 planes along z.  Same bits as one GPU, and every rank took the road."""
+    dims = (40, 36, 40)
+    kw = dict(warp_levels_count=12, outer_iterations_count=4)
+    f0, _ = f3d.synth_pair(*dims)
+    f1 = np.ascontiguousarray(np.roll(f0, 3, axis=0))
+    flow = f3d.OpticalFlow()
+    flow.initialize(*dims)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(4, dims, tmp_path, env={"F3D_TEST_HALO_CAPACITY": "7", "F3D_TEST_ROLL": "3"}, **kw)
+    assert all(c >= 1 for c in run_ranks.gathered), run_ranks.gathered
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"4 processes with a gathered frame: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+def test_exchange_after_every_solver_stage_across_processes(f3d, tmp_path):
+    """F3D_SLAB_EXCHANGE=stage with one rank per process (3 processes): pack / transfer / unpack after every solver stage"""
+    dims = (44, 36, 50)
+    kw = dict(warp_levels_count=10, outer_iterations_count=4)
+    f0, f1 = f3d.synth_pair(*dims)
+    flow = f3d.OpticalFlow()
+    flow.initialize(*dims)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(3, dims, tmp_path, env={"F3D_SLAB_EXCHANGE": "stage"}, **kw)
+    assert run_ranks.overlapped == [0, 0, 0]
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"3 processes exchanging per stage: component {c} differs, max {np.abs(g - e).max():.3e}"

@@ -51,6 +51,14 @@ CASE = textwrap.dedent('''
             flow = pkg.SlabOpticalFlow(ranks, list(range(ranks)), halo_capacity=16); flow.initialize(W, H, D)
             got = flow.compute(f0, f1, **kw); flow.destroy()
             assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), f"{ranks} slabs on the host backend differ from the oracle"
+        # one exchange per solver stage (2 / 1 / 3 planes) instead of six planes once per outer iteration: same bits
+        os.environ["F3D_SLAB_EXCHANGE"] = "stage"
+        for ranks in (2, 3, 4):
+            flow = pkg.SlabOpticalFlow(ranks, list(range(ranks)), halo_capacity=16); flow.initialize(W, H, D)
+            got = flow.compute(f0, f1, **kw); n_stage = flow.stage_exchanges(); flow.destroy()
+            assert n_stage == 5 * (3 * 3 - 1), n_stage      # 5 levels x (3 outer iterations x 3 stages, none after the last)
+            assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), f"{ranks} slabs exchanging per stage differ from the oracle"
+        del os.environ["F3D_SLAB_EXCHANGE"]
         # a rank list that is not 0 .. n-1 is refused
         bad = pkg.SlabOpticalFlow(2, [1, 0], halo_capacity=16)
         try:
