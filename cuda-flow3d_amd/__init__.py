@@ -77,6 +77,8 @@ def hip():
     sig = {
         "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_is_initialized": [], "f3d_device_count": [C.POINTER(C.c_int)],
         "f3d_crash_maps_enable": [C.c_char_p],
+        "f3d_lane_create": [C.POINTER(C.c_void_p)], "f3d_lane_make_current": [C.c_void_p], "f3d_lane_is_private": [],
+        "f3d_lane_destroy": [C.c_void_p],
         "f3d_selftest_weights": [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
                                  C.POINTER(C.c_uint)],
         "f3d_device_name": [C.c_char_p, _sz], "f3d_mem_info": [C.POINTER(_sz), C.POINTER(_sz)],
@@ -212,6 +214,7 @@ def host():
         "f3d_plan_resample_source": [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2,
         "f3d_volume_wrap": [C.POINTER(C.c_void_p), _fp, _sz, _sz, _sz], "f3d_volume_destroy": [C.c_void_p],
         "f3d_op_solve_p_last": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(C.c_int)],
+        "f3d_op_solve_p_fused_weights": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_plan_solve_piecemeal": [_sz, _sz, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5,
         "f3d_pflow_create": [C.POINTER(C.c_void_p)], "f3d_pflow_initialize": [C.c_void_p, _sz, _sz, _sz],
         "f3d_pflow_compute": [C.c_void_p, _fp, _fp, _sz, _sz, _sz, pp, C.c_int, _fp, _fp, _fp, _fp],
@@ -420,6 +423,38 @@ def sync():
     check(hip().f3d_stream_sync(), "f3d_stream_sync")
 
 
+class Lane:
+    """A stream and a container geometry of one's own (include/f3d.h, f3d_lane_*): a driver created and used between
+    make_current() and release() in ONE thread runs beside the drivers of other threads instead of in line with them.
+        with f3d.Lane():            # in a worker thread
+            flow = f3d.OpticalFlow(); flow.initialize(w, h, d); u, v, w = flow.compute(f0, f1); flow.destroy()"""
+
+    def __init__(self):
+        check(hip().f3d_init(-1), "f3d_init")
+        self._h = C.c_void_p()
+        check(hip().f3d_lane_create(C.byref(self._h)), "f3d_lane_create")
+
+    def make_current(self):
+        check(hip().f3d_lane_make_current(self._h), "f3d_lane_make_current")
+
+    def release(self):
+        hip().f3d_lane_make_current(None)
+
+    def destroy(self):
+        if self._h:
+            hip().f3d_lane_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        self.make_current()
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+        self.destroy()
+        return False
+
+
 def mem_info():
     """(free, total) bytes of device memory."""
     check(hip().f3d_init(-1), "f3d_init")
@@ -574,6 +609,12 @@ class Operation:
         check(host().f3d_op_execute(self._h, keys, ptrs, n), "f3d_op_execute")
         self.values = {k: (v.value if hasattr(v, "value") else v) for k, v in store.items()}
         return self.values
+
+    def solve_p_fused_weights(self):
+        """whether the last solve_p execute fused the last sweep of an outer iteration with the next weights"""
+        f = C.c_int()
+        check(host().f3d_op_solve_p_fused_weights(self._h, C.byref(f)), "f3d_op_solve_p_fused_weights")
+        return bool(f.value)
 
     def solve_p_last(self):
         """(chunk, outer_per_pass, halo, passes, overlapped) of the last solve_p execute"""

@@ -9,6 +9,7 @@
 #include <csignal>
 #include <fcntl.h>
 #include <map>
+#include <mutex>
 #include <unistd.h>
 #include <vector>
 
@@ -18,14 +19,23 @@ namespace {
 
 thread_local char g_error[512] = "";
 
-struct State {
-  bool ready = false;
-  int device = -1;
+// What a sequence of launches shares: the stream they are ordered on, the container geometry the kernels address with, the
+// taps of the blur.  The library has one such lane of its own (the "library stream" of include/f3d.h); a driver that wants to run
+// beside another one in the same process makes a lane of its own and binds it to its thread (f3d_lane_*).
+struct Lane {
   hipStream_t stream = nullptr;
   f3d_size4 container = {0, 0, 0, 0};
   f3d::ConvTaps taps = {{0}, 0};
+};
+struct State {
+  bool ready = false;
+  int device = -1;
+  Lane lane;   // the default lane
   hipDeviceProp_t prop;
 } S;
+thread_local Lane* t_lane = nullptr;   // the calling thread's lane; null = the default one
+inline Lane& cur() { return t_lane ? *t_lane : S.lane; }
+std::mutex g_mutex;   // allocation table and event pool: the only library state two lanes share
 
 struct ProfRec {
   int kernel;
@@ -72,14 +82,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line)
   return fail("HIP error %d (%s) in %s at %s:%d", static_cast<int>(e), hipGetErrorString(e), what, file, line);
 }
 
-hipStream_t stream() { return S.stream; }
+hipStream_t stream() { return cur().stream; }
 bool ready() { return S.ready; }
-const f3d_size4& container() { return S.container; }
-const ConvTaps& conv_taps() { return S.taps; }
+const f3d_size4& container() { return cur().container; }
+const ConvTaps& conv_taps() { return cur().taps; }
 
 bool make_geo(F3dGeo* g, size_t w, size_t h, size_t d, const f3d_slab* slab, const char* who)
 {
-  const f3d_size4& c = S.container;
+  const f3d_size4& c = cur().container;
   if (c.pitch == 0 || c.height == 0) {
     fail("%s: f3d_set_container() has not been called", who);
     return false;
@@ -118,20 +128,22 @@ bool make_geo(F3dGeo* g, size_t w, size_t h, size_t d, const f3d_slab* slab, con
 
 void prof_begin(int kernel, size_t voxels)
 {
+  if (t_lane) return;   // the event bracket belongs to the default lane (bench.py, tools/kbench.py)
   if (!P.enabled || !((P.mask >> kernel) & 1u)) return;
   hipEvent_t e = take_event();
   if (!e) return;
-  (void)hipEventRecord(e, S.stream);
+  (void)hipEventRecord(e, cur().stream);
   P.open_start[kernel] = e;
   P.open_voxels[kernel] = voxels;
 }
 
 void prof_end(int kernel)
 {
+  if (t_lane) return;
   if (!P.enabled || !P.open_start[kernel]) return;
   hipEvent_t e = take_event();
   if (!e) return;
-  (void)hipEventRecord(e, S.stream);
+  (void)hipEventRecord(e, cur().stream);
   P.pending.push_back({kernel, P.open_voxels[kernel], P.open_start[kernel], e});
   P.open_start[kernel] = nullptr;
 }
@@ -177,7 +189,7 @@ int f3d_init(int device)
     return f3d::fail("f3d_init: device %d is %s; this library carries gfx950 (MI355X) code only", device,
                      S.prop.gcnArchName);
   }
-  F3D_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  F3D_HIP(hipStreamCreateWithFlags(&S.lane.stream, hipStreamNonBlocking));
   S.device = device;
   S.ready = true;
   return 0;
@@ -186,7 +198,7 @@ int f3d_init(int device)
 int f3d_shutdown(void)
 {
   if (!S.ready) return 0;
-  (void)hipStreamSynchronize(S.stream);
+  (void)hipStreamSynchronize(S.lane.stream);
   for (auto& r : P.pending) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
@@ -194,13 +206,56 @@ int f3d_shutdown(void)
   P.pending.clear();
   for (auto e : P.pool) (void)hipEventDestroy(e);
   P.pool.clear();
-  (void)hipStreamDestroy(S.stream);
-  S.stream = nullptr;
+  (void)hipStreamDestroy(S.lane.stream);
+  S.lane.stream = nullptr;
+  t_lane = nullptr;
   S.ready = false;
   return 0;
 }
 
 int f3d_is_initialized(void) { return S.ready ? 1 : 0; }
+
+// ---- lanes: a stream and a container geometry of one's own --------------------------------------------------------------------
+struct f3d_lane_s {
+  Lane lane;
+};
+
+int f3d_lane_create(f3d_lane* lane)
+{
+  F3D_REQUIRE_READY("f3d_lane_create");
+  if (!lane) return f3d::fail("f3d_lane_create: null argument");
+  F3D_HIP(hipSetDevice(S.device));   // the device is per-thread state of the runtime: a worker thread starts on device 0
+  f3d_lane_s* l = new f3d_lane_s();
+  const hipError_t e = hipStreamCreateWithFlags(&l->lane.stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete l;
+    return f3d::hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+  }
+  *lane = l;
+  return 0;
+}
+
+int f3d_lane_make_current(f3d_lane lane)
+{
+  F3D_REQUIRE_READY("f3d_lane_make_current");
+  F3D_HIP(hipSetDevice(S.device));
+  t_lane = lane ? &lane->lane : nullptr;
+  return 0;
+}
+
+int f3d_lane_is_private(void) { return t_lane ? 1 : 0; }
+
+int f3d_lane_destroy(f3d_lane lane)
+{
+  if (!lane) return 0;
+  if (t_lane == &lane->lane) t_lane = nullptr;
+  if (S.ready && lane->lane.stream) {
+    (void)hipStreamSynchronize(lane->lane.stream);
+    (void)hipStreamDestroy(lane->lane.stream);
+  }
+  delete lane;
+  return 0;
+}
 
 namespace {
 struct Roctx {
@@ -344,9 +399,10 @@ int f3d_alloc_pitched(f3d_devptr* ptr, size_t* pitch, size_t width_bytes, size_t
     return e ? static_cast<size_t>(std::atol(e)) / 256 * 256 : static_cast<size_t>(17 * 256);
   }();
   static size_t serial = 0;
-  const size_t skew = skew_unit ? (serial++ * skew_unit) % 65536 : 0;
   void* d = nullptr;
   F3D_HIP(hipMalloc(&d, p * rows + align + (skew_unit ? 65536 : 0)));
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const size_t skew = skew_unit ? (serial++ * skew_unit) % 65536 : 0;
   char* user = static_cast<char*>(d) + skew;
   if (skew_unit) g_alloc_base[user] = d;
   *ptr = static_cast<f3d_devptr>(reinterpret_cast<uintptr_t>(user));
@@ -358,10 +414,13 @@ int f3d_free(f3d_devptr ptr)
 {
   F3D_REQUIRE_READY("f3d_free");
   void* user = f3d_ptr<void>(ptr);
-  auto it = g_alloc_base.find(user);
-  if (it != g_alloc_base.end()) {
-    user = it->second;
-    g_alloc_base.erase(it);
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_alloc_base.find(user);
+    if (it != g_alloc_base.end()) {
+      user = it->second;
+      g_alloc_base.erase(it);
+    }
   }
   F3D_HIP(hipFree(user));
   return 0;
@@ -379,12 +438,12 @@ int f3d_memset2d(f3d_devptr ptr, size_t pitch, int value, size_t width_bytes, si
     const unsigned word = b | (b << 8) | (b << 16) | (b << 24);
     const unsigned words = static_cast<unsigned>(width_bytes / 4);
     const dim3 block(256, 1, 1), grid((words + 255) / 256, static_cast<unsigned>(rows > 65535 ? 65535 : rows), 1);
-    hipLaunchKernelGGL(k_fill_rows, grid, block, 0, S.stream, f3d_ptr<unsigned>(ptr), static_cast<size_t>(pitch / 4), word, words,
+    hipLaunchKernelGGL(k_fill_rows, grid, block, 0, cur().stream, f3d_ptr<unsigned>(ptr), static_cast<size_t>(pitch / 4), word, words,
                        static_cast<unsigned>(rows));
     F3D_HIP(hipGetLastError());
     return 0;
   }
-  F3D_HIP(hipMemset2DAsync(f3d_ptr<void>(ptr), pitch, value, width_bytes, rows, S.stream));
+  F3D_HIP(hipMemset2DAsync(f3d_ptr<void>(ptr), pitch, value, width_bytes, rows, cur().stream));
   return 0;
 }
 
@@ -401,7 +460,7 @@ int copy_dense(char* dev, size_t dev_pitch, size_t dev_height, char* host, size_
   const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
   if (height == dev_height && wb == dev_pitch) {
     const size_t bytes = wb * height * depth;
-    F3D_HIP(to_device ? hipMemcpyAsync(dev, host, bytes, kind, S.stream) : hipMemcpyAsync(host, dev, bytes, kind, S.stream));
+    F3D_HIP(to_device ? hipMemcpyAsync(dev, host, bytes, kind, cur().stream) : hipMemcpyAsync(host, dev, bytes, kind, cur().stream));
     return 0;
   }
   // planes per call: whole planes, at most kRowsPerCopy rows (sub-boxes lower than the container go plane by plane)
@@ -410,8 +469,8 @@ int copy_dense(char* dev, size_t dev_pitch, size_t dev_height, char* host, size_
     const size_t n = std::min(per_call, depth - z);
     char* d = dev + z * dev_height * dev_pitch;
     char* h = host + z * height * wb;
-    if (to_device) F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, h, wb, wb, height * n, kind, S.stream));
-    else F3D_HIP(hipMemcpy2DAsync(h, wb, d, dev_pitch, wb, height * n, kind, S.stream));
+    if (to_device) F3D_HIP(hipMemcpy2DAsync(d, dev_pitch, h, wb, wb, height * n, kind, cur().stream));
+    else F3D_HIP(hipMemcpy2DAsync(h, wb, d, dev_pitch, wb, height * n, kind, cur().stream));
   }
   return 0;
 }
@@ -424,7 +483,7 @@ int f3d_copy3d_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t d
   if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_h2d: volume exceeds container");
   char* d = f3d_ptr<char>(dst) + dev_plane0 * dev_height * dev_pitch;
   if (copy_dense(d, dev_pitch, dev_height, reinterpret_cast<char*>(const_cast<float*>(src)), width, height, depth, true)) return 1;
-  F3D_HIP(hipStreamSynchronize(S.stream));
+  F3D_HIP(hipStreamSynchronize(cur().stream));
   return 0;
 }
 
@@ -435,7 +494,7 @@ int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_de
   if (height > dev_height || width * sizeof(float) > dev_pitch) return f3d::fail("f3d_copy3d_d2h: volume exceeds container");
   char* s = f3d_ptr<char>(src) + dev_plane0 * dev_height * dev_pitch;
   if (copy_dense(s, dev_pitch, dev_height, reinterpret_cast<char*>(dst), width, height, depth, false)) return 1;
-  F3D_HIP(hipStreamSynchronize(S.stream));
+  F3D_HIP(hipStreamSynchronize(cur().stream));
   return 0;
 }
 
@@ -445,7 +504,7 @@ int f3d_copy3d_d2h(float* dst, size_t width, size_t height, size_t depth, f3d_de
 struct f3d_queue_s {
   hipStream_t stream;
 };
-static hipStream_t stream_of(f3d_queue q) { return q ? q->stream : S.stream; }
+static hipStream_t stream_of(f3d_queue q) { return q ? q->stream : cur().stream; }
 
 int f3d_copy_planes_h2d(f3d_devptr dst, size_t dev_pitch, size_t dev_height, size_t dev_plane0, const float* src,
                         size_t src_row_floats, size_t src_rows, size_t width, size_t height, size_t depth)
@@ -518,7 +577,7 @@ int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t 
   p.dstPtr = make_hipPitchedPtr(f3d_ptr<char>(dst) + dst_plane0 * dst_rows * dst_pitch, dst_pitch, dst_pitch / sizeof(float), dst_rows);
   p.extent = make_hipExtent(wb, height, depth);
   p.kind = hipMemcpyDeviceToDevice;
-  F3D_HIP(hipMemcpy3DAsync(&p, S.stream));
+  F3D_HIP(hipMemcpy3DAsync(&p, cur().stream));
   return 0;
 }
 
@@ -555,7 +614,7 @@ int f3d_host_unregister(void* ptr)
 int f3d_copy_d2d(f3d_devptr dst, f3d_devptr src, size_t bytes)
 {
   F3D_REQUIRE_READY("f3d_copy_d2d");
-  F3D_HIP(hipMemcpyAsync(f3d_ptr<void>(dst), f3d_ptr<const void>(src), bytes, hipMemcpyDeviceToDevice, S.stream));
+  F3D_HIP(hipMemcpyAsync(f3d_ptr<void>(dst), f3d_ptr<const void>(src), bytes, hipMemcpyDeviceToDevice, cur().stream));
   return 0;
 }
 
@@ -564,14 +623,14 @@ int f3d_set_container(const f3d_size4* c)
   if (!c || c->width == 0 || c->height == 0 || c->depth == 0 || c->pitch < c->width * sizeof(float) ||
       c->pitch % sizeof(float) != 0)
     return f3d::fail("f3d_set_container: invalid container size");
-  S.container = *c;
+  cur().container = *c;
   return 0;
 }
 
 int f3d_get_container(f3d_size4* c)
 {
   if (!c) return f3d::fail("f3d_get_container: null output");
-  *c = S.container;
+  *c = cur().container;
   return 0;
 }
 
@@ -579,8 +638,8 @@ int f3d_set_conv_taps(const float* taps, size_t count)
 {
   if (!taps || count == 0 || count > 51 || count % 2 == 0)
     return f3d::fail("f3d_set_conv_taps: need an odd tap count of at most 51, got %zu", count);
-  std::memcpy(S.taps.k, taps, count * sizeof(float));
-  S.taps.count = static_cast<int>(count);
+  std::memcpy(cur().taps.k, taps, count * sizeof(float));
+  cur().taps.count = static_cast<int>(count);
   return 0;
 }
 
@@ -604,7 +663,7 @@ int f3d_event_create(f3d_event* ev)
 int f3d_event_record(f3d_event ev)
 {
   F3D_REQUIRE_READY("f3d_event_record");
-  F3D_HIP(hipEventRecord(ev->ev, S.stream));
+  F3D_HIP(hipEventRecord(ev->ev, cur().stream));
   return 0;
 }
 
@@ -677,7 +736,7 @@ int f3d_event_destroy(f3d_event ev)
 int f3d_stream_sync(void)
 {
   F3D_REQUIRE_READY("f3d_stream_sync");
-  F3D_HIP(hipStreamSynchronize(S.stream));
+  F3D_HIP(hipStreamSynchronize(cur().stream));
   return 0;
 }
 
@@ -696,7 +755,7 @@ int f3d_prof_select(unsigned kernel_mask)
 int f3d_prof_reset(void)
 {
   F3D_REQUIRE_READY("f3d_prof_reset");
-  F3D_HIP(hipStreamSynchronize(S.stream));
+  F3D_HIP(hipStreamSynchronize(cur().stream));
   for (auto& r : P.pending) {
     P.pool.push_back(r.start);
     P.pool.push_back(r.stop);
@@ -709,7 +768,7 @@ int f3d_prof_read(int kernel, size_t min_voxels, double* total_ms, uint64_t* lau
 {
   F3D_REQUIRE_READY("f3d_prof_read");
   if (kernel < 0 || kernel >= F3D_K_COUNT) return f3d::fail("f3d_prof_read: bad kernel id %d", kernel);
-  F3D_HIP(hipStreamSynchronize(S.stream));
+  F3D_HIP(hipStreamSynchronize(cur().stream));
   double ms = 0, vox = 0;
   uint64_t n = 0;
   for (auto& r : P.pending) {

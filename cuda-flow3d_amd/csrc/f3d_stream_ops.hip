@@ -459,7 +459,7 @@ int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, con
   F3D_REQUIRE_READY("f3d_abs_max");
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_abs_max")) return 1;
-  static unsigned* d_result = nullptr;
+  static thread_local unsigned* d_result = nullptr;   // per thread: two lanes may ask at once
   if (!d_result) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_result), sizeof(unsigned)));
   F3D_HIP(hipMemsetAsync(d_result, 0, sizeof(unsigned), f3d::stream()));
   if (g.z_hi > g.z_lo) {
@@ -482,7 +482,7 @@ int f3d_flow_stats(f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w, size
   if (!min_magnitude || !max_magnitude || !sum_magnitude) return f3d::fail("f3d_flow_stats: null argument");
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_flow_stats")) return 1;
-  static FlowStats* d_stats = nullptr;
+  static thread_local FlowStats* d_stats = nullptr;
   if (!d_stats) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(FlowStats)));
   const FlowStats init = {0x7f7fffffu, 0u, 0.0};  // FLT_MAX, 0, 0
   F3D_HIP(hipMemcpyAsync(d_stats, &init, sizeof(init), hipMemcpyHostToDevice, f3d::stream()));
@@ -508,7 +508,7 @@ int f3d_residual_stats(f3d_devptr frame_0, f3d_devptr frame_1_warped, size_t wid
   if (!sum_squares || !sum_abs || !max_abs) return f3d::fail("f3d_residual_stats: null argument");
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_residual_stats")) return 1;
-  static ResidualStats* d_stats = nullptr;
+  static thread_local ResidualStats* d_stats = nullptr;
   if (!d_stats) F3D_HIP(hipMalloc(reinterpret_cast<void**>(&d_stats), sizeof(ResidualStats)));
   F3D_HIP(hipMemsetAsync(d_stats, 0, sizeof(ResidualStats), f3d::stream()));
   if (g.z_hi > g.z_lo) {

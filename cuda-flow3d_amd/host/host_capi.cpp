@@ -264,6 +264,14 @@ int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, s
   return 0;
 }
 
+int f3d_op_solve_p_fused_weights(f3d_op op, int* fused)
+{
+  auto* solve_p = op ? dynamic_cast<CudaOperationSolveP*>(op->op) : nullptr;
+  if (!solve_p || !fused) return 1;
+  *fused = solve_p->LastFusedWeights() ? 1 : 0;
+  return 0;
+}
+
 int f3d_volume_wrap(f3d_volume* vol, float* data, size_t width, size_t height, size_t depth)
 {
   if (!vol || !data || width == 0 || height == 0 || depth == 0) return 1;

@@ -4,16 +4,24 @@
 // the nine-key parameter bag, write flow-u/v/w as RAW float32), with the compile-time constants turned into
 // flags:  flow3d --dims W H D --frames f0.raw f1.raw [f2.raw ...] [--f32] [--out prefix] [--levels N] [--scale s]
 //                [--outer N] [--inner N] [--alpha a] [--eps-smooth e] [--eps-data e] [--median r] [--sigma s]
-//                [--synthetic] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]]
+//                [--synthetic] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]] [--concurrent N]
 // More than two frames make a sequence: the driver, its containers and operators are set up once (the reference does
 // Initialize / Destroy per pair, src/main.cpp:150,184) and the flow of every consecutive pair is written as
 // <prefix>_<k>_flow-{u,v,w}-W-H-D.raw.  --partial runs the out-of-core driver (the reference's use_partial_gpu branch,
 // src/main.cpp:187-220): volumes stay in host memory, output files end in "-partial.raw"; --full adds the pre-blur and the
 // median the reference's piecemeal driver leaves out, which makes the result equal the resident mode's.
+// --concurrent N solves N pairs of a sequence AT ONCE: N host threads, each with a driver and a lane of its own (f3d_lane_*: its
+// own stream and container geometry), pair k going to thread k mod N.  Pair k+1 does not depend on pair k, and a small volume
+// (up to ~128^3) is a chain of dependent launches of 10-20 us that leaves most of the chip idle: two such chains side by side
+// nearly double the pairs per second.  Large volumes fill the chip by themselves and gain nothing.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "f3d_host.h"
@@ -26,7 +34,8 @@ static void Usage()
 {
   std::printf("usage: flow3d --dims W H D (--frames f0.raw f1.raw [f2.raw ...] [--f32] | --synthetic) [--out prefix]\n"
               "              [--levels N] [--scale s] [--outer N] [--inner N] [--alpha a] [--eps-smooth e]\n"
-              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]]\n");
+              "              [--eps-data e] [--median r] [--sigma s] [--vtk] [--stats] [--silent] [--partial [--full] [--budget-mb N]]\n"
+              "              [--concurrent N]\n");
 }
 
 int main(int argc, char** argv)
@@ -36,6 +45,7 @@ int main(int argc, char** argv)
   std::string prefix = "flow3d";
   bool f32_input = false, synthetic = false, write_vtk = false, silent_mode = false, print_stats = false;
   bool use_partial_gpu = false, partial_full = false;
+  size_t concurrent = 1;
 
   // defaults of src/main.cpp:77-85
   size_t warp_levels_count = 40;
@@ -79,6 +89,7 @@ int main(int argc, char** argv)
     else if (a == "--partial") use_partial_gpu = true;
     else if (a == "--full") partial_full = true;
     else if (a == "--budget-mb") { need(1); setenv("F3D_P_BUDGET_MB", argv[++i], 1); }
+    else if (a == "--concurrent") { need(1); concurrent = std::strtoull(argv[++i], nullptr, 10); }
     else { Usage(); return 64; }
   }
   if (width == 0 || height == 0 || depth == 0 || (!synthetic && files.size() < 2)) {
@@ -154,6 +165,58 @@ int main(int argc, char** argv)
     optical_flow_p.Destroy();
     f3d_host_shutdown();
     return 0;
+  }
+
+  if (concurrent > 1 && pairs > 1) {
+    // N pairs at once: every worker thread binds a lane of its own and drives a driver of its own on it
+    const size_t workers = std::min(concurrent, pairs);
+    std::printf("Mode: Full GPU mode, %zu pairs at a time\n", workers);
+    std::mutex print_mutex;
+    std::atomic<int> failed{0};
+    const auto t_start = std::chrono::steady_clock::now();
+    auto work = [&](size_t me) {
+      f3d_lane lane = nullptr;
+      if (CheckDeviceError(f3d_lane_create(&lane)) || CheckDeviceError(f3d_lane_make_current(lane))) {
+        failed = 3;
+        return;
+      }
+      {
+        OpticalFlowE flow;
+        Data3D f0, f1, u(width, height, depth), v(width, height, depth), w(width, height, depth);
+        bool ok;
+        {
+          std::lock_guard<std::mutex> lock(print_mutex);   // the set-up lines of one driver at a time
+          ok = flow.Initialize(data_size);
+        }
+        flow.silent = true;
+        // the bag holds pointers to main's variables, which nobody writes from here on: the workers share it read-only
+        for (size_t k = me; ok && k < pairs && !failed; k += workers) {
+          if (!load(f0, files[k]) || !load(f1, files[k + 1])) {
+            failed = 2;
+            break;
+          }
+          flow.ComputeFlow(f0, f1, u, v, w, params);
+          const std::string tag = prefix + "_" + std::to_string(k);
+          u.WriteRAWToFileF32((tag + "_flow-u" + suffix).c_str());
+          v.WriteRAWToFileF32((tag + "_flow-v" + suffix).c_str());
+          w.WriteRAWToFileF32((tag + "_flow-w" + suffix).c_str());
+          if (write_vtk) Data3D::WriteFlowToFileVTK((tag + "_flow.vtk").c_str(), u, v, w);
+          std::lock_guard<std::mutex> lock(print_mutex);
+          std::printf("pair %zu of %zu done by worker %zu\n", k + 1, pairs, me);
+        }
+        if (!ok) failed = 3;
+        flow.Destroy();
+      }
+      f3d_lane_make_current(nullptr);
+      f3d_lane_destroy(lane);
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < workers; ++t) threads.emplace_back(work, t);
+    for (std::thread& t : threads) t.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::printf("%zu pairs in %.3f s: %.2f pairs per second with %zu at a time\n", pairs, secs, pairs / secs, workers);
+    f3d_host_shutdown();
+    return failed;
   }
 
   OpticalFlowE optical_flow_e;

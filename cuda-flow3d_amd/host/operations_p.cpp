@@ -259,13 +259,15 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
 }  // namespace
 
 SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode)
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode, int fields)
 {
   SolvePiecemealPlan plan;
   const ChunkBox box(width, height);
   const size_t cap = static_cast<size_t>(std::numeric_limits<int>::max());
-  const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 13) / 13, cap));
-  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 26) / 26, cap));
+  // 13 fields per chunk set (eight inputs, phi, ksi, three outputs), 15 with the second weight pair of the fused last sweep
+  const size_t nf = static_cast<size_t>(fields);
+  const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf) / nf, cap));
+  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 2 * nf) / (2 * nf), cap));
   plan.max_planes = serial_planes;
   if (depth <= 0 || outer_iterations <= 0) return plan;
   if (serial_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
@@ -649,21 +651,35 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     if (f3d_host_is_pinned(v->DataPtr(), &yes) != 0 || !yes) all_pinned = false;
   }
   if (!all_pinned) overlap_mode = 0;
-  SolvePiecemealPlan plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode);
-  if (plan.overlapped && !PipelineReady()) plan = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0);
+  // The last sweep of an outer iteration and the weights of the next one in ONE launch wherever another outer iteration follows
+  // inside the residency (f3d_solve_sweep_phi_ksi_edges, as the resident operator and the z-slab driver do): it needs a second
+  // weight pair in every chunk set, 15 fields instead of 13.  Where only the 13 fit, the four-launch order stays.
+  bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && K % 2 == 1 && outer > 1;
+  auto make_plan = [&](int fields) {
+    SolvePiecemealPlan p = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode, fields);
+    if (p.overlapped && !PipelineReady()) p = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0, fields);
+    return p;
+  };
+  SolvePiecemealPlan plan = make_plan(fuse_weights ? 15 : 13);
+  if (fuse_weights && (plan.chunk < 1 || plan.outer_per_pass < 2)) {  // nothing to fuse inside a residency of one outer iteration
+    fuse_weights = false;
+    plan = make_plan(13);
+  }
   last_plan_ = plan;
+  last_fused_weights_ = fuse_weights;
   if (plan.chunk < 1) return LowMemory(GetName());
   const int chunk = plan.chunk, halo = plan.halo, planes = std::min(D, chunk + 2 * halo);
   const int n_sets = plan.overlapped ? 2 : 1;
 
-  enum { F0, F1, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, kFields };
+  enum { F0, F1, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, PHI2, KSI2, kAllFields };
+  const int kFields = fuse_weights ? 15 : 13;
   const ChunkBox box(W, H);
   Carver carve(box);
   for (int i = 0; i < n_sets * kFields; ++i) carve.Add(planes);
   if (!carve.Commit()) return;
   ContainerScope scope(box, planes);
   if (!scope.ok()) return;
-  DevicePtr sets[2][kFields];
+  DevicePtr sets[2][kAllFields] = {};
   for (int s = 0; s < n_sets; ++s)
     for (int i = 0; i < kFields; ++i) sets[s][i] = carve[s * kFields + i];
   // Serial: copies and kernels in order on the library stream.  Overlapped: uploads on one queue, downloads on another,
@@ -709,15 +725,40 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       }
       // Outer iteration j of this pass leaves the increments valid on the chunk widened by g = (n-1-j)(K+1) planes:
       // phi/ksi on g + K, sweep s on g + K-1-s; a fused pair runs on the window of its second sweep.
+      bool weights_ready = false;
       for (int j = 0; j < n; ++j) {
         const int g = halo ? (n - 1 - j) * (K + 1) : 0;
         const f3d_slab pw = window(g + K);
-        if (CheckDeviceError(f3d_phi_ksi(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], W, H, D, hx, hy, hz,
+        if (!weights_ready &&
+            CheckDeviceError(f3d_phi_ksi(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], W, H, D, hx, hy, hz,
                                          equation_smoothness, equation_data, buf[PHI], buf[KSI], &pw)))
           return;
+        weights_ready = false;
         for (int s = 0; s < K;) {
           const bool pair = fused && s + 2 <= K;
           const f3d_slab sw = window(g + K - 1 - s - (pair ? 1 : 0));
+          if (fuse_weights && !pair && s == K - 1 && j + 1 < n) {
+            // The next outer iteration wants its weights on window(g - 1): this sweep's window shrunk by one plane wherever it does
+            // not end at a face of the volume (the weights of a plane need the new increments of both z neighbours).  The launch
+            // computes the sweep on those edge planes anyway and stores it there too (keep_below / keep_above).
+            const int lo_in = sw.z_lo > 0 ? 1 : 0, hi_in = sw.z_hi < D ? 1 : 0;
+            const f3d_slab ww = {sw.z_base, sw.z_lo + lo_in, sw.z_hi - hi_in};
+            if (ww.z_hi - ww.z_lo >= 1) {
+              if (CheckDeviceError(f3d_solve_sweep_phi_ksi_edges(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW],
+                                                                 buf[PHI], buf[KSI], W, H, D, hx, hy, hz, equation_alpha,
+                                                                 equation_smoothness, equation_data, buf[TDU], buf[TDV], buf[TDW],
+                                                                 buf[PHI2], buf[KSI2], &ww, lo_in, hi_in)))
+                return;
+              std::swap(buf[DU], buf[TDU]);
+              std::swap(buf[DV], buf[TDV]);
+              std::swap(buf[DW], buf[TDW]);
+              std::swap(buf[PHI], buf[PHI2]);
+              std::swap(buf[KSI], buf[KSI2]);
+              weights_ready = true;
+              s += 1;
+              continue;
+            }
+          }
           const int status =
               pair ? f3d_solve_sweep2(buf[F0], buf[F1], buf[FU], buf[FV], buf[FW], buf[DU], buf[DV], buf[DW], buf[PHI], buf[KSI], W, H, D,
                                       hx, hy, hz, equation_alpha, buf[TDU], buf[TDV], buf[TDW], &sw)

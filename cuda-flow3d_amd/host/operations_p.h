@@ -42,7 +42,7 @@ struct SolvePiecemealPlan {
 // the serial / overlapped schedule, anything else lets the cost model choose (F3D_P_OVERLAP); chunk == 0 means the budget
 // cannot hold even one plane with its halo.
 SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode = -1);
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode = -1, int fields = 13);
 
 class CudaOperationPiecemealBase : public CudaOperationBase {
  public:
@@ -108,10 +108,13 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   // what the last Execute did (tests and the driver's log)
   const SolvePiecemealPlan& LastPlan() const { return last_plan_; }
   size_t LastPasses() const { return last_passes_; }
+  // whether the last Execute ran the last sweep of an outer iteration and the next weights as one launch (15 fields per chunk set)
+  bool LastFusedWeights() const { return last_fused_weights_; }
 
  private:
   SolvePiecemealPlan last_plan_;
   size_t last_passes_ = 0;
+  bool last_fused_weights_ = false;
 };
 
 // The two filters the reference's piecemeal driver leaves out (its median is commented out, optical_flow_p.cpp:268-302, and

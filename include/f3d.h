@@ -59,6 +59,19 @@ int f3d_init(int device);
 int f3d_shutdown(void);
 /* 1 between a successful f3d_init() and f3d_shutdown(), else 0 (exit-time code asks before it touches the device) */
 int f3d_is_initialized(void);
+/* Lanes (no reference counterpart: the reference has one context and the NULL stream, src/utils/cuda_utils.cpp:21-57).  Every call
+ * below that says "library stream", and f3d_set_container / f3d_set_conv_taps, act on the LANE of the calling thread: by default the
+ * one lane the library creates in f3d_init.  A driver that is to run beside another one in the same process -- two frame pairs of a
+ * sequence of small volumes solved at once (bin/flow3d --concurrent) -- creates a lane of its own (a stream, a container geometry, blur
+ * taps) and makes it current in the thread that drives it; launches of different lanes are not ordered with each other.  Allocation,
+ * events, queues and host registration are lane-agnostic; the profiling bracket (f3d_prof_*), the communicator and the out-of-core arena
+ * belong to the default lane. */
+typedef struct f3d_lane_s* f3d_lane;
+int f3d_lane_create(f3d_lane* lane);
+int f3d_lane_make_current(f3d_lane lane);   /* for the calling thread; NULL = back to the default lane */
+int f3d_lane_is_private(void);              /* 1 when the calling thread is on a lane of its own */
+int f3d_lane_destroy(f3d_lane lane);        /* waits for the lane's stream first */
+
 /* Diagnostics (no reference counterpart): from now on a fatal signal (SIGSEGV, SIGBUS, SIGILL, SIGFPE, SIGABRT) first writes
  * the signal number, the fault address and /proc/self/maps to `path`, then hands the signal to the handler that was installed
  * before (Python's faulthandler, a profiler's, the default action), so that the frames of a native stack trace can be resolved

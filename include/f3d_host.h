@@ -101,6 +101,10 @@ float* f3d_volume_data(f3d_volume vol);
 int f3d_volume_destroy(f3d_volume vol);
 /* what the last solve_p Execute did */
 int f3d_op_solve_p_last(f3d_op op, int* chunk, int* outer_per_pass, int* halo, size_t* passes, int* overlapped);
+/* 1 when the last execute of the "solve_p" operator ran the last sweep of an outer iteration together with the weights of the next
+ * one (a second weight pair per chunk set: 15 fields instead of 13, taken when they fit and a residency holds two outer iterations
+ * or more) */
+int f3d_op_solve_p_fused_weights(f3d_op op, int* fused);
 /* chunk plan of solve_p for a level (pure host arithmetic) and the device budget it would use now.  overlap_mode 0 = copies
  * and kernels in order, 1 = two chunk sets with the copies beside the kernels, -1 = whichever the cost model prefers */
 int f3d_plan_solve_piecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations, int outer_iterations,

@@ -201,7 +201,11 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     f1[:D, :H, :W] = f0[:D, :H, :W] + rng.uniform(-8, 8, size=(D, H, W)).astype(np.float32)
     u, v, w = (box_in_container(rng, dims, cd, -2, 2) for _ in range(3))
     expect = oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, 7.5, 0.001, 0.001)
-    fields = 26 if overlap and planes < D else 13
+    # 13 fields per chunk set, 15 with the second weight pair of the fused last sweep (odd inner count, another outer iteration to
+    # fuse with inside the residency -- forced == 1 leaves none)
+    want_fused = inner % 2 == 1 and outer > 1 and forced != 1
+    per_set = 15 if want_fused else 13
+    fields = 2 * per_set if overlap and planes < D else per_set
     set_budget(budget_for(fields * planes, W, H, fields))
     os.environ["F3D_P_OUTER_PER_PASS"] = str(forced)
     os.environ["F3D_P_OVERLAP"] = str(min(overlap, 1))
@@ -213,6 +217,7 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     op.execute(outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5, equation_smoothness=0.001,
                equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **vols)
     chunk, per_pass, halo, passes, overlapped = op.solve_p_last()
+    assert op.solve_p_fused_weights() == (want_fused and per_pass >= 2), (want_fused, per_pass)
     if planes >= D:
         assert (chunk, per_pass, halo, passes, overlapped) == (D, outer, 0, 1, False)
     else:

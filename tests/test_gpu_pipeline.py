@@ -303,3 +303,79 @@ def test_fused_pairs_equal_single_sweeps_end_to_end(tmp_path):
     core = (slice(60, 140),) * 3
     # 24 levels x 10 outer iterations are not converged: the translation is recovered to ~10 %
     assert abs(u[core].mean() - 2.0) < 0.4 and abs(v[core].mean() + 1.0) < 0.3 and abs(w[core].mean() - 0.5) < 0.2
+
+
+def test_two_drivers_on_lanes_of_their_own_run_side_by_side(f3d):
+    """Two host threads, each with a lane of its own (stream + container geometry) and a driver of its own, solve different pairs of
+    DIFFERENT sizes at the same time: every result equals what the same pair gives alone on the default lane -- the launches of the
+    two drivers share nothing but the device (and interleave freely on it)."""
+    import threading
+    cases = [((40, 36, 24), dict(warp_levels_count=8, outer_iterations_count=6)),
+             ((56, 30, 33), dict(warp_levels_count=10, outer_iterations_count=5))]
+    pairs = [f3d.synth_pair(*dims) for dims, _ in cases]
+    alone = []
+    for (dims, kw), (f0, f1) in zip(cases, pairs):
+        flow = f3d.OpticalFlow()
+        flow.initialize(*dims)
+        alone.append(flow.compute(f0, f1, silent=True, **kw))
+        flow.destroy()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            with f3d.Lane():
+                assert f3d.hip().f3d_lane_is_private() == 1
+                (dims, kw), (f0, f1) = cases[i], pairs[i]
+                flow = f3d.OpticalFlow()
+                flow.initialize(*dims)
+                for _ in range(3):          # several solves per thread: the two chains of launches overlap for a while
+                    results[i] = flow.compute(f0, f1, silent=True, **kw)
+                flow.destroy()
+        except Exception as e:              # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert f3d.hip().f3d_lane_is_private() == 0
+    for i in range(2):
+        for g, e, c in zip(results[i], alone[i], "uvw"):
+            assert same(g, e), f"driver {i} on its own lane: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+def test_cli_concurrent_pairs(f3d, tmp_path):
+    """bin/flow3d --concurrent 2 on five frames: two worker threads, each with a lane and a driver of its own, take the four pairs
+    alternately; every pair equals a fresh OpticalFlow.compute of its two frames."""
+    import re
+    import subprocess
+    W, H, D = 48, 40, 24
+    f0, f1 = f3d.synth_pair(W, H, D)
+    mix = [0.0, 1.0, 0.5, 0.75, 0.2]
+    frames = [np.round(np.clip((1 - a) * f0 + a * f1, 0, 255)) for a in mix]
+    paths = []
+    for k, fr in enumerate(frames):
+        p = tmp_path / f"frame{k}.raw"
+        fr.astype(np.uint8).tofile(p)
+        paths.append(str(p))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow3d_amd", "bin", "flow3d")
+    prefix = str(tmp_path / "par")
+    kw = dict(warp_levels_count=6, outer_iterations_count=4)
+    run = subprocess.run([exe, "--dims", str(W), str(H), str(D), "--frames", *paths, "--out", prefix, "--levels", "6", "--outer", "4",
+                          "--silent", "--concurrent", "2"], capture_output=True, text=True, timeout=180)
+    assert run.returncode == 0, run.stdout + run.stderr
+    done = re.findall(r"^pair (\d) of 4 done by worker (\d)", run.stdout, flags=re.M)
+    assert sorted(int(p) for p, _ in done) == [1, 2, 3, 4] and {w for _, w in done} == {"0", "1"}, run.stdout
+    assert re.search(r"4 pairs in [\d.]+ s: [\d.]+ pairs per second with 2 at a time", run.stdout), run.stdout
+    for k in range(4):
+        a = frames[k].astype(np.uint8).astype(np.float32)
+        b = frames[k + 1].astype(np.uint8).astype(np.float32)
+        flow = f3d.OpticalFlow()
+        flow.initialize(W, H, D)
+        exp = flow.compute(a, b, silent=True, **kw)
+        flow.destroy()
+        got = [np.fromfile(f"{prefix}_{k}_flow-{c}-{W}-{H}-{D}.raw", np.float32).reshape(D, H, W) for c in "uvw"]
+        for g, e in zip(got, exp):
+            assert same(g, e)
