@@ -2,10 +2,10 @@
 # SQ-level counters of one solver kernel on a 512^3 level (tools/kbench.py), separate rocprofv3 --pmc passes.
 #   tools/pmc_sq.sh <kernel: sweep|sweep2|phi> <tag>
 set -e
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+R=$(pwd)   # the tree the command was started in (a staged copy under tools/gpu_stage.sh)
 K=${1:-sweep2}
 T=${2:-sq}
-O=$R/gpurun_out/$T
+O=${F3D_OUT:-$R/gpurun_out}/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 pass() {

@@ -3,8 +3,8 @@
 # rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section), plus the same two counters on lab kernels with a known byte
 # count (tools/lab/stream_lab: 10 x 512^3 floats read once, 3 x written once) as the calibration of the gfx950 factor.
 set -e
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/traffic
+R=$(pwd)   # the tree the command was started in (a staged copy under tools/gpu_stage.sh)
+O=${F3D_OUT:-$R/gpurun_out}/traffic
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- $R/tools/lab/bin/stream_lab > $O/cal_fetch.log 2>&1

@@ -2,8 +2,8 @@
 # Collects the evidence committed under profiles/: the default bench line, the rocprofv3 kernel-trace stats of the same
 # command, and the HBM-traffic counters (separate --pmc passes, MI355X_MICROARCH.md "HBM") of the two solver kernels.
 set -e
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/round
+R=$(pwd)   # the tree the command was started in (a staged copy under tools/gpu_stage.sh)
+O=${F3D_OUT:-$R/gpurun_out}/round
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
