@@ -130,6 +130,7 @@ def hip():
         "f3d_pack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_unpack_planes": [_dp, C.c_int, C.c_int, _sz, _sz, _dp, _sz],
         "f3d_copy_planes": [_dp, C.c_int, _dp, C.c_int, C.c_int, _sz, _sz],
+        "f3d_copy_plane_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, _sz, _sz],
         "f3d_pack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_unpack_segments": [C.POINTER(_dp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.c_int, _sz, _sz, _dp],
         "f3d_comm_sendrecv": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],

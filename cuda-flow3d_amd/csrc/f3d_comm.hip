@@ -12,6 +12,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -301,6 +302,25 @@ __global__ __launch_bounds__(256) void k_copy_planes(float* __restrict__ dst, co
   dst[(dst_plane0 + p) * plane + row] = src[(src_plane0 + p) * plane + row];
 }
 
+// the same for up to kMaxSeg (destination, source, plane range) triples in one launch: a whole in-process exchange
+struct CopyTable {
+  float* dst[kMaxSeg];
+  const float* src[kMaxSeg];
+  int dst_plane0[kMaxSeg], src_plane0[kMaxSeg], count[kMaxSeg];
+};
+__global__ __launch_bounds__(256) void k_copy_planes_batched(CopyTable t, int width, int height, int Hc, int pitch, int max_count)
+{
+  const int seg = blockIdx.z / max_count;
+  const int p = blockIdx.z - seg * max_count;
+  if (p >= t.count[seg]) return;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= width || y >= height) return;
+  const size_t row = static_cast<size_t>(y) * pitch + x;
+  const size_t plane = static_cast<size_t>(Hc) * pitch;
+  t.dst[seg][(t.dst_plane0[seg] + p) * plane + row] = t.src[seg][(t.src_plane0[seg] + p) * plane + row];
+}
+
 int check_planes(int plane0, int count, size_t width, size_t height, const char* who)
 {
   const f3d_size4& c = f3d::container();
@@ -535,6 +555,37 @@ int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plan
                      src_plane0, static_cast<int>(width), static_cast<int>(height), static_cast<int>(c.height),
                      static_cast<int>(c.pitch / sizeof(float)));
   F3D_HIP(hipGetLastError());
+  return 0;
+}
+
+int f3d_copy_plane_segments(const f3d_devptr* dst, const int* dst_plane0, const f3d_devptr* src, const int* src_plane0, const int* count,
+                            int n_segments, size_t width, size_t height)
+{
+  F3D_REQUIRE_READY("f3d_copy_plane_segments");
+  if (n_segments < 0 || (n_segments > 0 && (!dst || !dst_plane0 || !src || !src_plane0 || !count)))
+    return f3d::fail("f3d_copy_plane_segments: bad argument");
+  const f3d_size4& c = f3d::container();
+  for (int i = 0; i < n_segments; i += kMaxSeg) {
+    const int n = std::min(kMaxSeg, n_segments - i);
+    CopyTable t = {};
+    int max_count = 0;
+    for (int k = 0; k < n; ++k) {
+      if (check_planes(dst_plane0[i + k], count[i + k], width, height, "f3d_copy_plane_segments") ||
+          check_planes(src_plane0[i + k], count[i + k], width, height, "f3d_copy_plane_segments"))
+        return 1;
+      t.dst[k] = f3d_ptr<float>(dst[i + k]);
+      t.src[k] = f3d_ptr<const float>(src[i + k]);
+      t.dst_plane0[k] = dst_plane0[i + k];
+      t.src_plane0[k] = src_plane0[i + k];
+      t.count[k] = count[i + k];
+      max_count = std::max(max_count, count[i + k]);
+    }
+    if (max_count == 0) continue;
+    const dim3 grid((width + 63) / 64, (height + 3) / 4, n * max_count), block(64, 4, 1);
+    hipLaunchKernelGGL(k_copy_planes_batched, grid, block, 0, f3d::stream(), t, static_cast<int>(width), static_cast<int>(height),
+                       static_cast<int>(c.height), static_cast<int>(c.pitch / sizeof(float)), max_count);
+    F3D_HIP(hipGetLastError());
+  }
   return 0;
 }
 

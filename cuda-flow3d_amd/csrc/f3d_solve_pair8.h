@@ -119,7 +119,12 @@ struct Pair8Lds {
   // neighbour rows and halo columns at the end of step p-1) has been read when barrier B_p falls, so at step q the loader
   // refills the slot of plane q with plane q+3 while q+1 is being read and q+2 is landing.
   static constexpr int kSlots = 3;
-  static constexpr int kPerPlane = NA * NK + NH;      // DMA instructions per plane (the counted wait leaves one plane in flight)
+  // DMA instructions per plane (the counted wait leaves one plane in flight).  vmcnt is a 6-bit counter: with more than 31 pieces per
+  // plane (TY = 8, 12) the second plane's issue stalls in the counter until enough of the first has landed -- "two planes in flight"
+  // means two planes REQUESTED; harmless for a wave that does nothing else, and the wait count itself must fit
+  // (tools/isa_hazards.py checks kPerPlane <= 63 and that exactly one or two planes are issued between a barrier and the wait).
+  static constexpr int kPerPlane = NA * NK + NH;
+  static_assert(kPerPlane <= 63, "s_waitcnt vmcnt(kPerPlane): the counter has six bits");
 };
 
 // A wave-uniform pointer moved into scalar registers for good: the "s" operands of the hand-issued memory instructions need

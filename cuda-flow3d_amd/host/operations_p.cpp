@@ -653,15 +653,20 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   if (!all_pinned) overlap_mode = 0;
   // The last sweep of an outer iteration and the weights of the next one in ONE launch wherever another outer iteration follows
   // inside the residency (f3d_solve_sweep_phi_ksi_edges, as the resident operator and the z-slab driver do): it needs a second
-  // weight pair in every chunk set, 15 fields instead of 13.  Where only the 13 fit, the four-launch order stays.
+  // weight pair in every chunk set, 15 fields instead of 13.  Measured (1024^3 on a 16 GB budget, tools/r3_job7.sh): where a level
+  // goes through in CHUNKS the solver is bound by the link, not by the device, and 15 fields mean fewer planes per chunk, deeper
+  // relative halos and more residencies -- 32.8 s of solver against 30.2 s with the 13.  So the fused launch is taken only where the
+  // level fits the budget with all 15 fields (one residency, no halo: the device is what is left to save on); F3D_P_FUSED=1
+  // forces it for chunked levels too (the tests run both).
   bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && K % 2 == 1 && outer > 1;
+  const bool fuse_when_chunked = std::getenv("F3D_P_FUSED") && std::atoi(std::getenv("F3D_P_FUSED")) == 1;
   auto make_plan = [&](int fields) {
     SolvePiecemealPlan p = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode, fields);
     if (p.overlapped && !PipelineReady()) p = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0, fields);
     return p;
   };
   SolvePiecemealPlan plan = make_plan(fuse_weights ? 15 : 13);
-  if (fuse_weights && (plan.chunk < 1 || plan.outer_per_pass < 2)) {  // nothing to fuse inside a residency of one outer iteration
+  if (fuse_weights && (plan.chunk < 1 || plan.outer_per_pass < 2 || (plan.halo > 0 && !fuse_when_chunked))) {
     fuse_weights = false;
     plan = make_plan(13);
   }

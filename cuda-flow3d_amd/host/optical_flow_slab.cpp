@@ -233,20 +233,27 @@ bool OpticalFlowSlab::Exchange(int depth, size_t width, size_t height, const std
     failed_ = true;
     return false;
   }
-  if (locals_.size() > 1) {  // every rank lives here: copy planes between their containers
+  if (locals_.size() > 1) {  // every rank lives here: copy planes between their containers -- the whole exchange in a few launches
+    std::vector<f3d_devptr> dst, src;
+    std::vector<int> dst_plane, src_plane, count;
     for (Local& me : locals_) {
       const int my_base = ZBase(depth, me.rank);
       for (const HaloTransfer& t : PlanHaloExchange(depth, me.rank, n_ranks_, need_lo, need_hi)) {
         if (t.recv.empty()) continue;
         const Local& peer = locals_[t.peer];
         const int peer_base = ZBase(depth, peer.rank);
-        for (Role role : roles)
-          if (!Check(f3d_copy_planes(me.buf[role], t.recv.lo - my_base, peer.buf[role], t.recv.lo - peer_base, t.recv.size(),
-                                     width, height)))
-            return false;
+        for (Role role : roles) {
+          dst.push_back(me.buf[role]);
+          dst_plane.push_back(t.recv.lo - my_base);
+          src.push_back(peer.buf[role]);
+          src_plane.push_back(t.recv.lo - peer_base);
+          count.push_back(t.recv.size());
+        }
       }
     }
-    return true;
+    // sources are owned planes, destinations halo planes: no segment reads what another one writes
+    return Check(f3d_copy_plane_segments(dst.data(), dst_plane.data(), src.data(), src_plane.data(), count.data(),
+                                         static_cast<int>(dst.size()), width, height));
   }
   // one rank per process: pack -> grouped send/recv -> unpack
   return ExchangeBegin(depth, width, height, roles, roles, need_lo, need_hi) && ExchangeEnd(width, height);

@@ -317,6 +317,10 @@ int f3d_unpack_segments(const f3d_devptr* fields, const int* plane0, const int* 
 /* same-device plane copy between two containers (one-GPU rehearsal of the slab decomposition) */
 int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width,
                     size_t height);
+/* ... and up to any number of (destination, source, plane range) triples in as few launches as possible (32 per launch): a whole
+ * in-process exchange -- every rank, peer and field -- instead of a launch per triple */
+int f3d_copy_plane_segments(const f3d_devptr* dst, const int* dst_plane0, const f3d_devptr* src, const int* src_plane0, const int* count,
+                            int n_segments, size_t width, size_t height);
 /* One grouped exchange on the library stream: for every i, send send_count[i] floats from send_buf + send_offset[i]
  * to peers[i] and receive recv_count[i] floats into recv_buf + recv_offset[i] from peers[i] (zero counts skipped). */
 int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,

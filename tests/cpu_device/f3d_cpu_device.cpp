@@ -502,6 +502,16 @@ int f3d_unpack_segments(const f3d_devptr* fields, const int* plane0, const int* 
   for (int i = 0; i < n; ++i) plane_copy(P<float>(fields[i]), plane0[i], count[i], width, height, P<float>(staging) + off[i], false);
   return 0;
 }
+int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width, size_t height);
+int f3d_copy_plane_segments(const f3d_devptr* dst, const int* dst_plane0, const f3d_devptr* src, const int* src_plane0, const int* count,
+                            int n_segments, size_t width, size_t height)
+{
+  // NOTE: segments may alias (a rank's planes are another rank's source): the device kernel reads and writes disjoint planes, and so
+  // does this loop as long as every source plane is an OWNED plane and every destination a halo plane, which is what the driver asks for
+  for (int i = 0; i < n_segments; ++i)
+    if (f3d_copy_planes(dst[i], dst_plane0[i], src[i], src_plane0[i], count[i], width, height)) return 1;
+  return 0;
+}
 int f3d_copy_planes(f3d_devptr dst, int dst_plane0, f3d_devptr src, int src_plane0, int count, size_t width, size_t height)
 {
   const size_t pitch_f = g_container.pitch / sizeof(float);

@@ -202,7 +202,9 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     u, v, w = (box_in_container(rng, dims, cd, -2, 2) for _ in range(3))
     expect = oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, 7.5, 0.001, 0.001)
     # 13 fields per chunk set, 15 with the second weight pair of the fused last sweep (odd inner count, another outer iteration to
-    # fuse with inside the residency -- forced == 1 leaves none)
+    # fuse with inside the residency -- forced == 1 leaves none).  By default the operator fuses only where the level fits in one
+    # residency; F3D_P_FUSED=1 makes it fuse inside the residencies of chunked levels too, which is what this test wants to see.
+    os.environ["F3D_P_FUSED"] = "1"
     want_fused = inner % 2 == 1 and outer > 1 and forced != 1
     per_set = 15 if want_fused else 13
     fields = 2 * per_set if overlap and planes < D else per_set
@@ -217,8 +219,13 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     op.execute(outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=7.5, equation_smoothness=0.001,
                equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **vols)
     chunk, per_pass, halo, passes, overlapped = op.solve_p_last()
-    assert op.solve_p_fused_weights() == (want_fused and per_pass >= 2), (want_fused, per_pass)
-    if planes >= D:
+    fused = op.solve_p_fused_weights()
+    assert not fused or want_fused
+    if want_fused and not fused:
+        # the 15-field plan came out with one outer iteration per residency (nothing to fuse): the operator took the 13-field plan
+        # of the same budget instead, i.e. 15/13 of the planes this test budgeted per field
+        assert passes == -(-outer // per_pass) and halo == (0 if chunk == D else per_pass * (inner + 1))
+    elif planes >= D:
         assert (chunk, per_pass, halo, passes, overlapped) == (D, outer, 0, 1, False)
     else:
         assert overlapped == pinned
@@ -235,6 +242,7 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     op.destroy()
     for x in vols.values():
         x.destroy()
+    del os.environ["F3D_P_FUSED"]
 
 
 def test_solve_reports_low_memory(f3d, capfd):
