@@ -603,10 +603,13 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         // the tile's row neighbours (ym, yp here) and the march neighbours (M, P) in their geometric roles
         const Face6 fM = plane_face(M), fP = plane_face(P);
         const bool row_p = vy < RDIM - 1, row_m = vy > 0, mar_p = q < MDIM - 1, mar_m = q > 0;
-        sweep_stage1<FD, true>(xm, xp, YM ? fM : ym, YM ? fP : yp, YM ? ym : fM, YM ? yp : fP, cfc.v, C.u, C.v, C.w, C.dv, C.dw,
-                               C.ksi, a.hx, a.hy, a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, YM ? mar_p : row_p, YM ? mar_m : row_m,
-                               YM ? row_p : mar_p, YM ? row_m : mar_m, r_du, r_dv, r_dw, kN, C.f0, C.f1, C.fz, C.ft,
-                               CW ? col_at_x_face : tile_at_x_face, a.w[0], a.w[1], a.w[2]);
+        // ABL bit 4 (timing only, wrong results): the frame derivatives are taken from registers as if they had been read (what a
+        // frame-derivative build of THIS tile shape would save in arithmetic, without its two extra arrays)
+        constexpr bool FDA = FD || (ABL & 16) != 0;
+        sweep_stage1<FDA, true>(xm, xp, YM ? fM : ym, YM ? fP : yp, YM ? ym : fM, YM ? yp : fP, cfc.v, C.u, C.v, C.w, C.dv, C.dw,
+                                C.ksi, a.hx, a.hy, a.hz, fdivs, a.alpha, vx < g.W - 1, vx > 0, YM ? mar_p : row_p, YM ? mar_m : row_m,
+                                YM ? row_p : mar_p, YM ? row_m : mar_m, r_du, r_dv, r_dw, kN, C.f0, C.f1, FD ? C.fz : C.phi,
+                                FD ? C.ft : C.ksi, CW ? col_at_x_face : tile_at_x_face, a.w[0], a.w[1], a.w[2]);
       }
       pN.fx = kN.fx; pN.fy = kN.fy; pN.fz = kN.fz; pN.ft = kN.ft;
       {
@@ -814,6 +817,9 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
   if constexpr (YM) return go(k_pair8<MODE, TY, 0, false, true>);
   else if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
   else {
+    if constexpr (TY == 12) {
+      if (abl == 16) return go(k_pair8<MODE, TY, 16>);
+    }
     if constexpr (MODE == PAIR_SS) {
       if (abl == 1) return go(k_pair8<MODE, TY, 1>);
       if (abl == 2) return go(k_pair8<MODE, TY, 2>);

@@ -4,6 +4,14 @@ set -e
 R=$(pwd)
 O=${F3D_OUT:-$R/gpurun_out}/r3/job8c
 mkdir -p $O
+tools/lab/bin/issue_cost_lab > $O/issue_cost.log 2>&1
+cat $O/issue_cost.log
+for abl in 0 16 0 16; do
+  echo "== F3D_ABLATE8=$abl" >> $O/kb_abl.log
+  F3D_ABLATE8=$abl python3 tools/kbench.py --size 512 --reps 20 --kernel sweep2 2>&1 | grep -v "^\[" >> $O/kb_abl.log
+  F3D_ABLATE8=$abl python3 tools/kbench.py --size 512 --reps 20 --kernel sweeppk 2>&1 | grep -v "^\[" >> $O/kb_abl.log
+done
+cat $O/kb_abl.log
 python3 tools/pbench.py --size 1024 --budget-mb 16384 --no-resident > $O/pbench1024.log 2>&1 || true
 tail -2 $O/pbench1024.log
 python3 tools/pbench.py --size 512 --budget-mb 8192 --no-resident > $O/pbench512_8g.log 2>&1 || true
