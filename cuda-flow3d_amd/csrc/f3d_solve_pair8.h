@@ -104,15 +104,22 @@ inline void pair_consts(PairArgs& a)
   if (a.plain_division) a.fdivs_ok = a.sdivs_ok = 0;
 }
 
-template <int TY, int NA = 10>
+// FD (frame derivatives read instead of formed): twelve inputs, of which only seven are STENCILLED (u, v, w, du, dv, dw, phi: a voxel
+// reads its neighbours' values) -- fx, fy, fz, ft and ksi are looked at by their own voxel only.  The stencilled ones keep the ring
+// described here; the five centre-only ones get a ring of their own (`cring`, C* below) that holds just the rows a stage 1 runs on
+// (y0-1 .. y0+TY) and the halo columns of the core rows, and only TWO slots: a centre-only plane is read once, at the very start of
+// the step in which it is the z+1 plane, so its slot is free one step earlier than a stencilled plane's -- which is what lets a
+// 12-row tile with twelve inputs fit the 160 KB of a CU (3 x 32 KB + 2 x 19.5 KB + 22.5 KB of stage-1 images).
+template <int TY, int NA = 10, bool FD = false>
 struct Pair8Lds {
   static constexpr int NR = TY + 2;                   // row waves
   static constexpr int NJ = TY + 4;                   // ring rows: y0-2 .. y0+TY+1
   static constexpr int NK = (NJ + 3) / 4;             // row pieces (4 rows x 64 floats = 1 KiB) per array and plane
   static constexpr int NJP = NJ;                      // rows per array in the ring (a partial last piece masks its surplus lanes)
-  static constexpr int kHaloLanes = NA * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
+  static constexpr int NS = FD ? 7 : NA;              // arrays in the three-slot ring
+  static constexpr int kHaloLanes = NS * 2 * NJ;      // 16-byte x-halo pieces per plane: [array][side][row]
   static constexpr int NH = (kHaloLanes + 63) / 64;   // halo instructions per plane
-  static constexpr int kRowFloats = NA * NJP * 64;
+  static constexpr int kRowFloats = NS * NJP * 64;
   static constexpr int kHaloOff = kRowFloats;         // float offset of the halo area inside a slot
   static constexpr int kSlotFloats = kRowFloats + NH * 256;
   // Three slots hold TWO planes in flight: everything a step reads of plane p (its rows as z+1 plane during step p-1, its
@@ -123,8 +130,19 @@ struct Pair8Lds {
   // plane (TY = 8, 12) the second plane's issue stalls in the counter until enough of the first has landed -- "two planes in flight"
   // means two planes REQUESTED; harmless for a wave that does nothing else, and the wait count itself must fit
   // (tools/isa_hazards.py checks kPerPlane <= 63 and that exactly one or two planes are issued between a barrier and the wait).
-  static constexpr int kPerPlane = NA * NK + NH;
+  static constexpr int kPerPlane = NS * NK + NH;
   static_assert(kPerPlane <= 63, "s_waitcnt vmcnt(kPerPlane): the counter has six bits");
+  // the centre-only ring of the FD builds
+  static constexpr int NC = FD ? 5 : 0;               // fx, fy, ksi, fz, ft
+  static constexpr int NRC = TY + 2;                  // rows y0-1 .. y0+TY
+  static constexpr int NKC = (NRC + 3) / 4;
+  static constexpr int kCHaloLanes = NC * 2 * TY;     // [array][side][core row]
+  static constexpr int NHC = (kCHaloLanes + 63) / 64;
+  static constexpr int kCRowFloats = NC * NRC * 64;
+  static constexpr int kCHaloOff = kCRowFloats;
+  static constexpr int kCSlotFloats = FD ? kCRowFloats + NHC * 256 : 4;
+  static constexpr int kCSlots = 2;
+  static constexpr int kPerPlaneC = NC * NKC + NHC;   // DMA instructions per centre-only plane
 };
 
 // A wave-uniform pointer moved into scalar registers for good: the "s" operands of the hand-issued memory instructions need
@@ -266,10 +284,13 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const int MDIM = YM ? g.H : g.D;   // extent along the march
   const int m_lo = YM ? 0 : g.z_lo, m_hi = YM ? g.H : g.z_hi;
   constexpr int NA = FD ? 12 : 10;
-  using L = Pair8Lds<TY, NA>;
+  using L = Pair8Lds<TY, NA, FD>;
   constexpr int NR = L::NR, NJ = L::NJ, NK = L::NK, NJP = L::NJP, NH = L::NH;
   static_assert(TY <= 32, "the column wave holds one halo voxel per lane: 2 x TY <= 64");
   __shared__ __attribute__((aligned(16))) float ring[L::kSlots][L::kSlotFloats];
+  __shared__ __attribute__((aligned(16))) float cring[L::kCSlots][L::kCSlotFloats];  // FD: the centre-only inputs (4 floats otherwise)
+  // FD: ring index of a stencilled input (u .. phi are inputs 2 .. 8) and centre-ring index of fx, fy, ksi, fz, ft (inputs 0, 1, 9, 10, 11)
+  constexpr int SB = FD ? 2 : 0;   // ring array = input - SB
   __shared__ float img1[2][3][NR][kLanes];  // stage-1 results of the row waves: S = U + dU' (SS) or dU' (SP)
   __shared__ float hc1[2][3][2][32];        // the same for the two halo columns: [component][side][core row]
 
@@ -336,12 +357,12 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       const int lp = 64 * h + lane;
       hv[h] = lp < L::kHaloLanes;
       const int lq = hv[h] ? lp : 0;
-      const int arr = lq / (2 * NJ);
+      const int arr = lq / (2 * NJ) + SB;
       const int s = (lq / NJ) & 1;
       const int j = lq % NJ;
-      const float* b = base[0];
+      const float* b = base[SB];
 #pragma unroll
-      for (int i = 1; i < NA; ++i)
+      for (int i = SB + 1; i < SB + L::NS; ++i)
         if (arr == i) b = base[i];
       const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, RDIM), 0, RDIM - 1);
       // tiles at an x face fetch a piece from inside the row instead (never used: the mirror rule substitutes there)
@@ -356,20 +377,70 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 #pragma unroll
       for (int k = 0; k < NK; ++k) off[k] = rowb[k] + poff;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
+      for (int i = 0; i < L::NS; ++i) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          if (NJ % 4 == 0 || rowv[k]) dma16(base[i], off[k], slot + (i * NJP + 4 * k) * kLanes);
+          if (NJ % 4 == 0 || rowv[k]) dma16(base[SB + i], off[k], slot + (i * NJP + 4 * k) * kLanes);
         }
       }
 #pragma unroll
       for (int h = 0; h < NH; ++h)
         if (hv[h]) dma16_lane(hptr[h] + (poff >> 2), slot + L::kHaloOff + h * 256);
     };
+    // FD: the centre-only inputs of plane p into centre slot (p - qs) mod 2: rows y0-1 .. y0+TY and the halo columns of the core rows
+    constexpr int NKC = FD ? L::NKC : 1, NHC = FD ? L::NHC : 1;
+    constexpr int kCIn[5] = {0, 1, 9, 10, 11};
+    unsigned crowb[NKC];
+    bool crowv[NKC];
+    const float* chptr[NHC];
+    bool chv[NHC];
+    if constexpr (FD) {
+#pragma unroll
+      for (int k = 0; k < NKC; ++k) {
+        const int j = 4 * k + (lane >> 4);
+        crowv[k] = j < L::NRC;
+        const int yrow = f3d_clampi(f3d_mir(y0 - 1 + (crowv[k] ? j : 0), RDIM), 0, RDIM - 1);
+        crowb[k] = static_cast<unsigned>(yrow) * row_b + static_cast<unsigned>(x0 + 4 * (lane & 15)) * 4u;
+      }
+#pragma unroll
+      for (int h = 0; h < NHC; ++h) {
+        const int lp = 64 * h + lane;
+        chv[h] = lp < L::kCHaloLanes;
+        const int lq = chv[h] ? lp : 0;
+        const int arr = lq / (2 * TY);
+        const int s = (lq / TY) & 1;
+        const int j = lq % TY;
+        const float* b = base[kCIn[0]];
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+          if (arr == i) b = base[kCIn[i]];
+        const int yrow = f3d_clampi(f3d_mir(y0 + j, RDIM), 0, RDIM - 1);
+        const int xc = s == 0 ? (left_face ? 0 : x0 - 4) : (right_face ? x0 + kLanes - 4 : x0 + kLanes);
+        chptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(row_b >> 2) + xc;
+      }
+    }
+    auto issue_c = [&](int p) {
+      if constexpr (FD) {
+        float* slot = &cring[(p - qs) & 1][0];
+        const int zz = f3d_mir(p, MDIM);
+        const unsigned poff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<unsigned>(zz - zb) * plane_b)));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+          for (int k = 0; k < NKC; ++k)
+            if (L::NRC % 4 == 0 || crowv[k]) dma16(base[kCIn[i]], crowb[k] + poff, slot + (i * L::NRC + 4 * k) * kLanes);
+        }
+#pragma unroll
+        for (int h = 0; h < NHC; ++h)
+          if (chv[h]) dma16_lane(chptr[h] + (poff >> 2), slot + L::kCHaloOff + h * 256);
+      }
+    };
     // prologue: planes qs-1, qs, qs+1 fill the three slots and must have landed before anybody reads
     issue(qs - 1);
     issue(qs);
     issue(qs + 1);
+    issue_c(qs);      // (a centre-only plane is needed as z+1 plane and as centre: never plane qs-1)
+    issue_c(qs + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ABL & 8) return;
@@ -377,11 +448,16 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       __syncthreads();  // B_q: the slots of planes q-1 and q have been read for the last time
       if (!(ABL & 1)) {
         if (q == qs && q + 2 <= p_last) issue(q + 2);  // steady state: issued one step ago
+        // FD: the centre-only plane q+2 goes into the slot of plane q, read for the last time before B_q (it is read only at the very
+        // start of step q-1), and must have landed at B_{q+1}: it is issued BEFORE plane q+3 of the ring, so the counted wait below
+        // -- everything but the youngest kPerPlane instructions -- covers it
         if (q + 3 <= p_last) {
+          issue_c(q + 2);
           issue(q + 3);
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::kPerPlane) : "memory");  // plane q+2 has landed, q+3 stays in flight
           continue;
         }
+        if (q + 2 <= p_last) issue_c(q + 2);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -437,28 +513,42 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     p.su = opaque(seedv); p.dv = opaque(seedv); p.dw = opaque(seedv); p.phi = opaque(seedv); p.ksi = opaque(seedv);
     p.fz = opaque(seedv); p.ft = opaque(seedv);
   };
-  auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi) __attribute__((always_inline)) {
+  // `cs` (FD, with_ksi only): the centre-only slot of the same plane; its rows start at y0-1, i.e. ring row j is centre row j-1
+  auto row_raw = [&](PlaneRegs& p, const float* slot, int j, bool with_ksi, const float* cs = nullptr) __attribute__((always_inline)) {
     if (ABL & 8) return fake_raw(p);
     const float* d = slot + j * kLanes + lane;
     constexpr int st = NJP * kLanes;
-    p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
-    p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
-    if (with_ksi) p.ksi = d[9 * st];
+    if (!FD) {
+      p.f0 = d[F0 * st];
+      p.f1 = d[F1 * st];
+    }
+    p.u = d[(U - SB) * st]; p.v = d[(V - SB) * st]; p.w = d[(Wf - SB) * st];
+    p.su = d[(DU - SB) * st]; p.dv = d[(DV - SB) * st]; p.dw = d[(DW - SB) * st]; p.phi = d[(PHI - SB) * st];
+    if (!FD && with_ksi) p.ksi = d[9 * st];
+    if (FD && !with_ksi) p.f0 = p.f1 = 0.f;   // neighbours' frame values are not looked at in FD builds
     if (FD && with_ksi) {
-      p.fz = d[10 * st];
-      p.ft = d[11 * st];
+      const float* c = cs + (j - 1) * kLanes + lane;
+      constexpr int ct = L::NRC * kLanes;
+      p.f0 = c[0 * ct]; p.f1 = c[1 * ct]; p.ksi = c[2 * ct]; p.fz = c[3 * ct]; p.ft = c[4 * ct];   // fx, fy, ksi, fz, ft
     }
   };
-  auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi) __attribute__((always_inline)) {
+  // column wave, own voxel (FD, with_ksi): centre-only halo pieces are indexed by CORE row, ring row j = core row + 2
+  auto halo_raw = [&](PlaneRegs& p, const float* slot, int s, int j, int e, bool with_ksi, const float* cs = nullptr) __attribute__((always_inline)) {
     if (ABL & 8) return fake_raw(p);
     const float* d = slot + L::kHaloOff + (s * NJ + j) * 4 + e;
     constexpr int st = 2 * NJ * 4;
-    p.f0 = d[F0 * st]; p.f1 = d[F1 * st]; p.u = d[U * st]; p.v = d[V * st]; p.w = d[Wf * st];
-    p.su = d[DU * st]; p.dv = d[DV * st]; p.dw = d[DW * st]; p.phi = d[PHI * st];
-    if (with_ksi) p.ksi = d[9 * st];
+    if (!FD) {
+      p.f0 = d[F0 * st];
+      p.f1 = d[F1 * st];
+    }
+    p.u = d[(U - SB) * st]; p.v = d[(V - SB) * st]; p.w = d[(Wf - SB) * st];
+    p.su = d[(DU - SB) * st]; p.dv = d[(DV - SB) * st]; p.dw = d[(DW - SB) * st]; p.phi = d[(PHI - SB) * st];
+    if (!FD && with_ksi) p.ksi = d[9 * st];
+    if (FD && !with_ksi) p.f0 = p.f1 = 0.f;
     if (FD && with_ksi) {
-      p.fz = d[10 * st];
-      p.ft = d[11 * st];
+      const float* c = cs + L::kCHaloOff + (s * TY + (j - 2)) * 4 + e;
+      constexpr int ct = 2 * TY * 4;
+      p.f0 = c[0 * ct]; p.f1 = c[1 * ct]; p.ksi = c[2 * ct]; p.fz = c[3 * ct]; p.ft = c[4 * ct];
     }
   };
 
@@ -489,8 +579,14 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       if (ABL & 8) {
         fake_raw(T);
       } else {
-        T.f0 = d[F0 * st]; T.f1 = d[F1 * st]; T.u = d[U * st]; T.v = d[V * st]; T.w = d[Wf * st];
-        T.su = d[DU * st]; T.dv = d[DV * st]; T.dw = d[DW * st]; T.phi = d[PHI * st];
+        if (!FD) {
+          T.f0 = d[F0 * st];
+          T.f1 = d[F1 * st];
+        } else {
+          T.f0 = T.f1 = 0.f;
+        }
+        T.u = d[(U - SB) * st]; T.v = d[(V - SB) * st]; T.w = d[(Wf - SB) * st];
+        T.su = d[(DU - SB) * st]; T.dv = d[(DV - SB) * st]; T.dw = d[(DW - SB) * st]; T.phi = d[(PHI - SB) * st];
       }
       nInr = {T.u, T.v, T.w};
       plane_finish(T);
@@ -529,6 +625,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     if (!(ABL & 8)) __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
     if (ABL & 4) return;
     const float* Sp = &ring[SLOT][0];
+    const float* Cp = &cring[FD ? ((q + 1 - qs) & 1) : 0][0];   // FD: centre-only inputs of plane q+1
     const bool do1 = q <= qe;
     const int b = q & 1;
 
@@ -541,7 +638,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       S3 rxm = {}, rxp = {};  // PAIR_SP: raw u, v, w of the x neighbours
       int vx, vy;
       if constexpr (CW) {
-        halo_raw(P, Sp, side, jc, e_near, true);
+        halo_raw(P, Sp, side, jc, e_near, true, Cp);
         plane_finish(P);
         const S3 router = nXr;
         const Face6 outer = nX;
@@ -563,7 +660,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
           rxp = rxm;
         }
       } else {
-        row_raw(P, Sp, jr, true);
+        row_raw(P, Sp, jr, true, Cp);
         plane_finish(P);
         const S3 rx = nXr;
         const Face6 xf = nX;
@@ -715,10 +812,10 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     constexpr bool CW = decltype(colw_c)::value;
     if constexpr (CW) {
       halo_raw(A, Sm, side, jc, e_near, false);
-      halo_raw(B, S0, side, jc, e_near, true);
+      halo_raw(B, S0, side, jc, e_near, true, &cring[0][0]);   // plane qs sits in centre slot 0
     } else {
       row_raw(A, Sm, jr, false);
-      row_raw(B, S0, jr, true);
+      row_raw(B, S0, jr, true, &cring[0][0]);
     }
     plane_finish(A);
     plane_finish(B);

@@ -47,7 +47,7 @@ def test_the_scanner_sees_a_premature_copy():
 # ---- k_pair8: the loader wave's DMA instructions, its counted wait and the barrier that publishes a plane --------------------
 
 # (MODE, TY, FD, YM): two sweeps / sweep + phi/ksi on 4-, 8-, 12-row tiles; on frame derivatives; marching along y (thin volumes)
-SHIPPED_PAIR8 = ([(mode, ty, 0, 0) for mode in (0, 1) for ty in (4, 8, 12)] + [(0, 8, 1, 0), (1, 8, 1, 0)] +
+SHIPPED_PAIR8 = ([(mode, ty, 0, 0) for mode in (0, 1) for ty in (4, 8, 12)] + [(mode, ty, 1, 0) for mode in (0, 1) for ty in (8, 12)] +
                  [(mode, ty, 0, 1) for mode in (0, 1) for ty in (4, 5, 8)])
 
 
@@ -71,6 +71,7 @@ def test_pair8_loader_waits_barriers_and_scratch(tmp_path):
     for mode, ty, fd, ym in SHIPPED_PAIR8:
         assert tool.pair8_per_plane(ty, fd) <= 63
     assert tool.pair8_per_plane(12, 0) == 45 and tool.pair8_per_plane(8, 0) == 34 and tool.pair8_per_plane(4, 0) == 23
+    assert tool.pair8_per_plane(12, 1) == 32 and tool.pair8_centre_per_plane(12, 1) == 22 and tool.pair8_centre_per_plane(12, 0) == 0
 
     # the mutant: the same sources with the steady-state wait one short
     src_dir = os.path.join(ROOT, "cuda-flow3d_amd", "csrc")

@@ -32,7 +32,8 @@ where a DMA instruction sits (every piece of a plane has at least one live lane 
   P3  every counted wait `s_waitcnt vmcnt(N > 0)` has N = kPerPlane of the instantiation (NA * ceil((TY + 4) / 4) row pieces +
       ceil(NA * 2 * (TY + 4) / 64) halo pieces, NA = 10 or 12) <= 63 (vmcnt is a 6-bit counter), and on every path from the closest
       workgroup barrier to the wait exactly N or 2 N DMA instructions are issued (one plane; two in the first step of a chunk)
-      and no other vector-memory instruction (it would be counted by vmcnt too);
+      and no other vector-memory instruction (it would be counted by vmcnt too); the frame-derivative builds issue the pieces of a
+      centre-only plane in front of each ring plane, and the count includes them;
   P4  no DMA instruction reaches a barrier or the end of the program without a vmcnt wait behind it (a plane published to the
       compute waves before it has landed);
   P5  no ds_read is reachable from the kernel entry without crossing a workgroup barrier (the prologue planes);
@@ -160,9 +161,19 @@ def pair8_params(name):
 
 
 def pair8_per_plane(ty, fd):
-    na = 12 if fd else 10
+    """DMA instructions per plane of the three-slot ring: the count the steady-state wait must carry.  The frame-derivative builds
+    keep only their seven stencilled inputs there"""
+    na = 7 if fd else 10
     nj = ty + 4
     return na * ((nj + 3) // 4) + (na * 2 * nj + 63) // 64
+
+
+def pair8_centre_per_plane(ty, fd):
+    """frame-derivative builds: DMA instructions per plane of the two-slot ring of the five centre-only inputs (rows y0-1 .. y0+TY and
+    the halo columns of the core rows); they are issued in front of the ring's plane, so they add to what a barrier-to-wait path issues"""
+    if not fd:
+        return 0
+    return 5 * ((ty + 2 + 3) // 4) + (5 * 2 * ty + 63) // 64
 
 
 def instructions(body):
@@ -234,8 +245,9 @@ def vmcnt_of(op, rest):
     return int(m.group(1)) if m else None
 
 
-def check_pair8(body, per_plane):
-    """violations of P2 .. P6 in one k_pair8 body (list of assembly lines); per_plane = the wait count the source must carry"""
+def check_pair8(body, per_plane, centre=0):
+    """violations of P2 .. P6 in one k_pair8 body (list of assembly lines); per_plane = the wait count the source must carry,
+    centre = DMA instructions of a centre-only plane issued in front of every ring plane (frame-derivative builds)"""
     ins = instructions(body)
     bad = []
     n = len(ins)
@@ -288,9 +300,9 @@ def check_pair8(body, per_plane):
                 waits_reached.add(i)
                 if cnt != per_plane or cnt > 63:
                     report("P3", ln, f"s_waitcnt vmcnt({cnt}): the instantiation issues {per_plane} pieces per plane (and vmcnt holds 63)")
-                elif count not in (cnt, 2 * cnt):
+                elif count not in (cnt + centre, 2 * cnt + centre):
                     report("P3", ln, f"s_waitcnt vmcnt({cnt}) is reached with {count} DMA instructions issued since the barrier "
-                                     f"(wants {cnt} or {2 * cnt}: one plane stays in flight)")
+                                     f"(wants {cnt + centre} or {2 * cnt + centre}: one plane stays in flight)")
                 elif other:
                     report("P3", ln, f"another vector-memory instruction sits between the barrier and s_waitcnt vmcnt({cnt}): vmcnt counts it too")
             count, other = 0, False
@@ -395,7 +407,7 @@ def run_pair8(path=None):
         prm = pair8_params(name)
         if prm is None or prm[2] != 0:
             continue        # ablation builds (ABL != 0): timing experiments with wrong results, never launched by default
-        report[name] = check_pair8(body, pair8_per_plane(prm[1], prm[3]))
+        report[name] = check_pair8(body, pair8_per_plane(prm[1], prm[3]), pair8_centre_per_plane(prm[1], prm[3]))
     return report, {k: v for k, v in scratch.items() if (pair8_params(k) or (0, 0, 1, 0))[2] == 0}
 
 
