@@ -1708,14 +1708,16 @@ int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], siz
   a.eps_d = eps_d;
   const int kid = with_weights ? F3D_K_SWEEP_PHI_KSI : F3D_K_SWEEP2;
   f3d::prof_begin(kid, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
-  // 12-row tiles where the round model prefers them (the centre-only inputs have a two-slot ring of their own, which is what
-  // makes twelve inputs fit the LDS of a CU with 16 waves), 8-row tiles elsewhere (levels small enough for 4-row tiles too)
-  const bool twelve = pair8_rows(g) == 12;
+  // the tile height the round model picks for the level, as for the frame builds (the centre-only inputs have a two-slot ring of their
+  // own, which is what makes twelve inputs fit the LDS of a CU with 16 waves)
+  const int rows = pair8_rows(g);
   if (with_weights) {
-    if (twelve) launch_pair8<PAIR_SP, 12, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+    if (rows == 12) launch_pair8<PAIR_SP, 12, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+    else if (rows == 4) launch_pair8<PAIR_SP, 4, true>(a, g, tuning().zchunk, tuning().xcd_remap);
     else launch_pair8<PAIR_SP, 8, true>(a, g, tuning().zchunk, tuning().xcd_remap);
   } else {
-    if (twelve) launch_pair8<PAIR_SS, 12, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+    if (rows == 12) launch_pair8<PAIR_SS, 12, true>(a, g, tuning().zchunk, tuning().xcd_remap);
+    else if (rows == 4) launch_pair8<PAIR_SS, 4, true>(a, g, tuning().zchunk, tuning().xcd_remap);
     else launch_pair8<PAIR_SS, 8, true>(a, g, tuning().zchunk, tuning().xcd_remap);
   }
   f3d::prof_end(kid);

@@ -47,7 +47,7 @@ def test_the_scanner_sees_a_premature_copy():
 # ---- k_pair8: the loader wave's DMA instructions, its counted wait and the barrier that publishes a plane --------------------
 
 # (MODE, TY, FD, YM): two sweeps / sweep + phi/ksi on 4-, 8-, 12-row tiles; on frame derivatives; marching along y (thin volumes)
-SHIPPED_PAIR8 = ([(mode, ty, 0, 0) for mode in (0, 1) for ty in (4, 8, 12)] + [(mode, ty, 1, 0) for mode in (0, 1) for ty in (8, 12)] +
+SHIPPED_PAIR8 = ([(mode, ty, 0, 0) for mode in (0, 1) for ty in (4, 8, 12)] + [(mode, ty, 1, 0) for mode in (0, 1) for ty in (4, 8, 12)] +
                  [(mode, ty, 0, 1) for mode in (0, 1) for ty in (4, 5, 8)])
 
 
