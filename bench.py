@@ -26,6 +26,7 @@ For N > 1 the volume is z-slab partitioned over one rank per GPU and the default
 in: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment), or
 bare -- `python bench.py --gpus N` starts the N rank processes itself (launch_ranks: the parent never loads the native
 library or touches the GPU, forwards rank 0's JSON line, and exits non-zero if any rank fails or hangs).
+F3D_SLAB_EXCHANGE=stage in the environment runs the other (bit-identical) halo-exchange order; the line says which one ran.
 """
 import argparse
 import ctypes as C
@@ -524,6 +525,10 @@ def run_multi(args):
                                       "n <= 4 outer iterations)"
                                       + (" -- REHEARSAL: shared-memory transport, ranks share devices"
                                          if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
+            # which of the two bit-identical exchange orders ran: one message of K + 1 planes per outer iteration with
+            # the sweeps on widened windows (default), or one message per solver stage (F3D_SLAB_EXCHANGE=stage) -- to be A/B'd on hardware
+            "exchange_order": "per solver stage (2 / 1 / 3 planes)" if os.environ.get("F3D_SLAB_EXCHANGE") == "stage"
+                              else "per outer iteration (K + 1 planes, widened windows)",
             "launched_by": "bench.py itself (one child process per rank)" if os.environ.get("F3D_BENCH_LAUNCHED") == "1"
                            else "an external launcher (RANK / WORLD_SIZE were set)",
             # the communicator as the transport reports it: `rccl_ranks` is ncclCommCount's answer on rank 0, not WORLD_SIZE
