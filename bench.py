@@ -326,7 +326,8 @@ def run_single(args):
     fused = s2_n > 0
     pair_kernel = "k_pair8" if os.environ.get("F3D_PAIR8", "1") != "0" else "k_sweep7"
     if fused:   # dominant kernel: the fused pair
-        dom_name, dom_b, dom_ms, dom_n, dom_vox = f"{pair_kernel} (two fused solver sweeps, f3d_solve_sweep2)", 2 * SWEEP_BYTES_PER_VOXEL, s2_ms, s2_n, s2_vox
+        fd_note = ", frame derivatives read: f3d_solve_sweep2_fd" if os.environ.get("F3D_FRAME_DERIVATIVES", "1") != "0" and pair_kernel == "k_pair8" else ", f3d_solve_sweep2"
+        dom_name, dom_b, dom_ms, dom_n, dom_vox = f"{pair_kernel} (two fused solver sweeps{fd_note})", 2 * SWEEP_BYTES_PER_VOXEL, s2_ms, s2_n, s2_vox
         fin_ms, fin_n, fin_vox = f2_ms, f2_n, f2_vox
     else:
         dom_name, dom_b, dom_ms, dom_n, dom_vox = "k_sweep6 (solver sweep, f3d_solve_sweep)", SWEEP_BYTES_PER_VOXEL, s1_ms, s1_n, s1_vox
@@ -374,7 +375,10 @@ def run_single(args):
     }
     if not events:
         out["roofline"]["note"] = "a profiler is attached: no HIP-event bracket in this run, kernel times come from its trace"
-    traffic = measured_traffic(dom_name.split()[0])
+    # the record of the kernel that ran: the resident operator reads frame derivatives (F3D_FRAME_DERIVATIVES, on by default) wherever
+    # its four extra volumes fit, i.e. the _fd builds of the fused launches
+    fd_on = os.environ.get("F3D_FRAME_DERIVATIVES", "1") != "0" and fused and pair_kernel == "k_pair8"
+    traffic = measured_traffic("k_pair8_fd" if fd_on else dom_name.split()[0])
     if traffic:
         tsize = traffic.pop("_size", 512)
         out["roofline"].update(traffic)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
 (f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
-   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|phi|both]
+   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|phi|both|bothfd|all]
 """
 import argparse
 import ctypes as C
@@ -48,17 +48,17 @@ def main():
     hip.f3d_prof_reset()
     hip.f3d_prof_enable(1)
     for _ in range(a.reps):
-        if a.kernel in ("phi", "both"):
+        if a.kernel in ("phi", "both", "all"):
             pkg.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, 0.001, 0.001, phi, ksi, None))
-        if a.kernel in ("sweep", "both"):
+        if a.kernel in ("sweep", "both", "all"):
             pkg.check(hip.f3d_solve_sweep(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
-        if a.kernel in ("sweep2", "both"):
+        if a.kernel in ("sweep2", "both", "all"):
             pkg.check(hip.f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
-        if a.kernel in ("sweep2fd",):
+        if a.kernel in ("sweep2fd", "bothfd", "all"):
             pkg.check(hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, *out, None))
-        if a.kernel in ("sweeppkfd",):
+        if a.kernel in ("sweeppkfd", "bothfd", "all"):
             pkg.check(hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
-        if a.kernel in ("sweeppk", "both"):
+        if a.kernel in ("sweeppk", "both", "all"):
             pkg.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
     pkg.sync()
     # sweep2: two sweeps of algorithmic work (2 x 52 B per voxel) per launch

@@ -11,10 +11,13 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -- $R/tools/lab/bin/stream_lab > $O/cal_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/k_fetch -- python3 $R/tools/kbench.py --size 512 --reps 3 > $O/k_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/k_write -- python3 $R/tools/kbench.py --size 512 --reps 3 > $O/k_write.log 2>&1
+# the frame-derivative builds of the two fused launches (what the resident operator runs by default since round 3)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fd_fetch -- python3 $R/tools/kbench.py --size 512 --reps 3 --kernel bothfd > $O/fd_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fd_write -- python3 $R/tools/kbench.py --size 512 --reps 3 --kernel bothfd > $O/fd_write.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
-for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
+for d in ("cal_fetch", "cal_write", "k_fetch", "k_write", "fd_fetch", "fd_write"):
     f = glob.glob("$O/" + d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -23,6 +26,10 @@ for d in ("cal_fetch", "cal_write", "k_fetch", "k_write"):
             if key in n:
                 if key.startswith("k_pair8"):
                     key = "k_pair8" if key.endswith("0") else "k_pair8_sweep_phi_ksi"
+                    # k_pair8<MODE, TY, ABL, FD, YM>: the fourth template argument tells the frame-derivative builds apart
+                    m = __import__("re").search(r"k_pair8<\d+, \d+, \d+, (true|false)", n) or __import__("re").search(r"k_pair8ILi\d+ELi\d+ELi\d+ELb([01])", n)
+                    if m and m.group(1) in ("true", "1"):
+                        key += "_fd"
                 if key == "k_flat":
                     key = "k_flat<float4>" if "float4" in n or "HIP_vector" in n else "k_flat<float>"
                 agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -39,7 +46,8 @@ res["_solver_source_sha16"] = bench.solver_source_stamp()
 json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
 # the record bench.py reads (profiles/rNN_pmc_traffic.json): HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
 S = 512
-alg = {"k_pair8": 104.0, "k_pair8_sweep_phi_ksi": 92.0, "k_sweep7": 104.0, "k_sweep6": 52.0, "k_phiksi6": 40.0}
+alg = {"k_pair8": 104.0, "k_pair8_sweep_phi_ksi": 92.0, "k_pair8_fd": 104.0, "k_pair8_sweep_phi_ksi_fd": 92.0, "k_sweep7": 104.0,
+       "k_sweep6": 52.0, "k_phiksi6": 40.0}
 out = {"_note": "HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                 "separate passes over tools/kbench.py --size 512 (tools/pmc_traffic.sh); both counters are in KiB; FETCH_SIZE is doubled as "
                 "MI355X_MICROARCH.md prescribes for gfx950, and the same run calibrates it on tools/lab/stream_lab (k_flat reads 10 x 512 MiB, "
@@ -54,4 +62,4 @@ for k, b in alg.items():
 json.dump(out, open("$O/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 PY
-rm -rf $O/cal_fetch $O/cal_write $O/k_fetch $O/k_write
+rm -rf $O/cal_fetch $O/cal_write $O/k_fetch $O/k_write $O/fd_fetch $O/fd_write

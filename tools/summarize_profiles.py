@@ -33,7 +33,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         kn = r["Kernel_Name"]
-        for name, key in (("k_pair8<0", "k_pair8 (two sweeps)"), ("k_pair8<1", "k_pair8 (sweep + phi/ksi)"), ("k_sweep7", "k_sweep7"),
+        fd = ", true, " in kn and "k_pair8<" in kn   # k_pair8<MODE, TY, ABL, FD, YM>
+        for name, key in (("k_pair8<0", "k_pair8 (two sweeps%s)" % (", frame derivatives" if fd else "")),
+                          ("k_pair8<1", "k_pair8 (sweep + phi/ksi%s)" % (", frame derivatives" if fd else "")), ("k_sweep7", "k_sweep7"),
                           ("k_sweep6", "k_sweep6"), ("k_phiksi6", "k_phiksi6")):
             if name in kn:
                 agg[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
