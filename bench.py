@@ -360,7 +360,10 @@ def run_single(args):
             "traffic": None, "launches": dom_n, "avg_launch_us": round(dom_ms / dom_n * 1e3, 3) if dom_n else None,
             "avg_voxels_per_launch": round(dom_vox / dom_n, 1) if dom_n else None,
             "finest_level": {"achieved": round(finest, 1), "frac": round(finest / HBM_PEAK_GBS, 4), "launches": fin_n,
-                             "avg_launch_us": round(fin_ms / fin_n * 1e3, 3) if fin_n else None},
+                             "avg_launch_us": round(fin_ms / fin_n * 1e3, 3) if fin_n else None,
+                             "note": "algorithmic bytes of TWO sweeps per launch (SURVEY.md 8d) over a launch that moves the bytes of one: "
+                                     "this fraction is not bounded by 1; hbm_frac below prices the same launch in the bytes the memory "
+                                     "system moved"},
             "all_solver_launches": {"achieved": round(all_sweeps, 1), "frac": round(all_sweeps / HBM_PEAK_GBS, 4),
                                     "note": "every solver launch at its algorithmic bytes (52 B per voxel-sweep, 40 B per voxel of "
                                             "phi/ksi), fused or not; the non-dominant kernels are timed in one extra untimed step"},
