@@ -1397,7 +1397,9 @@ PairArgs pair_args(const SolveArgs& a)
 // F3D_PAIR8_TY=8 / 12 pins one, F3D_PAIR8_STEP12 = cost of a 16-wave step in % of a 12-wave one (timing experiments)
 int pair8_rows(const F3dGeo& g)
 {
-  static const int forced = std::getenv("F3D_PAIR8_TY") ? std::atoi(std::getenv("F3D_PAIR8_TY")) : 0;
+  // read per call: the tests force every tile height on small shapes (a getenv per launch is ~50 ns)
+  const char* forced_env = std::getenv("F3D_PAIR8_TY");
+  const int forced = forced_env ? std::atoi(forced_env) : 0;
   static const long step12 = std::getenv("F3D_PAIR8_STEP12") ? std::atol(std::getenv("F3D_PAIR8_STEP12")) : 128;
   if (forced == 4 || forced == 8 || forced == 12) return forced;
   const long c8 = pair8_plan(g, 8).cost * 100, c12 = pair8_plan(g, 12).cost * step12;

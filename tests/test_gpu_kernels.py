@@ -805,3 +805,43 @@ def test_the_short_road_to_the_weights_is_exact_for_every_float(f3d):
     in_range = 0x71800000 - 0x0d800000 + 1
     assert checked.value + excluded.value == 2 ** 32
     assert checked.value == in_range - 200, (checked.value, in_range)    # 100 binades x 2 all-ones roots are left to the IEEE road
+
+
+@pytest.mark.parametrize("ty", ["4", "8", "12"])
+@pytest.mark.parametrize("dims,cdims", [((70, 29, 11), (128, 32, 12)), ((129, 13, 9), (192, 16, 9)), ((40, 50, 6), (64, 50, 6))])
+def test_every_tile_height_of_the_fused_kernels(f3d, oracle, dims, cdims, ty, monkeypatch):
+    """The launchers pick the tile height (4, 8 or 12 core rows: 8, 12 or 16 waves) per level from a cost model, and on shapes this
+    small they never pick twelve.  F3D_PAIR8_TY pins it: every height, frames and frame derivatives (the 12-row frame-derivative build
+    keeps its five centre-only inputs in a two-slot ring of their own), rows that do not divide the height, against the oracle."""
+    monkeypatch.setenv("F3D_PAIR8_TY", ty)
+    rng = np.random.default_rng(hash((dims, ty)) % 2**32)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    alpha, eps_s, eps_d = 7.5, 0.001, 0.002
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s1, dims, h, eps_s, eps_d)
+    dev = Dev(f3d, cdims)
+    hip = f3d.hip()
+    box = lambda p: dev.get(p)[:D, :H, :W]
+    cut = lambda a: a[:D, :H, :W]
+    try:
+        ptr = [dev.put(a) for a in arrs]
+        phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+        fd = [dev.out() for _ in range(4)]
+        f3d.check(hip.f3d_frame_derivatives(ptr[0], ptr[1], W, H, D, *h, *fd, None))
+        for label, two, one in (("frames", lambda o: hip.f3d_solve_sweep2(*ptr, phi, ksi, W, H, D, *h, alpha, *o, None),
+                                 lambda o: hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *o, None)),
+                                ("derivatives", lambda o: hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, alpha, *o, None),
+                                 lambda o: hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *o, None))):
+            outs = [dev.out() for _ in range(5)]
+            f3d.check(two(outs[:3]))
+            for name, g, e in zip("uvw", outs, s2):
+                assert bit_same(box(g), cut(e)), f"{ty} rows, {label}, two sweeps: d{name}"
+            f3d.check(one(outs))
+            for name, g, e in zip(("du", "dv", "dw", "phi", "ksi"), outs, list(s1) + [phi_n, ksi_n]):
+                assert bit_same(box(g), cut(e)), f"{ty} rows, {label}, sweep + phi/ksi: {name}"
+    finally:
+        dev.close()
