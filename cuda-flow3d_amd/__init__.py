@@ -77,7 +77,7 @@ def hip():
     sig = {
         "f3d_init": [C.c_int], "f3d_shutdown": [], "f3d_is_initialized": [], "f3d_device_count": [C.POINTER(C.c_int)],
         "f3d_crash_maps_enable": [C.c_char_p],
-        "f3d_lane_create": [C.POINTER(C.c_void_p)], "f3d_lane_make_current": [C.c_void_p], "f3d_lane_is_private": [],
+        "f3d_lane_create": [C.POINTER(C.c_void_p)], "f3d_lane_make_current": [C.c_void_p], "f3d_lane_is_private": [], "f3d_lane_get_current": [C.POINTER(C.c_void_p)],
         "f3d_lane_destroy": [C.c_void_p],
         "f3d_selftest_weights": [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
                                  C.POINTER(C.c_uint)],

@@ -1,6 +1,7 @@
 // libf3d_hip.so runtime: context, stream, pitched memory, 3-D copies, events, per-kernel timing.
 // Replaces the CUDA driver-API uses listed in SURVEY.md 2c (cuInit ... cuEventElapsedTime); each entry
 // point cites its reference call site in include/f3d.h.
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -244,6 +245,14 @@ int f3d_lane_make_current(f3d_lane lane)
 }
 
 int f3d_lane_is_private(void) { return t_lane ? 1 : 0; }
+
+int f3d_lane_get_current(f3d_lane* lane)
+{
+  if (!lane) return f3d::fail("f3d_lane_get_current: null argument");
+  // f3d_lane_s holds nothing but its Lane: the handle is the address of that member
+  *lane = t_lane ? reinterpret_cast<f3d_lane>(reinterpret_cast<char*>(t_lane) - offsetof(f3d_lane_s, lane)) : nullptr;
+  return 0;
+}
 
 int f3d_lane_destroy(f3d_lane lane)
 {

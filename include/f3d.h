@@ -70,6 +70,8 @@ typedef struct f3d_lane_s* f3d_lane;
 int f3d_lane_create(f3d_lane* lane);
 int f3d_lane_make_current(f3d_lane lane);   /* for the calling thread; NULL = back to the default lane */
 int f3d_lane_is_private(void);              /* 1 when the calling thread is on a lane of its own */
+int f3d_lane_get_current(f3d_lane* lane);   /* the calling thread's lane (NULL = the default one): code that borrows the thread for
+                                               another lane puts this one back afterwards */
 int f3d_lane_destroy(f3d_lane lane);        /* waits for the lane's stream first */
 
 /* Diagnostics (no reference counterpart): from now on a fatal signal (SIGSEGV, SIGBUS, SIGILL, SIGFPE, SIGABRT) first writes

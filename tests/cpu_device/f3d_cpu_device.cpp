@@ -446,6 +446,7 @@ struct f3d_lane_s { int unused; };
 int f3d_lane_create(f3d_lane* lane) { *lane = new f3d_lane_s(); return 0; }
 int f3d_lane_make_current(f3d_lane) { return 0; }
 int f3d_lane_is_private(void) { return 0; }
+int f3d_lane_get_current(f3d_lane* lane) { *lane = nullptr; return 0; }
 int f3d_lane_destroy(f3d_lane lane) { delete lane; return 0; }
 int f3d_crash_maps_enable(const char*) { return 0; }
 int f3d_selftest_weights(unsigned, unsigned, unsigned long long* checked, unsigned long long* excluded, unsigned long long* mismatches, unsigned* first)
