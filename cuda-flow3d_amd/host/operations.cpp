@@ -376,8 +376,9 @@ void CudaOperationSolve::Execute(OperationParameters& params)
     std::printf(" % 3.0f%%", 0.f);
   }
 
-  // increments start from zero at every level: current width, every row of the container (reference :183-188)
-  const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+  // increments start from zero at every level: current width, every row of the planes the level has (the reference clears the
+  // planes beyond them too, :183-188; nothing reads those -- rows and planes mirror by address inside the level's box)
+  const size_t rows = dev_container_size_.height * std::min(data_size.depth, dev_container_size_.depth);
   const size_t row_bytes = data_size.width * sizeof(float);
   CheckDeviceError(f3d_memset2d(*du_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
   CheckDeviceError(f3d_memset2d(*dv_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
