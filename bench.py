@@ -303,9 +303,11 @@ def run_single(args):
     f1_ms, f1_n, f1_vox = prof(1, S ** 3)
     pk_ms, pk_n, pk_vox = prof(0, 0)
     sp_ms, sp_n, sp_vox = prof(3, 0)          # last sweep of an outer iteration fused with the next phi/ksi
+    spf_ms, spf_n, spf_vox = prof(3, S ** 3)  # ... on the finest level alone
     # the kernels of the extra step ran once, the dominant one `steps` times: put them on the same footing
     pk_ms, pk_n, pk_vox = pk_ms * extra, pk_n * extra, pk_vox * extra
     sp_ms, sp_n, sp_vox = sp_ms * extra, sp_n * extra, sp_vox * extra
+    spf_ms, spf_n, spf_vox = spf_ms * extra, spf_n * extra, spf_vox * extra
     if dominant == 2:
         s1_ms, s1_n, s1_vox = s1_ms * extra, s1_n * extra, s1_vox * extra
         f1_ms, f1_n, f1_vox = f1_ms * extra, f1_n * extra, f1_vox * extra
@@ -369,7 +371,11 @@ def run_single(args):
                                             "phi/ksi), fused or not; the non-dominant kernels are timed in one extra untimed step"},
             "sweep_phi_ksi": {"kernel": "k_pair8 (last sweep + next phi/ksi, f3d_solve_sweep_phi_ksi)",
                               "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, sp_vox, sp_ms), 1),
-                              "launches": sp_n},
+                              "launches": sp_n,
+                              "finest_level": {"achieved": round(gbs(SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, spf_vox, spf_ms), 1),
+                                               "frac": round(gbs(SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, spf_vox, spf_ms) / HBM_PEAK_GBS, 4),
+                                               "launches": spf_n,
+                                               "avg_launch_us": round(spf_ms / spf_n * 1e3, 3) if spf_n else None}},
             "single_sweep": {"kernel": "k_sweep6", "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL, s1_vox, s1_ms), 1),
                              "launches": s1_n},
             "phi_ksi": {"kernel": "k_phiksi6", "achieved": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms), 1),
