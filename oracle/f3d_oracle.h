@@ -7,15 +7,23 @@
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   - level schedule (orc_max_warp_level / orc_level_geometry): PINNED against the reference's own
- *     src/optical_flow/optical_flow_base.cpp compiled verbatim into oracle/_ref/ (tests/test_oracle_ref.py).
+ *     src/optical_flow/optical_flow_base.cpp compiled verbatim into oracle/_ref/ (tests/test_host_logic.py).
  *   - RAW U8/F32 volume I/O: PINNED against the reference's src/data_types/data3d.cpp in oracle/_ref/.
  *   - warp (orc_warp) and flow statistics (orc_flow_stats): PINNED against the reference's own host implementations
  *     (partial_data/cuda_operation_register_p.cpp:96-139, cuda_operation_stat_p.cpp:85-104) compiled in place into
  *     oracle/_ref/libf3d_ref_ops.so (tests/test_oracle.py).
- *   - remaining kernel numerics (resample, phi/ksi, sweep, median, Gaussian, add): PARITY UNPINNED in this
- *     repo.  The reference ships no tests, golden vectors or fixtures for them, and its kernels are CUDA
- *     (.cu, need nvcc + the CUDA device runtime, absent here) so they cannot be built without writing
- *     stand-ins.  Each function below cites the reference file:line it restates.
+ *   - kernel numerics (resample A.1, phi/ksi A.3, sweep A.4, median A.5, Gaussian A.6, and the warp A.2 once more): PINNED ON THE
+ *     GPU against the reference's own kernels.  The reference ships no tests, golden vectors or fixtures for them and no nvcc
+ *     exists here, but its entire_data .cu files are plain CUDA C that hipcc accepts as HIP source unmodified: oracle/Makefile
+ *     compiles solve_3d.cu, median_3d.cu, resample_3d.cu, registration_3d.cu and convolution_3d.cu where they lie into
+ *     oracle/_ref/*.hsaco (gfx950, contraction off, IEEE division and square root; the recipe's comment names the one
+ *     include-guard definition it needs and why nothing is written in place of any header), tests/ref_kernels.py launches them
+ *     with the reference operators' block sizes, shared-memory sizes and argument lists, and
+ *     tests/test_gpu_reference_kernels.py holds reference == oracle and product == reference bit for bit on 59 cases.
+ *     What that does not cover: add_3d.cu (one line, a[i] += b[i]; it includes NVIDIA's vector_types.h by name), whether nvcc
+ *     would have fused multiply-adds (this repository defines the reference's numbers with contraction off), and
+ *     the host-side operator code around the kernels (CUDA driver API; restated, file:line cited).
+ *     Each function below cites the reference file:line it restates.
  *
  * Layout convention (reference IND macro, src/kernels/solve_3d.cu:26): a "container" is a pitched
  * array addressed ((z - z_base) * Hc + y) * pitch_f + x, Hc = container height, pitch_f = row pitch

@@ -197,3 +197,31 @@ def test_residual_stats_match_numpy(oracle):
         assert mx == np.abs(d).max()
         assert abs(ssq - (d.astype(np.float64) ** 2).sum()) <= 1e-12 * ssq
         assert abs(sab - np.abs(d).astype(np.float64).sum()) <= 1e-12 * sab
+
+
+def test_the_reference_kernels_are_built_from_the_reference_tree():
+    """oracle/_ref/*.hsaco (tests/ref_kernels.py, tests/test_gpu_reference_kernels.py): code objects for gfx950 holding the
+    reference's kernels under the reference's names, made by oracle/Makefile from the .cu files where they lie -- here, where
+    /root/reference exists, by running the recipe; on a box without the tree the prebuilt files are looked at as they are."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ref_kernels
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.isdir("/root/reference/src/kernels") and os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-C", os.path.join(root, "oracle"), "ref"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert ref_kernels.available()
+    elif not ref_kernels.available():
+        pytest.skip("oracle/_ref/*.hsaco not built (no /root/reference here)")
+    names = {"solve_3d": [b"compute_phi_ksi_3d", b"solve_3d"], "median_3d": [b"median_3d"], "registration_3d": [b"registration_3d"],
+             "resample_3d": [b"resample_x_3d", b"resample_y_3d", b"resample_z_3d"],
+             "convolution_3d": [b"convolutionRowsKernel", b"convolutionColumnsKernel", b"convolutionSlicesKernel", b"c_Kernel"]}
+    for module, symbols in names.items():
+        blob = open(os.path.join(ref_kernels.REF_DIR, module + ".hsaco"), "rb").read()
+        assert blob[:4] == b"\x7fELF" or blob.startswith(b"__CLANG_OFFLOAD_BUNDLE__"), module   # a code object or a bundle of one
+        assert b"gfx950" in blob, module
+        for s in symbols + [b"container_size"]:
+            assert s in blob, (module, s)
+    # nothing of the reference's text is kept in the repository: the recipe names the sources by path
+    recipe = open(os.path.join(root, "oracle", "Makefile")).read()
+    assert "$(REF)/src/kernels/%.cu" in recipe and "-D__DEVICE_LAUNCH_PARAMETERS_H__" in recipe
