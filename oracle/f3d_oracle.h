@@ -15,14 +15,15 @@
  *   - kernel numerics (resample A.1, phi/ksi A.3, sweep A.4, median A.5, Gaussian A.6, and the warp A.2 once more): PINNED ON THE
  *     GPU against the reference's own kernels.  The reference ships no tests, golden vectors or fixtures for them and no nvcc
  *     exists here, but its entire_data .cu files are plain CUDA C that hipcc accepts as HIP source unmodified: oracle/Makefile
- *     compiles solve_3d.cu, median_3d.cu, resample_3d.cu, registration_3d.cu and convolution_3d.cu where they lie into
- *     oracle/_ref/*.hsaco (gfx950, contraction off, IEEE division and square root; the recipe's comment names the one
- *     include-guard definition it needs and why nothing is written in place of any header), tests/ref_kernels.py launches them
+ *     compiles the six of them (solve, median, resample, registration, convolution, add) where they lie into
+ *     oracle/_ref/*.hsaco (gfx950, contraction off, IEEE division and square root; the recipe's comment names the two
+ *     include-guard definitions it needs and why nothing is written in place of any header), tests/ref_kernels.py launches them
  *     with the reference operators' block sizes, shared-memory sizes and argument lists, and
- *     tests/test_gpu_reference_kernels.py holds reference == oracle and product == reference bit for bit on 59 cases.
- *     What that does not cover: add_3d.cu (one line, a[i] += b[i]; it includes NVIDIA's vector_types.h by name), whether nvcc
- *     would have fused multiply-adds (this repository defines the reference's numbers with contraction off), and
- *     the host-side operator code around the kernels (CUDA driver API; restated, file:line cited).
+ *     tests/test_gpu_reference_kernels.py holds reference == oracle and product == reference bit for bit, kernel by kernel and
+ *     for whole pyramid solves driven on the reference's kernels (67 cases).
+ *     What that does not cover: whether nvcc would have fused multiply-adds (this repository defines the reference's numbers
+ *     with contraction off), and the host-side operator code around the kernels (CUDA driver API; restated,
+ *     file:line cited).
  *     Each function below cites the reference file:line it restates.
  *
  * Layout convention (reference IND macro, src/kernels/solve_3d.cu:26): a "container" is a pitched

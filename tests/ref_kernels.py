@@ -11,6 +11,7 @@ hipModuleGetGlobal the way the operators use cuModuleGetGlobal:
     registration_3d                cuda_operation_registration.cpp:105-131       block 16 x 8 x 4
     resample_{x,y,z}_3d            cuda_operation_resample.cpp:108-175           block 16 x 8 x 8
     convolution{Rows,Columns,Slices}Kernel   cuda_operation_convolution.cpp:190-343    blocks 16x4x4 / 4x16x4 / 4x4x16, 4 result + 2 halo steps
+    add_3d                         cuda_operation_add.cpp:81-100                 block 16 x 8 x 4
 
 Only tests import this (the files travel to the GPU box prebuilt; /root/reference does not exist there).  Nothing of the product
 depends on it."""
@@ -19,7 +20,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
-MODULES = ("solve_3d", "median_3d", "registration_3d", "resample_3d", "convolution_3d")
+MODULES = ("solve_3d", "median_3d", "registration_3d", "resample_3d", "convolution_3d", "add_3d")
 
 
 def available():
@@ -129,6 +130,12 @@ class RefKernels:
             shared = block[0] * block[1] * block[2] * (4 + 2) * 4
             args = [C.c_uint64(b), C.c_uint64(a)] + [C.c_int(d) for d in dims] + [C.c_int(pitch), C.c_int(radius)]
             self.launch("convolution_3d", kernel, self._grid(dims, block, steps), block, shared, args)
+
+    # ---- cuda_operation_add.cpp -----------------------------------------------------------------------------------------------
+    def add(self, a, b, dims):
+        block = (16, 8, 4)
+        args = [C.c_uint64(a), C.c_uint64(b)] + [C.c_size_t(d) for d in dims]
+        self.launch("add_3d", "add_3d", self._grid(dims, block), block, 0, args)
 
     def close(self):
         for mod in self.mods.values():

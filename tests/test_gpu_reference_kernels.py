@@ -176,3 +176,179 @@ def test_gaussian(f3d, oracle, rig, dims, sigma):
     op.execute(dev_input=pin, dev_output=p_out, dev_temp=p_tmp, data_size=dims, gaussian_sigma=sigma)
     assert bit_same(box(dev.get(p_out), dims), box(got, dims)), "product vs reference"
     op.destroy()
+
+
+def test_the_product_outruns_the_reference_kernels_on_the_same_gpu(f3d, rig, capsys):
+    """SURVEY.md 8d's sample -- phi/ksi + 5 sweeps of one outer iteration -- on a 256^3 level: the reference's kernels (compiled for
+    this GPU, launched as its operator launches them) against the product's three launches.  Same bits; the time ratio is what a
+    straight recompile of the CUDA kernels would have left on the table (printed, and written to $F3D_OUT when set)."""
+    import os
+    import time
+    S = 256
+    dims = (S, S, S)
+    rng = np.random.default_rng(7)
+    plane = lambda lo, hi: np.repeat(rng.uniform(lo, hi, size=(1, S, S)).astype(np.float32), S, axis=0) + \
+        rng.uniform(-0.01, 0.01, size=(S, 1, 1)).astype(np.float32)
+    arrs = [plane(0, 255), plane(0, 255), plane(-3, 3), plane(-3, 3), plane(-3, 3), plane(-.5, .5), plane(-.5, .5), plane(-.5, .5)]
+    h, eps_s, eps_d, alpha = (1.0, 1.0, 1.0), 0.001, 0.001, 7.5
+    dev, ref = rig(dims)
+    hip = f3d.hip()
+    ptr = [dev.put(a) for a in arrs]
+    del arrs
+
+    bufs = {who: ([dev.out() for _ in range(3)], [dev.out() for _ in range(3)], [dev.out() for _ in range(4)]) for who in ("ref", "pro")}
+
+    def reference():   # the inputs are read only: the increments ping-pong between two buffer triples of the run's own
+        x, y, (phi, ksi, _, _) = bufs["ref"]
+        f3d.sync()
+        t = time.perf_counter()
+        ref.phi_ksi(*ptr, dims, h, eps_s, eps_d, phi, ksi)
+        src = ptr[5:8]
+        for i in range(5):
+            dst = x if i % 2 == 0 else y
+            ref.solve_sweep(*ptr[:5], *src, phi, ksi, dims, h, alpha, *dst)
+            src = dst
+        return time.perf_counter() - t, src, (phi, ksi)
+
+    def product():
+        x, y, (phi, ksi, phi2, ksi2) = bufs["pro"]
+        f3d.sync()
+        t = time.perf_counter()
+        f3d.check(hip.f3d_phi_ksi(*ptr, S, S, S, *h, eps_s, eps_d, phi, ksi, None))
+        f3d.check(hip.f3d_solve_sweep2(*ptr[:5], *ptr[5:8], phi, ksi, S, S, S, *h, alpha, *x, None))
+        f3d.check(hip.f3d_solve_sweep2(*ptr[:5], *x, phi, ksi, S, S, S, *h, alpha, *y, None))
+        f3d.check(hip.f3d_solve_sweep_phi_ksi(*ptr[:5], *y, phi, ksi, S, S, S, *h, alpha, eps_s, eps_d, *x, phi2, ksi2, None))
+        f3d.sync()
+        return time.perf_counter() - t, x, (phi, ksi)
+
+    reference()
+    product()                     # warm: code objects loaded, scratch allocated
+    t_ref, r_out, r_w = reference()
+    t_pro, p_out, p_w = product()
+    for r, p in zip(list(r_out) + list(r_w), list(p_out) + list(p_w)):
+        assert bit_same(dev.get(r), dev.get(p))
+    line = (f"phi/ksi + 5 sweeps on {S}^3: the reference's kernels {t_ref * 1e3:.2f} ms, the product {t_pro * 1e3:.2f} ms "
+            f"(x {t_ref / t_pro:.1f}); {6 * S ** 3 / t_pro / 1e9:.1f} against {6 * S ** 3 / t_ref / 1e9:.1f} Gvoxel-updates/s")
+    with capsys.disabled():
+        print("\n" + line)
+    if os.environ.get("F3D_OUT"):
+        with open(os.path.join(os.environ["F3D_OUT"], "reference_kernels_vs_product.txt"), "a") as f:
+            f.write(line + "\n")
+    assert t_ref > 2.0 * t_pro, line
+
+
+@pytest.mark.parametrize("dims,cdims", CASES[:4])
+def test_add(f3d, oracle, rig, dims, cdims):
+    rng = np.random.default_rng(5)
+    W, H, D = dims
+    a, b = box_in_container(rng, dims, cdims, -3, 3), box_in_container(rng, dims, cdims, -0.5, 0.5)
+    exp = a.copy()
+    oracle.add(exp, b, dims)
+    dev, ref = rig(cdims)
+    ra, pa, pb = dev.put(a), dev.put(a), dev.put(b)
+    f3d.sync()
+    ref.add(ra, pb, dims)
+    got = dev.get(ra)
+    assert bit_same(box(got, dims), box(exp, dims)), "reference vs oracle"
+    f3d.check(f3d.hip().f3d_add(pa, pb, W, H, D, None))
+    assert bit_same(box(dev.get(pa), dims), box(got, dims)), "product vs reference"
+
+
+def reference_pyramid(f3d, oracle, dev, ref, f0, f1, prm):
+    """OpticalFlowE::ComputeFlow (optical_flow_e.cpp:208-576) with EVERY kernel launch made on the reference's own kernels: the blur of
+    both frames, and per level the two frame resamplings from the full-size frames, the flow of the level before brought up, the
+    registration, outer x (phi/ksi + inner x sweep with the buffer swap), flow += increment, the median.  Clearing and copying are the
+    library's (cuMemsetD2D8 / the container stack in the reference).  Returns (u, v, w) as host arrays."""
+    hip = f3d.hip()
+    d0, h0, w0 = f0.shape
+    full = (w0, h0, d0)
+    cont = dev.cont
+    rows = cont.height * cont.depth
+
+    def clear(p, width):
+        f3d.check(hip.f3d_memset2d(p, cont.pitch, 0, width * 4, rows))
+        f3d.sync()
+
+    raw0, raw1 = dev.put(f0), dev.put(f1)
+    fr0, fr1, tmp = dev.out(), dev.out(), dev.out()
+    f3d.sync()
+    if prm["gaussian_sigma"] > 0:
+        radius, taps = oracle.gaussian_taps(prm["gaussian_sigma"])
+        ref.gaussian(raw0, fr0, tmp, full, [float(t) for t in taps], int(radius))
+        ref.gaussian(raw1, fr1, tmp, full, [float(t) for t in taps], int(radius))
+    else:
+        fr0, fr1 = raw0, raw1
+    fr0_res, fr1_res = dev.out(), dev.out()
+    flow = [dev.out() for _ in range(3)]
+    incr = [dev.out() for _ in range(3)]
+    phi, ksi = dev.out(), dev.out()
+    tinc = [dev.out() for _ in range(3)]
+    level = min(prm["warp_levels_count"], oracle.max_warp_level(w0, h0, d0, prm["warp_scale_factor"])) - 1
+    prev = None
+    while level >= 0:
+        cur, h = oracle.level_geometry(w0, h0, d0, prm["warp_scale_factor"], level)
+        if level == 0:
+            fr0, fr0_res = fr0_res, fr0
+            fr1, fr1_res = fr1_res, fr1
+        else:
+            ref.resample(fr0, fr0_res, tmp, full, cur)
+            ref.resample(fr1, fr1_res, tmp, full, cur)
+        if prev is None:
+            for p in flow:
+                clear(p, cont.width)
+        else:
+            for i in range(3):
+                ref.resample(flow[i], incr[i], tmp, prev, cur)
+                flow[i], incr[i] = incr[i], flow[i]
+        ref.warp(fr0_res, fr1_res, *flow, cur, h, tmp)
+        fr1_res, tmp = tmp, fr1_res
+        for p in incr:
+            clear(p, cur[0])
+        for _ in range(prm["outer_iterations_count"]):
+            ref.phi_ksi(fr0_res, fr1_res, *flow, *incr, cur, h, prm["equation_smoothness"], prm["equation_data"], phi, ksi)
+            for _ in range(prm["inner_iterations_count"]):
+                ref.solve_sweep(fr0_res, fr1_res, *flow, *incr, phi, ksi, cur, h, prm["equation_alpha"], *tinc)
+                incr, tinc = tinc, incr
+        for i in range(3):
+            ref.add(flow[i], incr[i], cur)
+        for i in range(3):
+            ref.median(flow[i], cur, prm["median_radius"], tmp)
+            flow[i], tmp = tmp, flow[i]
+        prev = cur
+        level -= 1
+    return [dev.get(p) for p in flow]
+
+
+@pytest.mark.parametrize("shape,prm", [
+    ((24, 40, 48), dict(warp_levels_count=6, outer_iterations_count=5)),
+    ((5, 64, 96), dict(warp_levels_count=4, outer_iterations_count=4, warp_scale_factor=0.8)),
+    ((20, 36, 40), dict(warp_levels_count=3, outer_iterations_count=3, gaussian_sigma=0.0, median_radius=3)),
+])
+def test_whole_pyramid_on_the_reference_kernels(f3d, oracle, rig, shape, prm):
+    """A whole ComputeFlow -- blur, several pyramid levels, registration, solver, flow update, median -- three ways on the same pair:
+    the reference's kernels driven in the reference's order, the oracle, the product.  Bit for bit (the median passes values through:
+    signs of zero compared as values)."""
+    import importlib
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    params = dict(pkg.DEFAULT_PARAMS)
+    params.update(prm)
+    d, h, w = shape
+    zz, yy, xx = np.meshgrid(np.arange(d), np.arange(h), np.arange(w), indexing="ij")
+    blob = lambda cx, cy, cz, s: np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2) / (2.0 * s * s))
+    f0 = (180 * blob(w * 0.4, h * 0.5, d * 0.5, w / 7) + 90 * blob(w * 0.7, h * 0.3, d * 0.4, w / 10) + 5 * np.sin(xx * 0.9) * np.cos(yy * 0.7)).astype(np.float32)
+    f1 = (180 * blob(w * 0.4 + 1.5, h * 0.5 - 1.0, d * 0.5 + 0.4, w / 7) + 90 * blob(w * 0.7 + 1.5, h * 0.3 - 1.0, d * 0.4 + 0.4, w / 10) +
+          5 * np.sin((xx - 1.5) * 0.9) * np.cos((yy + 1.0) * 0.7)).astype(np.float32)
+    dev, ref = rig((w, h, d))
+    got = reference_pyramid(f3d, oracle, dev, ref, f0, f1, params)
+    exp, _ = oracle.compute_flow(f0, f1, **prm)
+    for n, g, e in zip("uvw", got, exp):
+        assert same(g, e), f"reference kernels vs oracle, {n}: {int((g != e).sum())} voxels differ, max {np.abs(g - e).max():.3e}"
+    flow = f3d.OpticalFlow()
+    flow.initialize(w, h, d)
+    try:
+        mine = flow.compute(f0, f1, silent=True, **prm)
+    finally:
+        flow.destroy()
+    for n, g, m in zip("uvw", got, mine):
+        assert same(m, g), f"product vs reference kernels, {n}: {int((g != m).sum())} voxels differ, max {np.abs(g - m).max():.3e}"
+    assert max(float(np.abs(c).max()) for c in got) > 1e-3   # not the zero field (a few outer iterations recover a fraction of the shift)
