@@ -215,7 +215,8 @@ def test_the_reference_kernels_are_built_from_the_reference_tree():
         pytest.skip("oracle/_ref/*.hsaco not built (no /root/reference here)")
     names = {"solve_3d": [b"compute_phi_ksi_3d", b"solve_3d"], "median_3d": [b"median_3d"], "registration_3d": [b"registration_3d"],
              "resample_3d": [b"resample_x_3d", b"resample_y_3d", b"resample_z_3d"],
-             "convolution_3d": [b"convolutionRowsKernel", b"convolutionColumnsKernel", b"convolutionSlicesKernel", b"c_Kernel"]}
+             "convolution_3d": [b"convolutionRowsKernel", b"convolutionColumnsKernel", b"convolutionSlicesKernel", b"c_Kernel"],
+             "add_3d": [b"add_3d"]}
     for module, symbols in names.items():
         blob = open(os.path.join(ref_kernels.REF_DIR, module + ".hsaco"), "rb").read()
         assert blob[:4] == b"\x7fELF" or blob.startswith(b"__CLANG_OFFLOAD_BUNDLE__"), module   # a code object or a bundle of one
