@@ -22,12 +22,46 @@ from test_gpu_kernels import CASES, RESAMPLE, SPACINGS, Dev, solver_inputs
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_kernels.available(), reason="oracle/_ref/*.hsaco not built (no /root/reference here)")]
 
 
+class GuardedDev:
+    """`Dev` with room around every container.  The reference's kernels read outside their buffers where the values are never
+    looked at: median_3d.cu:109-113 forms plane 2 D - offset - 2 = -1 for the rear halo of a five-plane volume (size_t arithmetic:
+    the plane BEFORE the buffer), and the same pattern exists for rows and columns.  On the reference's own allocations that is a
+    read of a neighbouring buffer; here an unmapped address is a GPU memory fault, so every container handed to a reference kernel
+    sits `margin` planes inside a larger allocation (NaN-poisoned like the rest)."""
+
+    def __init__(self, f3d, cdims, margin=8):
+        wc, hc, dc = cdims
+        self.f3d, self.cdims, self.margin = f3d, cdims, margin
+        self.alloc = f3d.Containers(wc, hc, dc + 2 * margin)
+        self.alloc.alloc(fill=0xFF)
+        self.cont = f3d.Containers(wc, hc, dc)          # the view the kernels are told about: same pitch and height, dc planes
+        self.cont.pitch = self.alloc.pitch
+        self.cont.set_current()
+        self.offset = margin * self.alloc.pitch * hc
+
+    def put(self, host_container):
+        p = self.alloc.new()
+        self.alloc.upload(p, host_container, plane0=self.margin)
+        return p + self.offset
+
+    def out(self):
+        return self.alloc.new() + self.offset
+
+    def get(self, p):
+        self.f3d.sync()
+        return self.alloc.download(p - self.offset, self.cdims, plane0=self.margin)
+
+    def close(self):
+        self.f3d.sync()
+        self.alloc.free()
+
+
 @pytest.fixture
 def rig(f3d):
     made = []
 
     def make(cdims):
-        dev = Dev(f3d, cdims)
+        dev = GuardedDev(f3d, cdims)
         ref = ref_kernels.RefKernels(dev.cont)
         made.append((dev, ref))
         return dev, ref
@@ -352,3 +386,43 @@ def test_whole_pyramid_on_the_reference_kernels(f3d, oracle, rig, shape, prm):
     for n, g, m in zip("uvw", got, mine):
         assert same(m, g), f"product vs reference kernels, {n}: {int((g != m).sum())} voxels differ, max {np.abs(g - m).max():.3e}"
     assert max(float(np.abs(c).max()) for c in got) > 1e-3   # not the zero field (a few outer iterations recover a fraction of the shift)
+
+
+@pytest.mark.parametrize("config", ["c1", "crop128", "croprub", "c2", "c3"])
+def test_baseline_configs_on_the_reference_kernels(f3d, oracle, rig, config):
+    """The committed golden results of BASELINE configs 1 - 3 and of the two full-default crops (tests/golden/expected_oracle.npz,
+    made by the oracle) reproduced by the REFERENCE'S KERNELS driven through the reference's sequence: the digests of (u, v, w) the
+    product is held to in tests/test_gpu_pipeline.py are the reference's, not only the restatement's."""
+    import importlib
+    import os
+    from test_gpu_pipeline import GOLD, digest
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    e = np.load(os.path.join(GOLD, "expected_oracle.npz"))
+    i128 = np.load(os.path.join(GOLD, "inputs_128.npz"))
+    irub = np.load(os.path.join(GOLD, "inputs_rub.npz"))
+    f0, f1 = i128["frame_0"].astype(np.float32), i128["frame_1"].astype(np.float32)
+    r0 = np.repeat(irub["slice_0"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    r1 = np.repeat(irub["slice_1"][None], int(irub["depth"]), axis=0).astype(np.float32)
+    prm = {}
+    if config == "c1":
+        prm = dict(warp_levels_count=1, outer_iterations_count=1, inner_iterations_count=5)
+    elif config == "crop128":
+        crop = (slice(40, 64), slice(40, 80), slice(40, 88))
+        f0, f1 = f0[crop].copy(), f1[crop].copy()
+    elif config == "croprub":
+        rc = (slice(0, 5), slice(100, 164), slice(200, 296))
+        f0, f1 = r0[rc].copy(), r1[rc].copy()
+    elif config == "c3":
+        f0, f1 = r0, r1
+    params = dict(pkg.DEFAULT_PARAMS)
+    params.update(prm)
+    d, h, w = f0.shape
+    dev, ref = rig((w, h, d))
+    got = reference_pyramid(f3d, oracle, dev, ref, f0, f1, params)
+    for c in got:
+        assert np.isfinite(c).all()
+    if config in ("c1", "c2", "c3"):
+        assert digest(*got) == str(e[config + "_sha256"])
+    else:
+        for n, g, x in zip("uvw", got, e[config + "_flow"]):
+            assert same(g, x), f"{config}: {n} differs in {int((g != x).sum())} voxels"
