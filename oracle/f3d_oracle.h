@@ -20,7 +20,7 @@
  *     include-guard definitions it needs and why nothing is written in place of any header), tests/ref_kernels.py launches them
  *     with the reference operators' block sizes, shared-memory sizes and argument lists, and
  *     tests/test_gpu_reference_kernels.py holds reference == oracle and product == reference bit for bit, kernel by kernel and
- *     for whole pyramid solves driven on the reference's kernels, the golden results of BASELINE configs 1 - 3 among them (72 cases).
+ *     for whole pyramid solves driven on the reference's kernels, the golden results of BASELINE configs 1 - 4 among them (73 cases).
  *     What that does not cover: whether nvcc would have fused multiply-adds (this repository defines the reference's numbers
  *     with contraction off), and the host-side operator code around the kernels (CUDA driver API; restated,
  *     file:line cited).

@@ -426,3 +426,29 @@ def test_baseline_configs_on_the_reference_kernels(f3d, oracle, rig, config):
     else:
         for n, g, x in zip("uvw", got, e[config + "_flow"]):
             assert same(g, x), f"{config}: {n} differs in {int((g != x).sum())} voxels"
+
+
+def test_baseline_config_4_on_the_reference_kernels(f3d, oracle, rig):
+    """BASELINE config 4 -- the 512^3 synthetic pair through the full default pyramid, the configuration bench.py times -- on the
+    reference's kernels: the sha256 of (u, v, w) is the digest committed in tests/golden/config_digests.json, the one every bench
+    line checks its own result against (`parity.match`).  The oracle cannot reach this size; the reference's kernels
+    on the GPU can, in about a minute."""
+    import importlib
+    from test_gpu_configs import committed, digest
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    f0, f1 = f3d.synth_pair(512, 512, 512)
+    import os
+    import time
+    dev, ref = rig((512, 512, 512))
+    t = time.perf_counter()
+    got = reference_pyramid(f3d, oracle, dev, ref, f0, f1, dict(pkg.DEFAULT_PARAMS))
+    seconds = time.perf_counter() - t
+    for c in got:
+        assert np.isfinite(c).all()
+    assert digest(got) == committed("c4_512_default_sha256")
+    line = (f"BASELINE config 4 on the reference's kernels (this GPU, upload and download included, one host wait per launch): "
+            f"{seconds:.1f} s = {512 ** 3 / seconds / 1e6:.1f} Mvoxels/s")
+    print("\n" + line)
+    if os.environ.get("F3D_OUT"):
+        with open(os.path.join(os.environ["F3D_OUT"], "reference_kernels_vs_product.txt"), "a") as f:
+            f.write(line + "\n")
