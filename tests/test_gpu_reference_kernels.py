@@ -452,3 +452,25 @@ def test_baseline_config_4_on_the_reference_kernels(f3d, oracle, rig):
     if os.environ.get("F3D_OUT"):
         with open(os.path.join(os.environ["F3D_OUT"], "reference_kernels_vs_product.txt"), "a") as f:
             f.write(line + "\n")
+
+
+@pytest.mark.skipif(__import__("os").environ.get("F3D_REF_C5") != "1", reason="five minutes and 110 GB: run with F3D_REF_C5=1 (tools/r3_job33.sh)")
+def test_baseline_config_5_on_the_reference_kernels(f3d, oracle, rig):
+    """BASELINE config 5 -- 1024^3, the configuration of the multi-GPU runs -- on the reference's kernels against the committed digest
+    (the one the 8-slab and the two-rank rehearsals are held to).  Opt-in: it takes minutes."""
+    import importlib
+    import os
+    import time
+    from test_gpu_configs import committed, digest
+    pkg = importlib.import_module("cuda-flow3d_amd")
+    f0, f1 = f3d.synth_pair(1024, 1024, 1024)
+    dev, ref = rig((1024, 1024, 1024))
+    t = time.perf_counter()
+    got = reference_pyramid(f3d, oracle, dev, ref, f0, f1, dict(pkg.DEFAULT_PARAMS))
+    seconds = time.perf_counter() - t
+    assert digest(got) == committed("c5_1024_default_sha256")
+    line = f"BASELINE config 5 on the reference's kernels: {seconds:.1f} s = {1024 ** 3 / seconds / 1e6:.1f} Mvoxels/s"
+    print("\n" + line)
+    if os.environ.get("F3D_OUT"):
+        with open(os.path.join(os.environ["F3D_OUT"], "reference_kernels_vs_product.txt"), "a") as f:
+            f.write(line + "\n")
