@@ -2,7 +2,7 @@
 # round 3, GPU job 8a: the whole GPU suite, smoke, the bench as the driver runs it, and `bench.py --gpus 2` started bare (rehearsal)
 set -e
 R=$(pwd)
-O=${F3D_OUT:-$R/gpurun_out}/r3/job30
+O=${F3D_OUT:-$R/gpurun_out}/r3/job34
 mkdir -p $O
 python3 -X faulthandler -m pytest tests -q -m gpu -x > $O/gpu_tests.log 2>&1 || { tail -40 $O/gpu_tests.log; exit 1; }
 tail -2 $O/gpu_tests.log
