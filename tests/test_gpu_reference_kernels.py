@@ -474,3 +474,76 @@ def test_baseline_config_5_on_the_reference_kernels(f3d, oracle, rig):
     if os.environ.get("F3D_OUT"):
         with open(os.path.join(os.environ["F3D_OUT"], "reference_kernels_vs_product.txt"), "a") as f:
             f.write(line + "\n")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_against_the_reference_kernels(f3d, rig, seed):
+    """Differential run without the oracle in between: random box sizes (widths around the 64-lane tile edges included), random
+    container slack, random spacings -- the product's launches (separate and fused, frames and frame derivatives) against the
+    reference's kernels for the solver, and the median, the registration and the resampling on the same boxes."""
+    rng = np.random.default_rng(1000 + seed)
+    W = int(rng.choice([rng.integers(4, 40), rng.integers(60, 70), rng.integers(120, 135), rng.integers(180, 200)]))
+    H, D = int(rng.integers(4, 60)), int(rng.integers(4, 36))
+    dims = (W, H, D)
+    cdims = (W + int(rng.integers(0, 9)), H + int(rng.integers(0, 5)), D + int(rng.integers(0, 3)))
+    h = tuple(float(x) for x in rng.uniform(0.6, 8.0, size=3).astype(np.float32))
+    eps_s, eps_d, alpha = 0.001, 0.0015, float(np.float32(rng.uniform(3, 12)))
+    arrs = solver_inputs(rng, dims, cdims)
+    dev, ref = rig(cdims)
+    hip = f3d.hip()
+    ptr = [dev.put(a) for a in arrs]
+    # reference: phi/ksi, sweep, sweep, and the weights of the next outer iteration from the increments after ONE sweep
+    r_phi, r_ksi, r_phi2, r_ksi2 = dev.out(), dev.out(), dev.out(), dev.out()
+    r1, r2 = [dev.out() for _ in range(3)], [dev.out() for _ in range(3)]
+    f3d.sync()
+    ref.phi_ksi(*ptr, dims, h, eps_s, eps_d, r_phi, r_ksi)
+    ref.solve_sweep(*ptr, r_phi, r_ksi, dims, h, alpha, *r1)
+    ref.solve_sweep(*ptr[:5], *r1, r_phi, r_ksi, dims, h, alpha, *r2)
+    ref.phi_ksi(*ptr[:5], *r1, dims, h, eps_s, eps_d, r_phi2, r_ksi2)
+    want = {n: box(dev.get(p), dims) for n, p in zip(("phi", "ksi", "phi2", "ksi2"), (r_phi, r_ksi, r_phi2, r_ksi2))}
+    for n, a, b in zip("uvw", r1, r2):
+        want["1" + n], want["2" + n] = box(dev.get(a), dims), box(dev.get(b), dims)
+    # product
+    p_phi, p_ksi = dev.out(), dev.out()
+    f3d.check(hip.f3d_phi_ksi(*ptr, W, H, D, *h, eps_s, eps_d, p_phi, p_ksi, None))
+    assert bit_same(box(dev.get(p_phi), dims), want["phi"]) and bit_same(box(dev.get(p_ksi), dims), want["ksi"]), (dims, cdims, h)
+    fd = [dev.out() for _ in range(4)]
+    f3d.check(hip.f3d_frame_derivatives(ptr[0], ptr[1], W, H, D, *h, *fd, None))
+    pitch_ok = dev.cont.pitch % 256 == 0
+    launches = [("two sweeps", lambda o: hip.f3d_solve_sweep2(*ptr, p_phi, p_ksi, W, H, D, *h, alpha, *o[:3], None), "2")]
+    if pitch_ok:
+        launches += [
+            ("sweep + phi/ksi", lambda o: hip.f3d_solve_sweep_phi_ksi(*ptr, p_phi, p_ksi, W, H, D, *h, alpha, eps_s, eps_d, *o, None), "1"),
+            ("two sweeps on derivatives", lambda o: hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], p_phi, p_ksi, W, H, D, *h, alpha, *o[:3], None), "2"),
+            ("sweep + phi/ksi on derivatives",
+             lambda o: hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], p_phi, p_ksi, W, H, D, *h, alpha, eps_s, eps_d, *o, None), "1")]
+    for label, launch, which in launches:
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(launch(outs))
+        for n, o in zip("uvw", outs):
+            assert bit_same(box(dev.get(o), dims), want[which + n]), f"{label}: d{n} on {dims} in {cdims}, h = {h}"
+        if which == "1":
+            assert bit_same(box(dev.get(outs[3]), dims), want["phi2"]) and bit_same(box(dev.get(outs[4]), dims), want["ksi2"]), label
+    # median, registration, resampling of one of the volumes
+    r = int(rng.choice([3, 5, 7]))
+    if min(dims) > r // 2:
+        src = dev.put(box_in_container(rng, dims, cdims, -2, 2))
+        a, b = dev.out(), dev.out()
+        f3d.sync()
+        ref.median(src, dims, r, a)
+        f3d.check(hip.f3d_median(src, W, H, D, r, b, None))
+        assert same(box(dev.get(b), dims), box(dev.get(a), dims)), f"median {r} on {dims}"
+    a, b = dev.out(), dev.out()
+    f3d.sync()
+    ref.warp(*ptr[:5], dims, h, a)
+    f3d.check(hip.f3d_warp(*ptr[:5], W, H, D, *h, b, None))
+    assert bit_same(box(dev.get(b), dims), box(dev.get(a), dims)), f"registration on {dims}"
+    dst = tuple(int(np.clip(round(n * s), 2, c)) for n, s, c in zip(dims, rng.uniform(0.45, 1.3, size=3), cdims))
+    a, b, t1, t2 = dev.out(), dev.out(), dev.out(), dev.out()
+    f3d.sync()
+    ref.resample(ptr[0], a, t1, dims, dst)
+    op = f3d.Operation("resample")
+    assert op.initialize(dev.cont)
+    op.execute(dev_input=ptr[0], dev_output=b, dev_temp=t2, data_size=dims, resample_size=dst)
+    assert bit_same(box(dev.get(b), dst), box(dev.get(a), dst)), f"resampling {dims} -> {dst}"
+    op.destroy()
