@@ -247,7 +247,9 @@ def golden_plane_digest(size):
 def parity_record(size, digest):
     want = golden_plane_digest(size)
     return {"what": "sha256 over the per-plane sha256 of the (u, v, w) this run left on the device(s) against the committed "
-                    "single-GPU result of the same pair (tests/golden/config_digests.json; bit-exact or false)",
+                    "single-GPU result of the same pair (tests/golden/config_digests.json; bit-exact or false).  That result is "
+                    "also what the reference's own kernels, compiled for gfx950 from the reference tree, give for this pair "
+                    "(tests/test_gpu_reference_kernels.py: test_baseline_config_4 / _5_on_the_reference_kernels)",
             "digest": digest, "golden": want, "match": (digest == want) if want else None}
 
 
