@@ -65,13 +65,35 @@ __device__ __forceinline__ float rank_nb_of_two_sorted(const float* a, const flo
   return r;
 }
 
+// Up to three volumes of one box per launch (f3d_median_n: u, v, w of a level): grid.z = z-chunks x volumes, a workgroup finds its
+// volume by subtraction (scalar work; the kernels below are register-bound and must not pay a vector division for it).
+constexpr int kMaxBatch = 3;
+struct MedVols {
+  const float* in[kMaxBatch];
+  float* out[kMaxBatch];
+  int zblocks;  // z-chunks (bisection kernel: planes) per volume
+};
+__device__ __forceinline__ int med_volume(const MedVols& v, int& zb)
+{
+  int vol = 0;
+  zb = static_cast<int>(blockIdx.z);
+  while (zb >= v.zblocks) {
+    zb -= v.zblocks;
+    ++vol;
+  }
+  return vol;
+}
+
 // LDS-staged variant: a workgroup of 64 x 4 lanes marches along z over a chunk of planes.  The (64 + 2h) x (4 + 2h)
 // mirrored footprint of every plane is fetched once into a ring of R planes in LDS (a few loads per lane and step);
 // the R^3 window of a voxel is then R^3 LDS reads instead of R^3 cached global loads with 64-bit address arithmetic.
 template <int R>
-__global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
-                                                        int zchunk)
+__global__ __launch_bounds__(kBX* kBY) void k_median_net(MedVols mv, F3dGeo g, int zchunk)
 {
+  int zb;
+  const int vol = med_volume(mv, zb);
+  const float* __restrict__ in = mv.in[vol];
+  float* __restrict__ out = mv.out[vol];
   constexpr int HALF = R / 2;
   constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
   __shared__ float ring[R][TH][TW];
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict
   const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
   const int x = x0 + threadIdx.x;
   const int y = y0 + threadIdx.y;
-  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z0 = g.z_lo + zb * zchunk;
   const int z1 = min(z0 + zchunk, g.z_hi);
   const bool owner = x < g.W && y < g.H;
 
@@ -120,9 +142,12 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_net(const float* __restrict
 // m - R^2 .. m), two small full sorts and two min/max chains -- 2 524 min/max for two outputs at R = 5 against 2 x 2 244 of
 // the single-output network -- and holds ~110 values at a time instead of 125 + temporaries.
 template <int R>
-__global__ __launch_bounds__(kBX* kBY) void k_median_pair(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
-                                                         int zchunk)
+__global__ __launch_bounds__(kBX* kBY) void k_median_pair(MedVols mv, F3dGeo g, int zchunk)
 {
+  int zb;
+  const int vol = med_volume(mv, zb);
+  const float* __restrict__ in = mv.in[vol];
+  float* __restrict__ out = mv.out[vol];
   constexpr int HALF = R / 2;
   constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
   constexpr int NS = R + 1;  // ring slots: planes z-HALF .. z+HALF+1
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_pair(const float* __restric
   const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
   const int x = x0 + threadIdx.x;
   const int y = y0 + threadIdx.y;
-  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z0 = g.z_lo + zb * zchunk;
   const int z1 = min(z0 + zchunk, g.z_hi);
   const bool owner = x < g.W && y < g.H;
   const int zz_max = z1 - 1 + HALF;  // the last plane this chunk may touch (a slab window holds nothing beyond it)
@@ -187,9 +212,12 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_pair(const float* __restric
 // sort of the raw 100 in k_median_pair.  Planes are named Q0 .. Q5 = z-2 .. z+3; a step consumes the lists of Q0 and Q1 and
 // produces those of Q4 and Q5, so six register arrays rotate by two per step and the march is unrolled three steps deep to
 // make the rotation a renaming.  ~200 live values at the peak: two waves per SIMD, like the single-output network.
-__global__ __launch_bounds__(kBX* kBY) void k_median_keep(const float* __restrict__ in, float* __restrict__ out, F3dGeo g,
-                                                         int zchunk)
+__global__ __launch_bounds__(kBX* kBY) void k_median_keep(MedVols mv, F3dGeo g, int zchunk)
 {
+  int zb;
+  const int vol = med_volume(mv, zb);
+  const float* __restrict__ in = mv.in[vol];
+  float* __restrict__ out = mv.out[vol];
   constexpr int R = 5, HALF = 2;
   constexpr int TW = kBX + 2 * HALF, TH = kBY + 2 * HALF;
   constexpr int NS = R + 1;
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_keep(const float* __restric
   const int x0 = blockIdx.x * kBX, y0 = blockIdx.y * kBY;
   const int x = x0 + threadIdx.x;
   const int y = y0 + threadIdx.y;
-  const int z0 = g.z_lo + blockIdx.z * zchunk;
+  const int z0 = g.z_lo + zb * zchunk;
   const int z1 = min(z0 + zchunk, g.z_hi);
   const bool owner = x < g.W && y < g.H;
   const int zz_max = z1 - 1 + HALF;
@@ -269,13 +297,17 @@ __device__ __forceinline__ unsigned order_key(float f)
 
 // Exact rank selection without holding the window: the answer is the largest T with #(key < T) <= rank.
 template <int R>
-__global__ __launch_bounds__(kBX* kBY) void k_median_bisect(const float* __restrict__ in, float* __restrict__ out, F3dGeo g)
+__global__ __launch_bounds__(kBX* kBY) void k_median_bisect(MedVols mv, F3dGeo g)
 {
+  int zb;
+  const int vol = med_volume(mv, zb);
+  const float* __restrict__ in = mv.in[vol];
+  float* __restrict__ out = mv.out[vol];
   constexpr int HALF = R / 2;
   constexpr int RANK = (R * R * R) / 2;
   const int x = blockIdx.x * kBX + threadIdx.x;
   const int y = blockIdx.y * kBY + threadIdx.y;
-  const int z = g.z_lo + blockIdx.z;
+  const int z = g.z_lo + zb;
   if (x >= g.W || y >= g.H) return;
   int xs[R];
 #pragma unroll
@@ -300,18 +332,22 @@ __global__ __launch_bounds__(kBX* kBY) void k_median_bisect(const float* __restr
 
 }  // namespace
 
-extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t depth, size_t radius, f3d_devptr output,
-                          const f3d_slab* slab)
+static int median_launch(const f3d_devptr* inputs, size_t count, size_t width, size_t height, size_t depth, size_t radius,
+                         const f3d_devptr* outputs, const f3d_slab* slab, const char* who)
 {
-  F3D_REQUIRE_READY("f3d_median");
-  if (input == output) return f3d::fail("f3d_median: input buffer cannot serve as output buffer");
+  F3D_REQUIRE_READY(who);
+  if (!inputs || !outputs) return f3d::fail("%s: null argument", who);
+  if (count == 0 || count > static_cast<size_t>(kMaxBatch)) return f3d::fail("%s: %zu volumes (one launch takes 1 .. %d)", who, count, kMaxBatch);
+  for (size_t i = 0; i < count; ++i)
+    for (size_t j = 0; j < count; ++j)
+      if (inputs[i] == outputs[j]) return f3d::fail("%s: input buffer cannot serve as output buffer", who);
   if (radius != 3 && radius != 5 && radius != 7)
-    return f3d::fail("f3d_median: wrong median radius (%zu). Supported values: 3, 5, 7", radius);
+    return f3d::fail("%s: wrong median radius (%zu). Supported values: 3, 5, 7", who, radius);
   F3dGeo g;
-  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_median")) return 1;
+  if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
   const int half = static_cast<int>(radius) / 2;
   if (g.W <= half || g.H <= half || g.D <= half)
-    return f3d::fail("f3d_median: every dimension must exceed radius/2 = %d for the mirror boundary", half);
+    return f3d::fail("%s: every dimension must exceed radius/2 = %d for the mirror boundary", who, half);
   if (g.z_lo == g.z_hi) return 0;
   {
     const int dc = static_cast<int>(f3d::container().depth);
@@ -320,17 +356,23 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
     if (g.z_lo - half < 0 && half + 1 > hi) hi = half + 1;
     if (g.z_hi + half > g.D && g.D - 1 - half < lo) lo = g.D - 1 - half;
     if (lo < g.z_base || hi - g.z_base > dc)
-      return f3d::fail("f3d_median: planes [%d,%d) needed but the container holds [%d,%d)", lo, hi, g.z_base, g.z_base + dc);
+      return f3d::fail("%s: planes [%d,%d) needed but the container holds [%d,%d)", who, lo, hi, g.z_base, g.z_base + dc);
   }
   const dim3 block(kBX, kBY, 1);
-  const float* in = f3d_ptr<const float>(input);
-  float* out = f3d_ptr<float>(output);
+  MedVols mv = {};
+  for (size_t i = 0; i < count; ++i) {
+    mv.in[i] = f3d_ptr<const float>(inputs[i]);
+    mv.out[i] = f3d_ptr<float>(outputs[i]);
+  }
+  const unsigned nvol = static_cast<unsigned>(count);
   if (radius == 7) {
-    const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo);
-    hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), in, out, g);
+    mv.zblocks = g.z_hi - g.z_lo;
+    const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, mv.zblocks * nvol);
+    hipLaunchKernelGGL(k_median_bisect<7>, grid, block, 0, f3d::stream(), mv, g);
   } else {
     const int planes = g.z_hi - g.z_lo;
-    const long tiles = static_cast<long>((g.W + kBX - 1) / kBX) * ((g.H + kBY - 1) / kBY);
+    // workgroups of ONE z-chunk layer of the launch: the volumes of a batch fill the rounds together
+    const long tiles = static_cast<long>((g.W + kBX - 1) / kBX) * ((g.H + kBY - 1) / kBY) * static_cast<long>(count);
     // F3D_MEDIAN_PAIR: 0 = the one-output-per-step network, 1 = k_median_pair, 2 = k_median_keep (timing comparisons);
     // unset = whichever the model below prefers.  Read per call (a launch costs far more) so that tests can switch it.
     const char* forced_env = std::getenv("F3D_MEDIAN_PAIR");
@@ -341,9 +383,10 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
       if (nz > planes) nz = planes;
       if (nz < 1) nz = 1;
       const int zchunk = static_cast<int>((planes + nz - 1) / nz);
-      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
-      if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-      if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+      mv.zblocks = (planes + zchunk - 1) / zchunk;
+      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, mv.zblocks * nvol);
+      if (radius == 3) hipLaunchKernelGGL(k_median_net<3>, grid, block, 0, f3d::stream(), mv, g, zchunk);
+      if (radius == 5) hipLaunchKernelGGL(k_median_net<5>, grid, block, 0, f3d::stream(), mv, g, zchunk);
     } else {
       // Both kernels are bound by the vector unit: a chunk of zc planes costs its min/max count (per pair of planes 2 600
       // resp. 1 430, plus the four plane sorts k_median_keep starts with and a few hundred for the ring prologue), a
@@ -372,12 +415,25 @@ extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t 
           keep = true;
         }
       }
-      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, (planes + zchunk - 1) / zchunk);
-      if (radius == 3) hipLaunchKernelGGL(k_median_pair<3>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-      if (radius == 5 && keep) hipLaunchKernelGGL(k_median_keep, grid, block, 0, f3d::stream(), in, out, g, zchunk);
-      if (radius == 5 && !keep) hipLaunchKernelGGL(k_median_pair<5>, grid, block, 0, f3d::stream(), in, out, g, zchunk);
+      mv.zblocks = (planes + zchunk - 1) / zchunk;
+      const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, mv.zblocks * nvol);
+      if (radius == 3) hipLaunchKernelGGL(k_median_pair<3>, grid, block, 0, f3d::stream(), mv, g, zchunk);
+      if (radius == 5 && keep) hipLaunchKernelGGL(k_median_keep, grid, block, 0, f3d::stream(), mv, g, zchunk);
+      if (radius == 5 && !keep) hipLaunchKernelGGL(k_median_pair<5>, grid, block, 0, f3d::stream(), mv, g, zchunk);
     }
   }
   F3D_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int f3d_median(f3d_devptr input, size_t width, size_t height, size_t depth, size_t radius, f3d_devptr output,
+                          const f3d_slab* slab)
+{
+  return median_launch(&input, 1, width, height, depth, radius, &output, slab, "f3d_median");
+}
+
+extern "C" int f3d_median_n(const f3d_devptr* inputs, size_t count, size_t width, size_t height, size_t depth, size_t radius,
+                            const f3d_devptr* outputs, const f3d_slab* slab)
+{
+  return median_launch(inputs, count, width, height, depth, radius, outputs, slab, "f3d_median_n");
 }

@@ -18,6 +18,16 @@ constexpr int kBY = 4;
 
 inline dim3 grid_for(int w, int h, int planes) { return dim3((w + kBX - 1) / kBX, (h + kBY - 1) / kBY, planes); }
 
+// Up to three volumes of ONE box per launch (f3d_*_n): u, v, w of a level -- or the two frames -- go through "+=", the median and
+// the three resampling passes independently of each other, and below ~128^3 each of those launches is a few microseconds of
+// fixed cost around a microsecond of work.  The kernels are the single-volume ones; a workgroup picks its volume from the
+// grid (resample: blockIdx.x, the others: blockIdx.z / planes).
+constexpr int kMaxBatch = 3;
+struct Vols {
+  const float* in[kMaxBatch];
+  float* out[kMaxBatch];
+};
+
 // ---- A.2 warp: src/kernels/registration_3d.cu:28-82 ------------------------------------------------------
 __global__ __launch_bounds__(kBX* kBY) void k_warp(const float* __restrict__ f0, const float* __restrict__ f1,
                                                    const float* __restrict__ u, const float* __restrict__ v,
@@ -62,9 +72,10 @@ __global__ __launch_bounds__(kBX* kBY) void k_warp(const float* __restrict__ f0,
 // they are formed once per wave instead of once per voxel (one voxel per lane with everything inside was bound by that
 // arithmetic: 2.4 TB/s for a 512^3 -> 512^3 pass).
 template <int AXIS>
-__global__ __launch_bounds__(kBX* kBY) void k_resample(const float* __restrict__ in, float* __restrict__ out,
-                                                       F3dGeo gi, F3dGeo g, int in_n, float delta, float normalization)
+__global__ __launch_bounds__(kBX* kBY) void k_resample(Vols v, F3dGeo gi, F3dGeo g, int in_n, float delta, float normalization)
 {
+  const float* __restrict__ in = v.in[blockIdx.x];
+  float* __restrict__ out = v.out[blockIdx.x];
   const int y = blockIdx.y * kBY + threadIdx.y;
   const int z = g.z_lo + blockIdx.z;
   if (y >= g.H) return;
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample(const float* __restrict__
   if (AXIS != 0) window(AXIS == 1 ? y : z);
   const size_t out_row = f3d_row(g, y, z);
   const size_t in_row = AXIS == 0 ? f3d_row(gi, y, z) : 0;
-  for (int x = blockIdx.x * kBX + threadIdx.x; x < g.W; x += gridDim.x * kBX) {
+  for (int x = threadIdx.x; x < g.W; x += kBX) {
     if (AXIS == 0) window(x);
     float value = 0.f;
     for (int j = 0; j < cnt; ++j) {
@@ -99,10 +110,11 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample(const float* __restrict__
 // The x pass through LDS: a wave streams its source row in with 16 bytes per lane (every level reads the full-size original
 // of both frames, so this pass moves the most bytes of the three) and gathers the windows of its outputs from there.
 constexpr int kResampleRowMax = 2048;  // floats of a source row a wave can stage (longer rows: k_resample<0>)
-__global__ __launch_bounds__(kBX* kBY) void k_resample_x_lds(const float* __restrict__ in, float* __restrict__ out, F3dGeo gi,
-                                                             F3dGeo g, int in_n, float delta, float normalization)
+__global__ __launch_bounds__(kBX* kBY) void k_resample_x_lds(Vols v, F3dGeo gi, F3dGeo g, int in_n, float delta, float normalization)
 {
   __shared__ __attribute__((aligned(16))) float rowbuf[kBY][kResampleRowMax];
+  const float* __restrict__ in = v.in[blockIdx.x];
+  float* __restrict__ out = v.out[blockIdx.x];
   const int y = blockIdx.y * kBY + threadIdx.y;
   const int z = g.z_lo + blockIdx.z;
   if (y >= g.H) return;
@@ -135,10 +147,11 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample_x_lds(const float* __rest
 // load.  Rows start on 256-byte boundaries (f3d_alloc_pitched) and the pitch is a multiple of four floats, so the last piece of
 // a row may read padding; only the columns inside the box are stored.
 template <int AXIS>
-__global__ __launch_bounds__(kBX* kBY) void k_resample_x4(const float* __restrict__ in, float* __restrict__ out, F3dGeo gi,
-                                                          F3dGeo g, int in_n, float delta, float normalization)
+__global__ __launch_bounds__(kBX* kBY) void k_resample_x4(Vols v, F3dGeo gi, F3dGeo g, int in_n, float delta, float normalization)
 {
   static_assert(AXIS == 1 || AXIS == 2, "x is gathered, not streamed");
+  const float* __restrict__ in = v.in[blockIdx.x];
+  float* __restrict__ out = v.out[blockIdx.x];
   const int y = blockIdx.y * kBY + threadIdx.y;
   const int z = g.z_lo + blockIdx.z;
   if (y >= g.H) return;
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample_x4(const float* __restric
   const int right_i = static_cast<int>(fminf(static_cast<float>(in_n), ceilf(right_f)));
   const int cnt = right_i - left_i;
   const size_t out_row = f3d_row(g, y, z);
-  for (int x = (blockIdx.x * kBX + threadIdx.x) * 4; x < g.W; x += gridDim.x * kBX * 4) {
+  for (int x = threadIdx.x * 4; x < g.W; x += kBX * 4) {
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     for (int j = 0; j < cnt; ++j) {
       float frac = 1.f;
@@ -175,14 +188,43 @@ __global__ __launch_bounds__(kBX* kBY) void k_resample_x4(const float* __restric
 }
 
 // ---- add: src/kernels/add_3d.cu:26-41 ------------------------------------------------------------------------
-__global__ __launch_bounds__(kBX* kBY) void k_add(float* __restrict__ a, const float* __restrict__ b, F3dGeo g)
+// v.out = operand_0 (read and written), v.in = operand_1; grid.z = planes x volumes
+__global__ __launch_bounds__(kBX* kBY) void k_add(Vols v, F3dGeo g)
 {
+  const int planes = g.z_hi - g.z_lo;
+  const int vol = static_cast<int>(blockIdx.z) / planes;
+  float* __restrict__ a = v.out[vol];
+  const float* __restrict__ b = v.in[vol];
   const int x = blockIdx.x * kBX + threadIdx.x;
   const int y = blockIdx.y * kBY + threadIdx.y;
-  const int z = g.z_lo + blockIdx.z;
+  const int z = g.z_lo + (static_cast<int>(blockIdx.z) - vol * planes);
   if (x >= g.W || y >= g.H) return;
   const size_t c = f3d_row(g, y, z) + x;
   a[c] = a[c] + b[c];
+}
+
+// the box [0, W) x [0, H) x [z_lo, z_hi) of up to three volumes set to +0: 16 bytes per lane where a row allows it (rows start
+// 16-byte aligned when the pitch is a multiple of four floats and the base is); the increments of a level, cleared in one launch
+__global__ __launch_bounds__(256) void k_clear_box(Vols v, F3dGeo g, int chunks_per_row, int rows, int vec)
+{
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned total = static_cast<unsigned>(chunks_per_row) * static_cast<unsigned>(rows);
+  if (t >= total) return;
+  float* __restrict__ p = v.out[blockIdx.y];
+  const int r = static_cast<int>(t / static_cast<unsigned>(chunks_per_row));
+  const int c = static_cast<int>(t - static_cast<unsigned>(r) * static_cast<unsigned>(chunks_per_row));
+  const int zi = r / g.H, y = r - zi * g.H;
+  float* row = p + f3d_row(g, y, g.z_lo + zi);
+  if (vec) {
+    const int x = c * 4;
+    if (x + 3 < g.W) {
+      *reinterpret_cast<float4*>(row + x) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int k = x; k < g.W; ++k) row[k] = 0.f;
+    }
+  } else {
+    row[c] = 0.f;
+  }
 }
 
 // ---- A.6 Gaussian passes: src/kernels/convolution_3d.cu:75-172,186-271,284-372 ---------------------------------
@@ -349,11 +391,25 @@ int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devp
   return 0;
 }
 
-static int resample_launch(int axis, f3d_devptr input, f3d_devptr output, size_t ow, size_t oh, size_t od, size_t in_n,
-                           const f3d_slab* slab_in, const f3d_slab* slab, const char* who)
+static bool batch_ok(size_t count, const char* who)
+{
+  if (count == 0 || count > static_cast<size_t>(kMaxBatch)) {
+    f3d::fail("%s: %zu volumes (one launch takes 1 .. %d)", who, count, kMaxBatch);
+    return false;
+  }
+  return true;
+}
+
+static int resample_launch(int axis, const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t ow, size_t oh,
+                           size_t od, size_t in_n, const f3d_slab* slab_in, const f3d_slab* slab, const char* who)
 {
   F3D_REQUIRE_READY(who);
-  if (same_buffer(input, output, who)) return 1;
+  if (!inputs || !outputs) return f3d::fail("%s: null argument", who);
+  if (!batch_ok(count, who)) return 1;
+  // no volume of the batch may be read and written: the passes stream rows, every output row of a volume depends on other rows
+  for (size_t i = 0; i < count; ++i)
+    for (size_t j = 0; j < count; ++j)
+      if (same_buffer(inputs[i], outputs[j], who)) return 1;
   if (in_n == 0) return f3d::fail("%s: empty input axis", who);
   F3dGeo g, gi;
   if (!f3d::make_geo(&g, ow, oh, od, slab, who)) return 1;
@@ -369,24 +425,27 @@ static int resample_launch(int axis, f3d_devptr input, f3d_devptr output, size_t
     if (hi > static_cast<int>(in_n)) hi = static_cast<int>(in_n);
     if (!planes_inside(gi, lo, hi, who)) return 1;
   }
-  // one block of 4 waves per 4 rows; a wave walks its row (small levels: still enough blocks, rows x planes / 4)
-  const dim3 grid(1, (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo), block(kBX, kBY, 1);
-  const float* in = f3d_ptr<const float>(input);
-  float* out = f3d_ptr<float>(output);
+  // one block of 4 waves per 4 rows; a wave walks its row (small levels: still enough blocks, rows x planes / 4); grid.x = volume
+  const dim3 grid(static_cast<unsigned>(count), (g.H + kBY - 1) / kBY, g.z_hi - g.z_lo), block(kBX, kBY, 1);
+  Vols v = {};
+  // 16 bytes per lane where every row of both containers starts 16-byte aligned
+  bool x4 = g.pitch % 4 == 0 && gi.pitch % 4 == 0;
+  for (size_t i = 0; i < count; ++i) {
+    v.in[i] = f3d_ptr<const float>(inputs[i]);
+    v.out[i] = f3d_ptr<float>(outputs[i]);
+    x4 = x4 && reinterpret_cast<uintptr_t>(v.in[i]) % 16 == 0 && reinterpret_cast<uintptr_t>(v.out[i]) % 16 == 0;
+  }
   const int n = static_cast<int>(in_n);
   const int out_n = axis == 0 ? g.W : (axis == 1 ? g.H : g.D);
   const float delta = static_cast<float>(n) / static_cast<float>(out_n);          // resample_3d.cu: the kernels' own divisions
   const float normalization = static_cast<float>(out_n) / static_cast<float>(n);
-  // 16 bytes per lane where every row of both containers starts 16-byte aligned
-  const bool x4 = g.pitch % 4 == 0 && gi.pitch % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0 &&
-                  reinterpret_cast<uintptr_t>(out) % 16 == 0;
   const bool staged = x4 && n <= kResampleRowMax && (n + 3) / 4 * 4 <= gi.pitch;
-  if (axis == 0 && staged) hipLaunchKernelGGL(k_resample_x_lds, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
-  if (axis == 0 && !staged) hipLaunchKernelGGL(k_resample<0>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
-  if (axis == 1 && x4) hipLaunchKernelGGL(k_resample_x4<1>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
-  if (axis == 2 && x4) hipLaunchKernelGGL(k_resample_x4<2>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
-  if (axis == 1 && !x4) hipLaunchKernelGGL(k_resample<1>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
-  if (axis == 2 && !x4) hipLaunchKernelGGL(k_resample<2>, grid, block, 0, f3d::stream(), in, out, gi, g, n, delta, normalization);
+  if (axis == 0 && staged) hipLaunchKernelGGL(k_resample_x_lds, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
+  if (axis == 0 && !staged) hipLaunchKernelGGL(k_resample<0>, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
+  if (axis == 1 && x4) hipLaunchKernelGGL(k_resample_x4<1>, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
+  if (axis == 2 && x4) hipLaunchKernelGGL(k_resample_x4<2>, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
+  if (axis == 1 && !x4) hipLaunchKernelGGL(k_resample<1>, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
+  if (axis == 2 && !x4) hipLaunchKernelGGL(k_resample<2>, grid, block, 0, f3d::stream(), v, gi, g, n, delta, normalization);
   F3D_HIP(hipGetLastError());
   return 0;
 }
@@ -394,29 +453,90 @@ static int resample_launch(int axis, f3d_devptr input, f3d_devptr output, size_t
 int f3d_resample_x(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
                    size_t in_width, const f3d_slab* slab)
 {
-  return resample_launch(0, input, output, out_width, out_height, out_depth, in_width, nullptr, slab, "f3d_resample_x");
+  return resample_launch(0, &input, &output, 1, out_width, out_height, out_depth, in_width, nullptr, slab, "f3d_resample_x");
 }
 
 int f3d_resample_y(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
                    size_t in_height, const f3d_slab* slab)
 {
-  return resample_launch(1, input, output, out_width, out_height, out_depth, in_height, nullptr, slab, "f3d_resample_y");
+  return resample_launch(1, &input, &output, 1, out_width, out_height, out_depth, in_height, nullptr, slab, "f3d_resample_y");
 }
 
 int f3d_resample_z(f3d_devptr input, f3d_devptr output, size_t out_width, size_t out_height, size_t out_depth,
                    size_t in_depth, const f3d_slab* slab_in, const f3d_slab* slab)
 {
-  return resample_launch(2, input, output, out_width, out_height, out_depth, in_depth, slab_in, slab, "f3d_resample_z");
+  return resample_launch(2, &input, &output, 1, out_width, out_height, out_depth, in_depth, slab_in, slab, "f3d_resample_z");
+}
+
+int f3d_resample_x_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_width, const f3d_slab* slab)
+{
+  return resample_launch(0, inputs, outputs, count, out_width, out_height, out_depth, in_width, nullptr, slab, "f3d_resample_x_n");
+}
+
+int f3d_resample_y_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_height, const f3d_slab* slab)
+{
+  return resample_launch(1, inputs, outputs, count, out_width, out_height, out_depth, in_height, nullptr, slab, "f3d_resample_y_n");
+}
+
+int f3d_resample_z_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_depth, const f3d_slab* slab_in, const f3d_slab* slab)
+{
+  return resample_launch(2, inputs, outputs, count, out_width, out_height, out_depth, in_depth, slab_in, slab, "f3d_resample_z_n");
+}
+
+static int add_launch(const f3d_devptr* operand_0, const f3d_devptr* operand_1, size_t count, size_t width, size_t height,
+                      size_t depth, const f3d_slab* slab, const char* who)
+{
+  F3D_REQUIRE_READY(who);
+  if (!operand_0 || !operand_1) return f3d::fail("%s: null argument", who);
+  if (!batch_ok(count, who)) return 1;
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
+  if (g.z_lo == g.z_hi) return 0;
+  Vols v = {};
+  for (size_t i = 0; i < count; ++i) {
+    v.out[i] = f3d_ptr<float>(operand_0[i]);
+    v.in[i] = f3d_ptr<const float>(operand_1[i]);
+  }
+  const int planes = g.z_hi - g.z_lo;
+  hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, planes * static_cast<int>(count)), dim3(kBX, kBY, 1), 0, f3d::stream(), v, g);
+  F3D_HIP(hipGetLastError());
+  return 0;
 }
 
 int f3d_add(f3d_devptr operand_0, f3d_devptr operand_1, size_t width, size_t height, size_t depth, const f3d_slab* slab)
 {
-  F3D_REQUIRE_READY("f3d_add");
+  return add_launch(&operand_0, &operand_1, 1, width, height, depth, slab, "f3d_add");
+}
+
+int f3d_add_n(const f3d_devptr* operand_0, const f3d_devptr* operand_1, size_t count, size_t width, size_t height, size_t depth,
+              const f3d_slab* slab)
+{
+  return add_launch(operand_0, operand_1, count, width, height, depth, slab, "f3d_add_n");
+}
+
+int f3d_clear_box_n(const f3d_devptr* volumes, size_t count, size_t width, size_t height, size_t depth, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_clear_box_n");
+  if (!volumes) return f3d::fail("f3d_clear_box_n: null argument");
+  if (!batch_ok(count, "f3d_clear_box_n")) return 1;
   F3dGeo g;
-  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_add")) return 1;
+  if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_clear_box_n")) return 1;
   if (g.z_lo == g.z_hi) return 0;
-  hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, g.z_hi - g.z_lo), dim3(kBX, kBY, 1), 0, f3d::stream(),
-                     f3d_ptr<float>(operand_0), f3d_ptr<const float>(operand_1), g);
+  Vols v = {};
+  bool vec = g.pitch % 4 == 0;
+  for (size_t i = 0; i < count; ++i) {
+    v.out[i] = f3d_ptr<float>(volumes[i]);
+    vec = vec && reinterpret_cast<uintptr_t>(v.out[i]) % 16 == 0;
+  }
+  const int chunks = vec ? (g.W + 3) / 4 : g.W;
+  const long rows = static_cast<long>(g.H) * (g.z_hi - g.z_lo);
+  const long total = rows * chunks;
+  if (total >= (1L << 32)) return f3d::fail("f3d_clear_box_n: box too large for one launch");
+  const dim3 grid(static_cast<unsigned>((total + 255) / 256), static_cast<unsigned>(count), 1);
+  hipLaunchKernelGGL(k_clear_box, grid, dim3(256, 1, 1), 0, f3d::stream(), v, g, chunks, static_cast<int>(rows), vec ? 1 : 0);
   F3D_HIP(hipGetLastError());
   return 0;
 }

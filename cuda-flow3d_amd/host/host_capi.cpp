@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "f3d_host.h"
 #include "hip_utils.h"
@@ -236,6 +237,19 @@ int f3d_op_execute(f3d_op op, const char* const* keys, void* const* value_ptrs, 
   if (auto* stat_p = dynamic_cast<CudaOperationStatP*>(op->op)) stat_p->silent = true;
   op->op->Execute(bag);
   return 0;
+}
+
+int f3d_op_execute_batch(f3d_op op, const char* const* keys, void* const* value_ptrs, const size_t* counts, size_t bags)
+{
+  if (!op || !counts || bags == 0) return 1;
+  std::vector<OperationParameters> bag(bags);
+  size_t at = 0;
+  for (size_t b = 0; b < bags; ++b)
+    for (size_t i = 0; i < counts[b]; ++i, ++at) bag[b].PushValuePtr(keys[at], value_ptrs[at]);
+  if (auto* add = dynamic_cast<CudaOperationAdd*>(op->op)) return add->ExecuteBatch(bag.data(), bags), 0;
+  if (auto* median = dynamic_cast<CudaOperationMedian*>(op->op)) return median->ExecuteBatch(bag.data(), bags), 0;
+  if (auto* resample = dynamic_cast<CudaOperationResample*>(op->op)) return resample->ExecuteBatch(bag.data(), bags), 0;
+  return 1;  // the other operators take one bag at a time
 }
 
 int f3d_op_set_slab(f3d_op op, const f3d_slab* slab)

@@ -5,6 +5,7 @@
 // is refreshed once per outer iteration.
 #include "operations.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <utility>
@@ -59,6 +60,37 @@ void CudaOperationAdd::Execute(OperationParameters& params)
   GET_PARAM_OR_RETURN(params, DevicePtr, operand_1, "operand_1");
   GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
   CheckDeviceError(f3d_add(operand_0, operand_1, data_size.width, data_size.height, data_size.depth, slab_));
+}
+
+namespace {
+constexpr size_t kBatchMax = 3;  // volumes per launch of the f3d_*_n entries
+bool SameBox(const DataSize4& a, const DataSize4& b) { return a.width == b.width && a.height == b.height && a.depth == b.depth; }
+}  // namespace
+
+void CudaOperationAdd::ExecuteBatch(OperationParameters* params, size_t count)
+{
+  if (!IsInitialized() || count == 0) return;
+  DevicePtr a[kBatchMax], b[kBatchMax];
+  DataSize4 size[kBatchMax];
+  bool together = count <= kBatchMax;
+  for (size_t i = 0; together && i < count; ++i) {
+    void *p0 = params[i].GetValuePtr("operand_0"), *p1 = params[i].GetValuePtr("operand_1"), *ps = params[i].GetValuePtr("data_size");
+    if (!p0 || !p1 || !ps) {
+      together = false;  // Execute prints which key is missing
+      break;
+    }
+    a[i] = *static_cast<DevicePtr*>(p0);
+    b[i] = *static_cast<DevicePtr*>(p1);
+    size[i] = *static_cast<DataSize4*>(ps);
+    together = SameBox(size[i], size[0]);
+    for (size_t j = 0; together && j < i; ++j) together = a[i] != a[j] && a[i] != b[j] && b[i] != a[j];
+  }
+  if (!together) {
+    for (size_t i = 0; i < count; ++i) Execute(params[i]);
+    return;
+  }
+  ProfilerRange range(GetName());
+  CheckDeviceError(f3d_add_n(a, b, count, size[0].width, size[0].height, size[0].depth, slab_));
 }
 
 // ---- flow statistics (cuda_operation_stat_p.cpp:44-107, on device data) ------------------------------------------
@@ -181,6 +213,36 @@ void CudaOperationMedian::Execute(OperationParameters& params)
   }
 }
 
+void CudaOperationMedian::ExecuteBatch(OperationParameters* params, size_t count)
+{
+  if (!IsInitialized() || count == 0) return;
+  DevicePtr in[kBatchMax], out[kBatchMax];
+  DataSize4 size[kBatchMax];
+  size_t radius[kBatchMax];
+  bool together = count <= kBatchMax;
+  for (size_t i = 0; together && i < count; ++i) {
+    void *pi = params[i].GetValuePtr("dev_input"), *po = params[i].GetValuePtr("dev_output"), *ps = params[i].GetValuePtr("data_size"),
+         *pr = params[i].GetValuePtr("radius");
+    if (!pi || !po || !ps || !pr) {
+      together = false;
+      break;
+    }
+    in[i] = *static_cast<DevicePtr*>(pi);
+    out[i] = *static_cast<DevicePtr*>(po);
+    size[i] = *static_cast<DataSize4*>(ps);
+    radius[i] = *static_cast<size_t*>(pr);
+    // the copy (1), the even-window warning and the range error stay with Execute
+    together = SameBox(size[i], size[0]) && radius[i] == radius[0] && (radius[i] == 3 || radius[i] == 5 || radius[i] == 7);
+    for (size_t j = 0; together && j <= i; ++j) together = in[i] != out[j] && in[j] != out[i] && (j == i || out[i] != out[j]);
+  }
+  if (!together) {
+    for (size_t i = 0; i < count; ++i) Execute(params[i]);
+    return;
+  }
+  ProfilerRange range(GetName());
+  CheckDeviceError(f3d_median_n(in, count, size[0].width, size[0].height, size[0].depth, radius[0], out, slab_));
+}
+
 // ---- warp (cuda_operation_registration.cpp:70-131) ----------------------------------------------------------
 
 void CudaOperationRegistration::Execute(OperationParameters& params)
@@ -236,6 +298,45 @@ void CudaOperationResample::Execute(OperationParameters& params)
   data_size.height = pass_out.height;
   pass_out.depth = resample_size.depth;
   ResampleZ(dev_temp, dev_output, data_size, pass_out);
+}
+
+void CudaOperationResample::ExecuteBatch(OperationParameters* params, size_t count)
+{
+  if (!IsInitialized() || count == 0) return;
+  DevicePtr in[kBatchMax], out[kBatchMax], tmp[kBatchMax];
+  DataSize4 from[kBatchMax], to[kBatchMax];
+  bool together = count <= kBatchMax;
+  for (size_t i = 0; together && i < count; ++i) {
+    void *pi = params[i].GetValuePtr("dev_input"), *po = params[i].GetValuePtr("dev_output"), *pt = params[i].GetValuePtr("dev_temp"),
+         *ps = params[i].GetValuePtr("data_size"), *pr = params[i].GetValuePtr("resample_size");
+    if (!pi || !po || !pt || !ps || !pr) {
+      together = false;
+      break;
+    }
+    in[i] = *static_cast<DevicePtr*>(pi);
+    out[i] = *static_cast<DevicePtr*>(po);
+    tmp[i] = *static_cast<DevicePtr*>(pt);
+    from[i] = *static_cast<DataSize4*>(ps);
+    to[i] = *static_cast<DataSize4*>(pr);
+    together = SameBox(from[i], from[0]) && SameBox(to[i], to[0]);
+    // nine distinct volumes: x writes out, y reads out and writes tmp, z reads tmp and writes out
+    for (size_t j = 0; together && j <= i; ++j) {
+      const DevicePtr mine[3] = {in[i], out[i], tmp[i]}, theirs[3] = {in[j], out[j], tmp[j]};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          if (mine[a] == theirs[b] && !(i == j && a == b)) together = false;
+    }
+  }
+  if (!together) {
+    for (size_t i = 0; i < count; ++i) Execute(params[i]);
+    return;
+  }
+  ProfilerRange range(GetName());
+  // the pass order and the mixed sizes of Execute above
+  const DataSize4 &s = from[0], &r = to[0];
+  if (CheckDeviceError(f3d_resample_x_n(in, out, count, r.width, s.height, s.depth, s.width, slab_))) return;
+  if (CheckDeviceError(f3d_resample_y_n(out, tmp, count, r.width, r.height, s.depth, s.height, slab_))) return;
+  CheckDeviceError(f3d_resample_z_n(tmp, out, count, r.width, r.height, r.depth, s.depth, nullptr, slab_));
 }
 
 void CudaOperationResample::ResampleX(DevicePtr input, DevicePtr output, DataSize4& in, DataSize4& out) const
@@ -376,13 +477,18 @@ void CudaOperationSolve::Execute(OperationParameters& params)
     std::printf(" % 3.0f%%", 0.f);
   }
 
-  // increments start from zero at every level: current width, every row of the planes the level has (the reference clears the
-  // planes beyond them too, :183-188; nothing reads those -- rows and planes mirror by address inside the level's box)
-  const size_t rows = dev_container_size_.height * std::min(data_size.depth, dev_container_size_.depth);
-  const size_t row_bytes = data_size.width * sizeof(float);
-  CheckDeviceError(f3d_memset2d(*du_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
-  CheckDeviceError(f3d_memset2d(*dv_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
-  CheckDeviceError(f3d_memset2d(*dw_ptr, dev_container_size_.pitch, 0, row_bytes, rows));
+  // increments start from zero at every level: the level's box, one launch for the three (the reference clears every row of every
+  // plane of the container, :183-188; nothing reads outside the box -- rows and planes mirror by address inside it)
+  {
+    const DevicePtr increments[3] = {*du_ptr, *dv_ptr, *dw_ptr};
+    // under a z-slab window the neighbours' planes held by the container are cleared too, as the row-wise clearing did
+    f3d_slab all = {0, 0, 0};
+    if (slab_) {
+      const long top = static_cast<long>(slab_->z_base) + static_cast<long>(dev_container_size_.depth);
+      all = {slab_->z_base, slab_->z_base, static_cast<int>(std::min<long>(static_cast<long>(data_size.depth), top))};
+    }
+    CheckDeviceError(f3d_clear_box_n(increments, 3, data_size.width, data_size.height, data_size.depth, slab_ ? &all : nullptr));
+  }
 
   const size_t w = data_size.width, h = data_size.height, d = data_size.depth;
   // Launch schedule of one outer iteration (the same bit pattern whichever way it is cut):

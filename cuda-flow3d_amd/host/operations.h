@@ -40,6 +40,9 @@ class CudaOperationAdd : public CudaOperationBase {
   CudaOperationAdd() : CudaOperationBase("CUDA Add") {}
   bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
   void Execute(OperationParameters& params) override;
+  // `count` bags (one per flow component, keys as for Execute) in ONE launch where they describe the same box (f3d_add_n);
+  // anything else -- more than three bags, differing sizes -- runs them one after the other through Execute.  Same results.
+  void ExecuteBatch(OperationParameters* params, size_t count);
 };
 
 // min / max / average flow magnitude        keys: dev_flow_u, dev_flow_v, dev_flow_w, data_size, stat (Stat3*)
@@ -77,6 +80,8 @@ class CudaOperationMedian : public CudaOperationBase {
   CudaOperationMedian() : CudaOperationBase("CUDA Median") {}
   bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
   void Execute(OperationParameters& params) override;
+  // `count` bags in one launch (f3d_median_n) where box and window agree and no input is another bag's output; else one by one
+  void ExecuteBatch(OperationParameters* params, size_t count);
 };
 
 // backward trilinear warp    keys: dev_frame_0, dev_frame_1, dev_flow_u/v/w, dev_output, data_size, hx, hy, hz
@@ -94,6 +99,9 @@ class CudaOperationResample : public CudaOperationBase {
   CudaOperationResample() : CudaOperationBase("CUDA Resample") {}
   bool Initialize(const OperationParameters* params = nullptr) override { return InitializeContainer(params); }
   void Execute(OperationParameters& params) override;
+  // `count` bags with the same data_size / resample_size in three launches instead of 3 x count (f3d_resample_{x,y,z}_n): every
+  // bag needs a dev_temp of its own, and no dev_input / dev_temp / dev_output may appear in two roles of the batch; else one by one
+  void ExecuteBatch(OperationParameters* params, size_t count);
 
  private:
   void ResampleX(DevicePtr input, DevicePtr output, DataSize4& input_size, DataSize4& output_size) const;

@@ -437,16 +437,20 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
       CheckDeviceError(f3d_memset2d(p, dev_container_size_.pitch, 0, dev_container_size_.width * sizeof(float), rows));
   }
 
-  auto resample = [&](DevicePtr& in, DevicePtr& out, DataSize4& from, DataSize4& to) {
-    DevicePtr dev_temp = Borrow();
-    op.Clear();
-    op.PushValuePtr("dev_input", &in);
-    op.PushValuePtr("dev_output", &out);
-    op.PushValuePtr("dev_temp", &dev_temp);
-    op.PushValuePtr("data_size", &from);
-    op.PushValuePtr("resample_size", &to);
-    cuop_resample_.Execute(op);
-    GiveBack(dev_temp);
+  // `count` volumes of one size through the three passes together (three launches instead of 3 x count): a temp each
+  auto resample = [&](DevicePtr* const* in, DevicePtr* const* out, size_t count, DataSize4& from, DataSize4& to) {
+    OperationParameters bags[3];
+    DevicePtr temps[3] = {0, 0, 0};
+    for (size_t i = 0; i < count; ++i) {
+      temps[i] = Borrow();
+      bags[i].PushValuePtr("dev_input", in[i]);
+      bags[i].PushValuePtr("dev_output", out[i]);
+      bags[i].PushValuePtr("dev_temp", &temps[i]);
+      bags[i].PushValuePtr("data_size", &from);
+      bags[i].PushValuePtr("resample_size", &to);
+    }
+    cuop_resample_.ExecuteBatch(bags, count);
+    for (size_t i = 0; i < count; ++i) GiveBack(temps[i]);
   };
 
   while (level >= 0) {
@@ -464,8 +468,9 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
       std::swap(dev_frame_0, dev_frame_0_res);
       std::swap(dev_frame_1, dev_frame_1_res_br);
     } else {
-      resample(dev_frame_0, dev_frame_0_res, original, current);
-      resample(dev_frame_1, dev_frame_1_res_br, original, current);
+      DevicePtr* const frames[2] = {&dev_frame_0, &dev_frame_1};
+      DevicePtr* const resampled[2] = {&dev_frame_0_res, &dev_frame_1_res_br};
+      resample(frames, resampled, 2, original, current);
     }
 
     // flow of the previous level brought to this size; values stay in original-voxel units (:303-345)
@@ -476,9 +481,9 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
       CheckDeviceError(f3d_memset2d(dev_flow_v, dev_container_size_.pitch, 0, row_bytes, rows));
       CheckDeviceError(f3d_memset2d(dev_flow_w, dev_container_size_.pitch, 0, row_bytes, rows));
     } else {
-      resample(dev_flow_u, dev_flow_du, prev_data_size, current);
-      resample(dev_flow_v, dev_flow_dv, prev_data_size, current);
-      resample(dev_flow_w, dev_flow_dw, prev_data_size, current);
+      DevicePtr* const coarse[3] = {&dev_flow_u, &dev_flow_v, &dev_flow_w};
+      DevicePtr* const fine[3] = {&dev_flow_du, &dev_flow_dv, &dev_flow_dw};
+      resample(coarse, fine, 3, prev_data_size, current);
       std::swap(dev_flow_u, dev_flow_du);
       std::swap(dev_flow_v, dev_flow_dv);
       std::swap(dev_flow_w, dev_flow_dw);
@@ -549,25 +554,28 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
     // flow += increment (:420-438), then median of each component (:444-473)
     DevicePtr* flow[3] = {&dev_flow_u, &dev_flow_v, &dev_flow_w};
     DevicePtr* incr[3] = {&dev_flow_du, &dev_flow_dv, &dev_flow_dw};
-    for (int i = 0; i < 3; ++i) {
-      op.Clear();
-      op.PushValuePtr("operand_0", flow[i]);
-      op.PushValuePtr("operand_1", incr[i]);
-      op.PushValuePtr("data_size", &current);
-      cuop_add_.Execute(op);
+    // the three components are independent through both steps: one launch each for the three of them.  The increments are
+    // consumed by "+=", so their containers take the filtered flow and the roles are swapped (the reference filters through one
+    // temp, a component at a time)
+    {
+      OperationParameters bags[3];
+      for (int i = 0; i < 3; ++i) {
+        bags[i].PushValuePtr("operand_0", flow[i]);
+        bags[i].PushValuePtr("operand_1", incr[i]);
+        bags[i].PushValuePtr("data_size", &current);
+      }
+      cuop_add_.ExecuteBatch(bags, 3);
     }
     {
-      DevicePtr dev_temp = Borrow();
+      OperationParameters bags[3];
       for (int i = 0; i < 3; ++i) {
-        op.Clear();
-        op.PushValuePtr("dev_input", flow[i]);
-        op.PushValuePtr("dev_output", &dev_temp);
-        op.PushValuePtr("data_size", &current);
-        op.PushValuePtr("radius", &median_radius);
-        cuop_median_.Execute(op);
-        std::swap(*flow[i], dev_temp);
+        bags[i].PushValuePtr("dev_input", flow[i]);
+        bags[i].PushValuePtr("dev_output", incr[i]);
+        bags[i].PushValuePtr("data_size", &current);
+        bags[i].PushValuePtr("radius", &median_radius);
       }
-      GiveBack(dev_temp);
+      cuop_median_.ExecuteBatch(bags, 3);
+      for (int i = 0; i < 3; ++i) std::swap(*flow[i], *incr[i]);
     }
 
     if (collect_level_statistics) {

@@ -622,12 +622,19 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       need_lo = std::max(need_lo, in.lo - src.lo);
       need_hi = std::max(need_hi, src.hi - in.hi);
     }
+    // the items (two frames or three flow components) of a pass in one launch: f3d_resample_*_n
+    const size_t n_items = items.size();
+    DevicePtr srcs[3], mids_p[3], dsts[3];
+    if (n_items == 0 || n_items > 3) return false;
     for (Local& l : locals_) {
       const f3d_slab in_own = Window(Din, l.rank, 0, 0);
-      for (const Item& it : items) {
-        if (!Check(f3d_resample_x(l.buf[it.src], l.buf[it.dst], to.width, from.height, Din, from.width, &in_own))) return false;
-        if (!Check(f3d_resample_y(l.buf[it.dst], l.buf[it.mid], to.width, to.height, Din, from.height, &in_own))) return false;
+      for (size_t k = 0; k < n_items; ++k) {
+        srcs[k] = l.buf[items[k].src];
+        mids_p[k] = l.buf[items[k].mid];
+        dsts[k] = l.buf[items[k].dst];
       }
+      if (!Check(f3d_resample_x_n(srcs, dsts, n_items, to.width, from.height, Din, from.width, &in_own))) return false;
+      if (!Check(f3d_resample_y_n(dsts, mids_p, n_items, to.width, to.height, Din, from.height, &in_own))) return false;
     }
     std::vector<Role> mids;
     for (const Item& it : items) mids.push_back(it.mid);
@@ -635,8 +642,11 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     for (Local& l : locals_) {
       const f3d_slab in_win = Window(Din, l.rank, need_lo, need_hi);
       const f3d_slab out_own = Window(Dout, l.rank, 0, 0);
-      for (const Item& it : items)
-        if (!Check(f3d_resample_z(l.buf[it.mid], l.buf[it.dst], to.width, to.height, Dout, Din, &in_win, &out_own))) return false;
+      for (size_t k = 0; k < n_items; ++k) {
+        mids_p[k] = l.buf[items[k].mid];
+        dsts[k] = l.buf[items[k].dst];
+      }
+      if (!Check(f3d_resample_z_n(mids_p, dsts, n_items, to.width, to.height, Dout, Din, &in_win, &out_own))) return false;
     }
     return true;
   };
@@ -740,8 +750,10 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per n_ex outer iterations
     for (Local& l : locals_) {
       l.weights_lo = l.weights_hi = 0;
-      for (Role r : {DU, DV, DW})
-        if (!Check(f3d_memset2d(l.buf[r], cpitch, 0, W * sizeof(float), crows))) return false;
+      // the increments start from zero on every plane of the level the container can hold (own planes and halo room), one launch
+      const f3d_slab room = Window(D, l.rank, halo_, halo_);
+      const DevicePtr incr[3] = {l.buf[DU], l.buf[DV], l.buf[DW]};
+      if (room.z_hi > room.z_lo && !Check(f3d_clear_box_n(incr, 3, W, H, D, &room))) return false;
     }
     // Overlapped order: one rank per process, a slab thick enough that zones and interior are distinct, and an exchange
     // to hide (not after the last outer iteration)
@@ -857,9 +869,8 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     // flow += increment on the slab, then the median with its own halo
     for (Local& l : locals_) {
       const f3d_slab own = Window(D, l.rank, 0, 0);
-      if (!Check(f3d_add(l.buf[FU], l.buf[DU], W, H, D, &own))) return false;
-      if (!Check(f3d_add(l.buf[FV], l.buf[DV], W, H, D, &own))) return false;
-      if (!Check(f3d_add(l.buf[FW], l.buf[DW], W, H, D, &own))) return false;
+      const DevicePtr flow[3] = {l.buf[FU], l.buf[FV], l.buf[FW]}, incr[3] = {l.buf[DU], l.buf[DV], l.buf[DW]};
+      if (!Check(f3d_add_n(flow, incr, 3, W, H, D, &own))) return false;
     }
     size_t radius = median_radius;
     if (radius != 1 && radius % 2 == 0) radius -= 1;
@@ -872,10 +883,12 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       if (!Exchange(D, W, H, {FU, FV, FW}, half, half)) return false;
       for (Local& l : locals_) {
         const f3d_slab own = Window(D, l.rank, 0, 0);
-        for (Role r : {FU, FV, FW}) {
-          if (!Check(f3d_median(l.buf[r], W, H, D, radius, l.buf[TMP], &own))) return false;
-          std::swap(l.buf[r], l.buf[TMP]);
-        }
+        // the three components in one launch; the increments are spent, their containers take the filtered flow
+        const DevicePtr flow[3] = {l.buf[FU], l.buf[FV], l.buf[FW]}, filtered[3] = {l.buf[DU], l.buf[DV], l.buf[DW]};
+        if (!Check(f3d_median_n(flow, 3, W, H, D, radius, filtered, &own))) return false;
+        std::swap(l.buf[FU], l.buf[DU]);
+        std::swap(l.buf[FV], l.buf[DV]);
+        std::swap(l.buf[FW], l.buf[DW]);
       }
     }
     prev = cur;

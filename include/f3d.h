@@ -246,6 +246,27 @@ int f3d_add(f3d_devptr operand_0, f3d_devptr operand_1, size_t width, size_t hei
 int f3d_median(f3d_devptr input, size_t width, size_t height, size_t depth, size_t radius, f3d_devptr output,
                const f3d_slab* slab);
 
+/* Up to three volumes of ONE box in one launch (extensions, no cu* site of their own): the reference runs "+=", the median and the
+ * three resampling passes once per flow component and frame (optical_flow_e.cpp:274-345, 420-473); the components do not depend
+ * on each other there, and on levels below ~128^3 a launch is mostly fixed cost.  Element i of every array belongs to volume i;
+ * the kernels, arguments and results are those of the single-volume entries above (which are the count = 1 case of these).  No
+ * input of a batch may be an output of the same batch.  count = 1 .. 3. */
+int f3d_resample_x_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_width, const f3d_slab* slab);
+int f3d_resample_y_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_height, const f3d_slab* slab);
+int f3d_resample_z_n(const f3d_devptr* inputs, const f3d_devptr* outputs, size_t count, size_t out_width, size_t out_height,
+                     size_t out_depth, size_t in_depth, const f3d_slab* slab_in, const f3d_slab* slab);
+int f3d_add_n(const f3d_devptr* operand_0, const f3d_devptr* operand_1, size_t count, size_t width, size_t height, size_t depth,
+              const f3d_slab* slab);
+int f3d_median_n(const f3d_devptr* inputs, size_t count, size_t width, size_t height, size_t depth, size_t radius,
+                 const f3d_devptr* outputs, const f3d_slab* slab);
+/* The box width x height x [slab planes] of up to three volumes of the current container set to +0.f in one launch: the
+ * increments du, dv, dw at the start of a level's solve.  The reference clears every row of every plane of the container there
+ * (three cuMemsetD2D8, cuda_operation_solve.cpp:183-188); nothing ever reads a row or plane outside the level's box -- every
+ * kernel mirrors by address inside it -- so only the box is written. */
+int f3d_clear_box_n(const f3d_devptr* volumes, size_t count, size_t width, size_t height, size_t depth, const f3d_slab* slab);
+
 /* c_Kernel upload: cuda_operation_convolution.cpp:160-161 (at most 51 taps, MAX_KERNEL_LENGTH) */
 int f3d_set_conv_taps(const float* taps, size_t count);
 /* convolution{Rows,Columns,Slices}Kernel, 7 args: cuda_operation_convolution.cpp:221-228,274-281,327-334;

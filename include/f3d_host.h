@@ -83,6 +83,10 @@ const char* f3d_op_name(f3d_op op);
 int f3d_op_initialize(f3d_op op, const f3d_size4* container_size);
 /* Execute(OperationParameters&): keys[i] -> value_ptrs[i] (non-owning, like the reference's bag) */
 int f3d_op_execute(f3d_op op, const char* const* keys, void* const* value_ptrs, size_t count);
+/* ExecuteBatch of the add, median and resample operators: `bags` bags laid end to end, bag b holding counts[b] entries -- up to
+ * three volumes of one box in one launch per kernel where the bags allow it, otherwise one Execute after the other (same results).
+ * Non-zero for operators without a batch form. */
+int f3d_op_execute_batch(f3d_op op, const char* const* keys, void* const* value_ptrs, const size_t* counts, size_t bags);
 int f3d_op_set_slab(f3d_op op, const f3d_slab* slab);
 int f3d_op_destroy(f3d_op op);
 

@@ -16,7 +16,7 @@
  *     GPU against the reference's own kernels.  The reference ships no tests, golden vectors or fixtures for them and no nvcc
  *     exists here, but its entire_data .cu files are plain CUDA C that hipcc accepts as HIP source unmodified: oracle/Makefile
  *     compiles the six of them (solve, median, resample, registration, convolution, add) where they lie into
- *     oracle/_ref/*.hsaco (gfx950, contraction off, IEEE division and square root; the recipe's comment names the two
+ *     oracle/_ref/<file>.hsaco (gfx950, contraction off, IEEE division and square root; the recipe's comment names the two
  *     include-guard definitions it needs and why nothing is written in place of any header), tests/ref_kernels.py launches them
  *     with the reference operators' block sizes, shared-memory sizes and argument lists, and
  *     tests/test_gpu_reference_kernels.py holds reference == oracle and product == reference bit for bit, kernel by kernel and

@@ -407,6 +407,68 @@ int f3d_median(f3d_devptr in, size_t width, size_t height, size_t depth, size_t 
   orc_median(P<float>(in), P<float>(out), o.W, o.H, o.D, static_cast<int>(radius), &o.g);
   return 0;
 }
+// the batched entries: the single-volume ones, one after the other
+static bool batch_ok(const void* a, const void* b, size_t count, const char* who)
+{
+  if (!a || !b) return fail("%s: null argument", who), false;
+  if (count == 0 || count > 3) return fail("%s: %zu volumes (one launch takes 1 .. 3)", who, count), false;
+  return true;
+}
+int f3d_resample_x_n(const f3d_devptr* in, const f3d_devptr* out, size_t count, size_t ow, size_t oh, size_t od, size_t in_w,
+                     const f3d_slab* slab)
+{
+  if (!batch_ok(in, out, count, "f3d_resample_x_n")) return 1;
+  for (size_t i = 0; i < count; ++i)
+    if (int e = resample(0, in[i], out[i], ow, oh, od, in_w, nullptr, slab, "f3d_resample_x_n")) return e;
+  return 0;
+}
+int f3d_resample_y_n(const f3d_devptr* in, const f3d_devptr* out, size_t count, size_t ow, size_t oh, size_t od, size_t in_h,
+                     const f3d_slab* slab)
+{
+  if (!batch_ok(in, out, count, "f3d_resample_y_n")) return 1;
+  for (size_t i = 0; i < count; ++i)
+    if (int e = resample(1, in[i], out[i], ow, oh, od, in_h, nullptr, slab, "f3d_resample_y_n")) return e;
+  return 0;
+}
+int f3d_resample_z_n(const f3d_devptr* in, const f3d_devptr* out, size_t count, size_t ow, size_t oh, size_t od, size_t in_d,
+                     const f3d_slab* slab_in, const f3d_slab* slab)
+{
+  if (!batch_ok(in, out, count, "f3d_resample_z_n")) return 1;
+  for (size_t i = 0; i < count; ++i)
+    if (int e = resample(2, in[i], out[i], ow, oh, od, in_d, slab_in, slab, "f3d_resample_z_n")) return e;
+  return 0;
+}
+int f3d_add_n(const f3d_devptr* a, const f3d_devptr* b, size_t count, size_t width, size_t height, size_t depth, const f3d_slab* slab)
+{
+  if (!batch_ok(a, b, count, "f3d_add_n")) return 1;
+  for (size_t i = 0; i < count; ++i)
+    if (int e = f3d_add(a[i], b[i], width, height, depth, slab)) return e;
+  return 0;
+}
+int f3d_median_n(const f3d_devptr* in, size_t count, size_t width, size_t height, size_t depth, size_t radius, const f3d_devptr* out,
+                 const f3d_slab* slab)
+{
+  if (!batch_ok(in, out, count, "f3d_median_n")) return 1;
+  for (size_t i = 0; i < count; ++i)
+    for (size_t j = 0; j < count; ++j)
+      if (in[i] == out[j]) return fail("f3d_median_n: input buffer cannot serve as output buffer");
+  for (size_t i = 0; i < count; ++i)
+    if (int e = f3d_median(in[i], width, height, depth, radius, out[i], slab)) return e;
+  return 0;
+}
+int f3d_clear_box_n(const f3d_devptr* volumes, size_t count, size_t width, size_t height, size_t depth, const f3d_slab* slab)
+{
+  if (!batch_ok(volumes, volumes, count, "f3d_clear_box_n")) return 1;
+  Geo o;
+  if (!make_geo(&o, width, height, depth, slab, "f3d_clear_box_n")) return 1;
+  for (size_t i = 0; i < count; ++i) {
+    float* p = P<float>(volumes[i]);
+    for (int z = o.g.z_lo; z < o.g.z_hi; ++z)
+      for (int y = 0; y < o.H; ++y)
+        std::memset(p + (static_cast<size_t>(z - o.g.z_base) * o.g.Hc + y) * o.g.pitch_f, 0, static_cast<size_t>(o.W) * sizeof(float));
+  }
+  return 0;
+}
 int f3d_set_conv_taps(const float* taps, size_t count)
 {
   if (!taps || count == 0 || count > 51 || count % 2 == 0) return fail("f3d_set_conv_taps: bad tap count %zu", count);

@@ -845,3 +845,102 @@ def test_every_tile_height_of_the_fused_kernels(f3d, oracle, dims, cdims, ty, mo
                 assert bit_same(box(g), cut(e)), f"{ty} rows, {label}, sweep + phi/ksi: {name}"
     finally:
         dev.close()
+
+
+def _dev_array(ptrs):
+    return (C.c_uint64 * len(ptrs))(*ptrs)
+
+
+@pytest.mark.parametrize("count", [1, 2, 3])
+@pytest.mark.parametrize("dims,cdims,window", [((37, 21, 9), (64, 32, 16), None), ((70, 9, 5), (70, 9, 5), None),
+                                               ((20, 12, 17), (24, 12, 17), (3, 11)), ((129, 7, 6), (132, 8, 6), None)])
+def test_batched_entries_equal_the_single_volume_ones(f3d, oracle, dims, cdims, window, count, monkeypatch):
+    """f3d_add_n, f3d_median_n (3, 5 -- every 5^3 kernel -- and 7), f3d_resample_{x,y,z}_n and f3d_clear_box_n on one, two and
+    three volumes of a box: what the single-volume entries (pinned to the oracle above) leave, volume by volume, also on a slab
+    window; nothing outside the box or the window is written."""
+    hip = f3d.hip()
+    rng = np.random.default_rng(hash((dims, count)) % 2**32)
+    W, H, D = dims
+    z_lo, z_hi = window or (0, D)
+    slab = C.byref(f3d.Slab(0, z_lo, z_hi)) if window else None
+    vols = [box_in_container(rng, dims, cdims, -2, 2) for _ in range(count)]
+    incs = [box_in_container(rng, dims, cdims, -1, 1) for _ in range(count)]
+    for v in vols:
+        v[:D, :H, :W][rng.random((D, H, W)) < 0.2] = 0.5
+    dev = Dev(f3d, cdims)
+    try:
+        # add
+        a1 = [dev.put(v) for v in vols]
+        a2 = [dev.put(v) for v in vols]
+        b = [dev.put(v) for v in incs]
+        for i in range(count):
+            f3d.check(hip.f3d_add(a1[i], b[i], W, H, D, slab))
+        f3d.check(hip.f3d_add_n(_dev_array(a2), _dev_array(b), count, W, H, D, slab))
+        for i in range(count):
+            one, many = dev.get(a1[i]), dev.get(a2[i])
+            assert one.tobytes() == many.tobytes()
+            exp = vols[i].copy()
+            oracle.add(exp, incs[i], dims)
+            assert bit_same(many[z_lo:z_hi, :H, :W], exp[z_lo:z_hi, :H, :W])
+        # median: every window, every 5^3 kernel
+        for r, variant in ((3, None), (5, "0"), (5, "1"), (5, "2"), (5, None), (7, None)):
+            if min(W, H, D) <= r // 2:
+                continue
+            if variant is None:
+                monkeypatch.delenv("F3D_MEDIAN_PAIR", raising=False)
+            else:
+                monkeypatch.setenv("F3D_MEDIAN_PAIR", variant)
+            o1 = [dev.out() for _ in range(count)]
+            o2 = [dev.out() for _ in range(count)]
+            for i in range(count):
+                f3d.check(hip.f3d_median(a1[i], W, H, D, r, o1[i], slab))
+            f3d.check(hip.f3d_median_n(_dev_array(a1), count, W, H, D, r, _dev_array(o2), slab))
+            for i in range(count):
+                assert dev.get(o1[i]).tobytes() == dev.get(o2[i]).tobytes(), (r, variant, i)
+        monkeypatch.delenv("F3D_MEDIAN_PAIR", raising=False)
+        # clear: the box (window planes) becomes +0, everything else keeps its bits
+        before = [dev.get(p) for p in a2]
+        f3d.check(hip.f3d_clear_box_n(_dev_array(a2), count, W, H, D, slab))
+        for i in range(count):
+            got = dev.get(a2[i])
+            assert (got[z_lo:z_hi, :H, :W].view(np.uint32) == 0).all()
+            keep = before[i].copy()
+            keep[z_lo:z_hi, :H, :W] = 0
+            assert got.tobytes() == keep.tobytes()
+        assert hip.f3d_add_n(_dev_array(a1), _dev_array(b), 0, W, H, D, slab) != 0
+        assert hip.f3d_add_n(_dev_array(a1 * 4), _dev_array(b * 4), 4, W, H, D, slab) != 0
+        if count > 1:
+            o = [dev.out() for _ in range(count)]
+            o[1] = a1[0]                                   # an input of the batch as another volume's output
+            assert hip.f3d_median_n(_dev_array(a1), count, W, H, D, 3, _dev_array(o), slab) != 0
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("count", [2, 3])
+@pytest.mark.parametrize("src,dst", [((37, 21, 9), (36, 20, 9)), ((36, 20, 9), (37, 21, 9)), ((50, 33, 23), (7, 5, 4)),
+                                     ((18, 18, 18), (128, 20, 40))])
+def test_batched_resampling(f3d, oracle, src, dst, count):
+    """The resample operator on a batch of bags (three launches for all volumes) against the oracle and against Execute bag by bag;
+    a batch whose bags share a temp falls back to one bag after the other and gives the same."""
+    rng = np.random.default_rng(hash((src, dst, count)) % 2**32)
+    cdims = tuple(max(a, b) + 3 for a, b in zip(src, dst))
+    inps = [box_in_container(rng, src, cdims, -5, 5) for _ in range(count)]
+    W, H, D = dst
+    dev = Dev(f3d, cdims)
+    try:
+        op = f3d.Operation("resample")
+        assert op.initialize(dev.cont)
+        pin = [dev.put(x) for x in inps]
+        for shared_temp in (False, True):
+            pout = [dev.out() for _ in range(count)]
+            one = dev.out()
+            ptmp = [one if shared_temp else dev.out() for _ in range(count)]
+            op.execute_batch([dict(dev_input=pin[i], dev_output=pout[i], dev_temp=ptmp[i], data_size=src, resample_size=dst)
+                              for i in range(count)])
+            for i in range(count):
+                exp = oracle.resample(inps[i], src, dst)
+                assert bit_same(dev.get(pout[i])[:D, :H, :W], exp[:D, :H, :W]), (i, shared_temp)
+        op.destroy()
+    finally:
+        dev.close()
