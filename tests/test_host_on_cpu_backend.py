@@ -120,6 +120,52 @@ CASE = textwrap.dedent('''
                 assert same(g[:d, :h, :w], e[:d, :h, :w]), (cdims, key)
             cont.free()
         op.destroy()
+    elif what == "batch":
+        # ExecuteBatch of the add / median / resample operators: bags that describe one box go out together (f3d_*_n), bags that do
+        # not -- another size, a shared temp, an output that is another bag's input -- one after the other; the oracle's values either way
+        rng = np.random.default_rng(5)
+        cdims = (40, 24, 12); cw, ch, cd = cdims
+        cont = pkg.Containers(*cdims)
+        def vol(dims):
+            w, h, d = dims
+            c = np.zeros((cd, ch, cw), np.float32)
+            c[:d, :h, :w] = rng.uniform(-2, 2, size=(d, h, w)).astype(np.float32)
+            return c
+        box = lambda a, dims: a[:dims[2], :dims[1], :dims[0]]
+        ops = {n: pkg.Operation(n) for n in ("add", "median", "resample")}
+        cont.new()                                        # the first allocation fixes the pitch the operators are initialised with
+        assert all(o.initialize(cont) for o in ops.values())
+        for sizes in (((30, 21, 9),) * 3, ((30, 21, 9), (30, 21, 9), (17, 9, 6)), ((30, 21, 9),) * 2):
+            a = [vol(s) for s in sizes]; b = [vol(s) for s in sizes]
+            pa = [cont.new(x) for x in a]; pb = [cont.new(x) for x in b]
+            ops["add"].execute_batch([dict(operand_0=pa[i], operand_1=pb[i], data_size=sizes[i]) for i in range(len(sizes))])
+            sums = []
+            for i, s in enumerate(sizes):
+                e = a[i].copy(); orc.add(e, b[i], s); sums.append(e)
+                assert same(box(cont.download(pa[i], cdims), s), box(e, s)), ("add", sizes, i)
+            po = [cont.new() for _ in sizes]
+            ops["median"].execute_batch([dict(dev_input=pa[i], dev_output=po[i], data_size=sizes[i], radius=5) for i in range(len(sizes))])
+            for i, s in enumerate(sizes):
+                assert same(box(cont.download(po[i], cdims), s), box(orc.median(sums[i], s, 5), s)), ("median", sizes, i)
+            to = (26, 24, 11)
+            for shared in (False, True):
+                pr = [cont.new() for _ in sizes]
+                one = cont.new()
+                pt = [one if shared else cont.new() for _ in sizes]
+                ops["resample"].execute_batch([dict(dev_input=pa[i], dev_output=pr[i], dev_temp=pt[i], data_size=sizes[i],
+                                                    resample_size=to) for i in range(len(sizes))])
+                for i, s in enumerate(sizes):
+                    assert same(box(cont.download(pr[i], cdims), to), box(orc.resample(sums[i], s, to), to)), ("resample", sizes, i, shared)
+        # an output that is another bag's input: the median goes bag by bag (and the second bag sees the first one's result)
+        x = [vol((30, 21, 9)) for _ in range(2)]
+        px = [cont.new(v) for v in x]; py = cont.new()
+        ops["median"].execute_batch([dict(dev_input=px[0], dev_output=px[1], data_size=(30, 21, 9), radius=3),
+                                     dict(dev_input=px[1], dev_output=py, data_size=(30, 21, 9), radius=3)])
+        m1 = orc.median(x[0], (30, 21, 9), 3)
+        assert same(box(cont.download(py, cdims), (30, 21, 9)), box(orc.median(m1, (30, 21, 9), 3), (30, 21, 9)))
+        for o in ops.values():
+            o.destroy()
+        cont.free()
     pkg.shutdown()
     print("ok", what)
 ''')
@@ -144,11 +190,11 @@ def run_case(what, libdir, sanitized):
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather", "batch"])
 def test_host_drivers_equal_the_oracle_on_the_cpu_backend(what):
     run_case(what, build("all"), sanitized=False)
 
 
-@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather"])
+@pytest.mark.parametrize("what", ["resident", "slabs", "piecemeal", "reinit", "gather", "batch"])
 def test_host_drivers_are_clean_under_asan_and_ubsan(what):
     run_case(what, build("asan"), sanitized=True)
