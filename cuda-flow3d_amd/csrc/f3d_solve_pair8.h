@@ -270,7 +270,8 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
 }
 
 // ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
-// arithmetic (LDS traffic, barriers and stores stay), bit 2 = the compute waves only keep the barriers
+// arithmetic (LDS traffic, barriers and stores stay), bit 2 = the compute waves only keep the barriers, bit 3 = arithmetic only behind the
+// prologue (no LDS reads, no step barriers), bit 5 (with bit 3: F3D_ABLATE8=40) = the prologue fetches one plane instead of three
 // FD: the kernel reads the frame derivatives fx, fy, fz, ft (k_frame_derivatives, once per level) instead of the frames: they
 // are centre values, so the frame entries of every neighbour -- their LDS reads, lane shifts, differences and the three
 // divisions by 4h -- drop out of stage 1 (a seventh of its arithmetic), for two more arrays to stream.
@@ -437,10 +438,12 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     };
     // prologue: planes qs-1, qs, qs+1 fill the three slots and must have landed before anybody reads
     issue(qs - 1);
-    issue(qs);
-    issue(qs + 1);
-    issue_c(qs);      // (a centre-only plane is needed as z+1 plane and as centre: never plane qs-1)
-    issue_c(qs + 1);
+    if (!(ABL & 32)) {  // ABL 32 (with 8: prologue-only probe): ONE plane instead of three -- is the prologue issue- or latency-bound?
+      issue(qs);
+      issue(qs + 1);
+      issue_c(qs);      // (a centre-only plane is needed as z+1 plane and as centre: never plane qs-1)
+      issue_c(qs + 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ABL & 8) return;
@@ -923,6 +926,7 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
       if (abl == 3) return go(k_pair8<MODE, TY, 3>);
       if (abl == 4) return go(k_pair8<MODE, TY, 4>);
       if (abl == 8) return go(k_pair8<MODE, TY, 8>);
+      if (abl == 40) return go(k_pair8<MODE, TY, 40>);
     }
     go(k_pair8<MODE, TY, 0>);
   }
