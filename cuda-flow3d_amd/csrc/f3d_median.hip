@@ -365,6 +365,11 @@ static int median_launch(const f3d_devptr* inputs, size_t count, size_t width, s
     mv.out[i] = f3d_ptr<float>(outputs[i]);
   }
   const unsigned nvol = static_cast<unsigned>(count);
+  if (count > 1 && static_cast<long>(g.z_hi - g.z_lo) * static_cast<long>(count) > 65535L) {  // grid.z: volume by volume
+    for (size_t i = 0; i < count; ++i)
+      if (int e = median_launch(inputs + i, 1, width, height, depth, radius, outputs + i, slab, who)) return e;
+    return 0;
+  }
   if (radius == 7) {
     mv.zblocks = g.z_hi - g.z_lo;
     const dim3 grid((g.W + kBX - 1) / kBX, (g.H + kBY - 1) / kBY, mv.zblocks * nvol);

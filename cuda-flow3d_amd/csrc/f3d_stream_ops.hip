@@ -501,7 +501,16 @@ static int add_launch(const f3d_devptr* operand_0, const f3d_devptr* operand_1, 
     v.in[i] = f3d_ptr<const float>(operand_1[i]);
   }
   const int planes = g.z_hi - g.z_lo;
-  hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, planes * static_cast<int>(count)), dim3(kBX, kBY, 1), 0, f3d::stream(), v, g);
+  if (static_cast<long>(planes) * static_cast<long>(count) > 65535L) {  // grid.z: a window that deep goes volume by volume
+    for (size_t i = 0; i < count; ++i) {
+      Vols one = {};
+      one.in[0] = v.in[i];
+      one.out[0] = v.out[i];
+      hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, planes), dim3(kBX, kBY, 1), 0, f3d::stream(), one, g);
+    }
+  } else {
+    hipLaunchKernelGGL(k_add, grid_for(g.W, g.H, planes * static_cast<int>(count)), dim3(kBX, kBY, 1), 0, f3d::stream(), v, g);
+  }
   F3D_HIP(hipGetLastError());
   return 0;
 }
