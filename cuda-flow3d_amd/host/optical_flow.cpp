@@ -137,6 +137,20 @@ bool OpticalFlowE::InitCudaOperations()
 
 DevicePtr OpticalFlowE::Borrow()
 {
+  // ComputeFlow holds at most 13 of the 15 containers at a time (ten roles + three temps of the batched flow resampling); a caller
+  // that keeps more -- results not yet released, a driver extended in place -- gets a fresh container instead of an empty stack
+  if (free_containers_.empty()) {
+    DevicePtr extra = 0;
+    size_t pitch = 0;
+    const size_t rows = dev_container_size_.height * dev_container_size_.depth;
+    if (CheckDeviceError(f3d_alloc_pitched(&extra, &pitch, dev_container_size_.width * sizeof(float), rows)) ||
+        pitch != dev_container_size_.pitch) {
+      std::printf("'%s': the container pool is empty and another container could not be allocated.\n", GetName());
+      if (extra) f3d_free(extra);
+      return 0;
+    }
+    return extra;   // joins the pool when it is given back
+  }
   DevicePtr p = free_containers_.back();
   free_containers_.pop_back();
   return p;
