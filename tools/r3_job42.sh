@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the "new" library of this job was a timing build (idle role in k_pair8) that was not kept -- see DESIGN.md section 7
 # round 3, GPU job 42: waves whose stage 1 nobody reads (rows outside the volume, the column wave of a one-column level) only keep
 # the barriers: kernel / pipeline / config / slab tests, then BASELINE configs 2, 3, 4 against the build before (ab_old/), alternating
 set -e

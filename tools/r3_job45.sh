@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: bit 1 of F3D_XCD_REMAP existed only in the timing build of this job (tx / ty exchanged in the tile decomposition of k_pair8); not kept -- see DESIGN.md section 7
 # round 3, GPU job 45: tile numbering of the fused launches along y first (F3D_XCD_REMAP=3) against x first (=1, shipped), alternating
 set -e
 R=$(pwd)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: F3D_PITCH_PAD existed only in the timing build of this job (f3d_alloc_pitched adding n x 256 B per row); not kept -- see DESIGN.md section 7
 # round 3, GPU job 46: row pitch of the containers padded by n x 256 B (F3D_PITCH_PAD) on the 512^3 solve: do 2 KiB rows alias in the memory system?
 set -e
 R=$(pwd)
