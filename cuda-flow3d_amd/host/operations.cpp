@@ -468,6 +468,23 @@ void CudaOperationSolve::Execute(OperationParameters& params)
   GET_PARAM_OR_RETURN(params, float, hz, "hz");
   GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
 
+  // increments start from zero at every level: the level's box, one launch for the three (the reference clears every row of every
+  // plane of the container, :183-188; nothing reads outside the box -- rows and planes mirror by address inside it)
+  {
+    const DevicePtr increments[3] = {*du_ptr, *dv_ptr, *dw_ptr};
+    // under a z-slab window the neighbours' planes held by the container are cleared too, as the row-wise clearing did
+    // (a container whose first plane lies BEFORE the volume -- rank 0 of the z-slab driver, z_base = own.lo - halo < 0 -- holds
+    // no data there: the window is the part of the container inside the volume)
+    f3d_slab all = {0, 0, 0};
+    if (slab_) {
+      const long top = static_cast<long>(slab_->z_base) + static_cast<long>(dev_container_size_.depth);
+      all = {slab_->z_base, std::max(0, slab_->z_base), static_cast<int>(std::min<long>(static_cast<long>(data_size.depth), top))};
+    }
+    if (slab_ && all.z_lo >= all.z_hi) return;  // the container holds no plane of this level
+    if (CheckDeviceError(f3d_clear_box_n(increments, 3, data_size.width, data_size.height, data_size.depth, slab_ ? &all : nullptr)))
+      return;  // sweeps on uncleared increments would be a wrong result, not a slow one
+  }
+
   f3d_event ev_start = nullptr, ev_stop = nullptr;
   if (!silent) {
     CheckDeviceError(f3d_event_create(&ev_start));
@@ -475,19 +492,6 @@ void CudaOperationSolve::Execute(OperationParameters& params)
     CheckDeviceError(f3d_event_record(ev_start));
     Utils::PrintProgressBar(0.f);
     std::printf(" % 3.0f%%", 0.f);
-  }
-
-  // increments start from zero at every level: the level's box, one launch for the three (the reference clears every row of every
-  // plane of the container, :183-188; nothing reads outside the box -- rows and planes mirror by address inside it)
-  {
-    const DevicePtr increments[3] = {*du_ptr, *dv_ptr, *dw_ptr};
-    // under a z-slab window the neighbours' planes held by the container are cleared too, as the row-wise clearing did
-    f3d_slab all = {0, 0, 0};
-    if (slab_) {
-      const long top = static_cast<long>(slab_->z_base) + static_cast<long>(dev_container_size_.depth);
-      all = {slab_->z_base, slab_->z_base, static_cast<int>(std::min<long>(static_cast<long>(data_size.depth), top))};
-    }
-    CheckDeviceError(f3d_clear_box_n(increments, 3, data_size.width, data_size.height, data_size.depth, slab_ ? &all : nullptr));
   }
 
   const size_t w = data_size.width, h = data_size.height, d = data_size.depth;
