@@ -18,6 +18,7 @@
 // Kernels: k_phiksi6 (A.3), k_sweep6 (one sweep, A.4), k_sweep7 (two consecutive sweeps in one launch).  The ladder
 // of earlier variants (register rows, LDS rows, buffer loads, halos two planes ahead, ...) is in DESIGN.md section 3
 // and in the git history.
+#include <cmath>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -1540,7 +1541,7 @@ int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, 
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep2")) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep2: every dimension must be at least 2");
   if (!pair_weights_finite(hx, hy, hz, equation_alpha))
-    return f3d::fail("f3d_solve_sweep2: alpha / h^2 is not finite (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
+    return f3d::fail("f3d_solve_sweep2: alpha / h^2 must be finite and not negative (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 2, "f3d_solve_sweep2")) return 1;
   SolveArgs a;
@@ -1573,7 +1574,7 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
   if (!f3d::make_geo(&g, width, height, depth, slab, "f3d_solve_sweep_phi_ksi")) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("f3d_solve_sweep_phi_ksi: every dimension must be at least 2");
   if (!pair_weights_finite(hx, hy, hz, equation_alpha))
-    return f3d::fail("f3d_solve_sweep_phi_ksi: alpha / h^2 is not finite (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
+    return f3d::fail("f3d_solve_sweep_phi_ksi: alpha / h^2 must be finite and not negative (alpha %g, h %g %g %g)", equation_alpha, hx, hy, hz);
   if (phi_next == phi || ksi_next == ksi || phi_next == ksi || ksi_next == phi)
     return f3d::fail("f3d_solve_sweep_phi_ksi: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)");
   if (g.pitch % kLanes != 0)
@@ -1693,7 +1694,7 @@ int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], siz
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
   if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("%s: every dimension must be at least 2", who);
-  if (!pair_weights_finite(hx, hy, hz, alpha)) return f3d::fail("%s: alpha / h^2 is not finite (alpha %g, h %g %g %g)", who, alpha, hx, hy, hz);
+  if (!pair_weights_finite(hx, hy, hz, alpha)) return f3d::fail("%s: alpha / h^2 must be finite and not negative (alpha %g, h %g %g %g)", who, alpha, hx, hy, hz);
   if (g.pitch % kLanes != 0) return f3d::fail("%s: the container pitch must be a multiple of 256 bytes (f3d_alloc_pitched gives that)", who);
   if (with_weights && (out[3] == in[8] || out[4] == in[9] || out[3] == in[9] || out[4] == in[8]))
     return f3d::fail("%s: phi_next / ksi_next must not alias phi / ksi (other tiles still read them)", who);

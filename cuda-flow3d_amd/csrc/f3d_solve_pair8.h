@@ -75,13 +75,15 @@ struct PairArgs {
   int fdivs_ok, sdivs_ok;
 };
 
-// The fused kernels apply the face weights alpha / h^2 by selection ((float)(flag) * w is w or +0 only for a finite w: 0 * inf is
-// NaN), so their entry points refuse spacings and alphas that do not give finite weights -- the reference would return NaN there.
+// The fused kernels apply the face weights alpha / h^2 by selection: (float)(flag) * w is w or +0 only for a finite w that is not
+// negative (0 * inf is NaN, 0 * -w is -0), so their entry points refuse spacings and alphas outside that -- documented in
+// include/f3d.h; the host drivers take the one-sweep launches (k_sweep6: the reference's multiply) for such parameters
+// (host/hip_utils.cpp: NoteSolveWeights), so that the operator API still returns what the reference would.
 inline bool pair_weights_finite(float hx, float hy, float hz, float alpha)
 {
   for (float h : {hx, hy, hz}) {
     const float w = alpha / (h * h);
-    if (!(w - w == 0.f)) return false;
+    if (!(w - w == 0.f) || std::signbit(w)) return false;
   }
   return true;
 }

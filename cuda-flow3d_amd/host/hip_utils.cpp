@@ -1,5 +1,7 @@
 #include "hip_utils.h"
 
+#include <cmath>
+
 #include <cstdlib>
 
 bool InitDeviceContextWithFirstAvailableDevice()
@@ -29,13 +31,29 @@ void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_he
                                   device_pitch, device_height, 0));
 }
 
+namespace {
+// The fused launches apply the face weights alpha / h^2 by selection, which equals the reference's (float)(flag) * w only for a
+// finite w that is not negative (include/f3d.h); a solve with other parameters -- the reference would propagate NaN or -0 --
+// takes the one-sweep launches, whose kernels multiply as the reference does.  Per thread: drivers on lanes solve side by side.
+thread_local bool g_solve_weights_plain = true;
+}  // namespace
+
+void NoteSolveWeights(float equation_alpha, float hx, float hy, float hz)
+{
+  g_solve_weights_plain = true;
+  for (float h : {hx, hy, hz}) {
+    const float w = equation_alpha / (h * h);   // the kernels' own expression (solve_3d.cu:437-439)
+    if (!(w - w == 0.f) || std::signbit(w)) g_solve_weights_plain = false;
+  }
+}
+
 bool FusedSweepsEnabled()
 {
   static const bool on = [] {
     const char* e = std::getenv("F3D_FUSED_SWEEPS");
     return !(e && e[0] == '0');
   }();
-  return on;
+  return on && g_solve_weights_plain;
 }
 
 bool FusedPhiKsiEnabled()

@@ -35,6 +35,9 @@ void CopyData3DtoDevice(Data3D& data3d, DevicePtr device_ptr, size_t device_heig
 void CopyData3DFromDevice(DevicePtr device_ptr, Data3D& data3d, size_t device_height, size_t device_pitch);
 // Inner sweeps are launched in fused pairs unless F3D_FUSED_SWEEPS=0 (A/B timing; the results are bit-identical).
 bool FusedSweepsEnabled();
+// called by every solver driver with the parameters of the solve it is about to launch: alpha / h^2 that is not finite or negative
+// switches the fused launches off for this thread until the next call (they select where the reference multiplies)
+void NoteSolveWeights(float equation_alpha, float hx, float hy, float hz);
 // The last sweep of an outer iteration and the phi/ksi of the next one are one launch unless F3D_FUSED_PHI_KSI=0.
 bool FusedPhiKsiEnabled();
 // F3D_FRAME_DERIVATIVES=1: the fused launches read frame derivatives computed once per level instead of the frames.  Off by

@@ -467,6 +467,7 @@ void CudaOperationSolve::Execute(OperationParameters& params)
   GET_PARAM_OR_RETURN(params, float, hy, "hy");
   GET_PARAM_OR_RETURN(params, float, hz, "hz");
   GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  NoteSolveWeights(equation_alpha, hx, hy, hz);
 
   // increments start from zero at every level: the level's box, one launch for the three (the reference clears every row of every
   // plane of the container, :183-188; nothing reads outside the box -- rows and planes mirror by address inside it)

@@ -618,6 +618,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   GET_PARAM_OR_RETURN(params, float, hy, "hy");
   GET_PARAM_OR_RETURN(params, float, hz, "hz");
   GET_PARAM_OR_RETURN(params, DataSize4, data_size, "data_size");
+  NoteSolveWeights(equation_alpha, hx, hy, hz);
 
   Data3D* fixed[5] = {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w};
   Data3D* inc[3] = {p_flow_du, p_flow_dv, p_flow_dw};

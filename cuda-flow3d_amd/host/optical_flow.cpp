@@ -95,6 +95,10 @@ bool OpticalFlowE::InitCudaMemory()
   const size_t optional_memory = pitch_guess * rows * CudaOperationSolve::ScratchVolumes();
   std::printf("Needed (approx.):\t%.0fMB (+ %.0fMB optional solver scratch)\n", needed_memory / mb, optional_memory / mb);
   if (needed_memory >= free_memory) return false;
+  // the fit decision counts the 15 containers only; what the optional scratch will meet is said here, so that a run that ends up on
+  // the schedules without it (frame builds, separate phi/ksi launches) is not a surprise (advisor, round 3)
+  if (optional_memory > 0 && needed_memory + optional_memory >= free_memory)
+    std::printf("Solver scratch	:	does not fit beside the containers: the solver will take the launches that need none\n");
 
   size_t allocated_memory = 0;
   for (size_t i = 0; i < kContainers; ++i) {

@@ -149,7 +149,19 @@ bool OpticalFlowSlab::GatherPlanes(int depth, size_t width, size_t height, Role 
       s_cnt.push_back(s_pos - s_off.back());
       r_cnt.push_back(r_pos - r_off.back());
     }
-    if (s_pos > stage_floats_ || r_pos > stage_floats_) {
+    // The decision to give up must be COLLECTIVE: what a rank packs and unpacks differs by rank (edge ranks move half of what middle
+    // ranks do, multi-hop plans vary further), and a rank that returned here while the others entered the grouped send / recv would
+    // leave them blocked.  Every rank therefore prices the plan of EVERY rank and all fail on the largest (advisor, round 3).
+    size_t worst = 0;
+    for (int r = 0; r < n_ranks_; ++r) {
+      size_t s_all = 0, r_all = 0;
+      for (const HaloTransfer& t : PlanHaloExchange(depth, r, n_ranks_, need, need)) {
+        s_all += static_cast<size_t>(t.send.size()) * plane;
+        r_all += static_cast<size_t>(t.recv.size()) * plane;
+      }
+      worst = std::max(worst, std::max(s_all, r_all));
+    }
+    if (worst > stage_floats_) {
       std::printf("'%s': staging buffer too small to gather %d planes of frame 1 on either side.\n", GetName(), need);
       failed_ = true;
       ok = false;
@@ -170,15 +182,21 @@ bool OpticalFlowSlab::WarpWithGatheredFrame(int D, size_t W, size_t H, float hx,
   for (int r = 0; r < n_ranks_; ++r) max_slab = std::max(max_slab, OwnedPlanes(D, r, n_ranks_).size());
   const size_t planes = static_cast<size_t>(max_slab) + 2 * static_cast<size_t>(need);
   const size_t plane_bytes = local_container_.pitch * local_container_.height;
-  if (planes > wide_planes_) {  // grows with the largest reach seen; released in Destroy()
+  if (planes > wide_planes_) {  // grows with the largest reach seen; released in Destroy()  (`planes` is the same on every rank)
     if (f1_wide_) f3d_free(f1_wide_);
     f1_wide_ = 0;
     wide_planes_ = 0;
     size_t pitch = 0;
-    if (!Check(f3d_alloc_pitched(&f1_wide_, &pitch, local_container_.width * sizeof(float), local_container_.height * planes * locals_.size())) ||
-        pitch != local_container_.pitch) {
-      std::printf("'%s': no room for %zu planes of frame 1 (warp reach %d beyond the halo capacity %d).\n", GetName(), planes, need - wide,
-                  halo_);
+    const bool got = f3d_alloc_pitched(&f1_wide_, &pitch, local_container_.width * sizeof(float),
+                                       local_container_.height * planes * locals_.size()) == 0 && pitch == local_container_.pitch;
+    // whether the memory is there can differ by rank: agree on it before anybody enters the gather's grouped send / recv
+    float nobody_failed = got ? 0.f : 1.f;
+    if (locals_.size() == 1 && n_ranks_ > 1 && !Check(f3d_comm_allreduce_max_f32(&nobody_failed))) return false;
+    if (nobody_failed != 0.f) {
+      if (got) f3d_free(f1_wide_);
+      f1_wide_ = 0;
+      std::printf("'%s': no room for %zu planes of frame 1 (warp reach %d beyond the halo capacity %d)%s.\n", GetName(), planes, need - wide,
+                  halo_, got ? " on another rank" : "");
       failed_ = true;
       return false;
     }
@@ -730,6 +748,7 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
     // exchange after every solver stage: the deepest stage reads p_max planes of the increments and of the weights beyond the
     // slab, the weights p_max + 1 planes of everything else
     const bool per_stage = exchange_per_stage_ && n_ranks_ > 1;
+    NoteSolveWeights(equation_alpha, hx, hy, hz);
     const int p_max = (FusedSweepsEnabled() && K >= 2) ? 2 : 1;
     if (per_stage) n_ex = 1;
     const int wide = per_stage ? p_max + 1 : n_ex * (K + 1);

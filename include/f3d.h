@@ -175,7 +175,11 @@ int f3d_solve_sweep(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f
 /* TWO consecutive solve_3d sweeps in one launch: temp_d* receive what two f3d_solve_sweep calls with a buffer swap in
  * between would leave in flow_d* (bit for bit); the intermediate field never goes to HBM, so the pair moves the bytes of
  * one sweep.  Replaces two iterations of the inner loop of cuda_operation_solve.cpp:222-255; the caller swaps ONCE.
- * A slab window [z_lo, z_hi) needs planes z_lo-2 .. z_hi+1 of every input inside the container. */
+ * A slab window [z_lo, z_hi) needs planes z_lo-2 .. z_hi+1 of every input inside the container.
+ * RESTRICTION of every fused entry (f3d_solve_sweep2, f3d_solve_sweep_phi_ksi[_edges] and their _fd forms): the three face weights
+ * equation_alpha / (h * h) must be finite and not negative -- the kernels select w or +0 where solve_3d.cu:437-445 multiplies by
+ * (float)(flag), which is the same float only then; other parameters are refused (status 1, f3d_last_error says so) and the
+ * caller uses f3d_solve_sweep / f3d_phi_ksi, which multiply like the reference (the host operators do that by themselves). */
 int f3d_solve_sweep2(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
                      f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi,
                      size_t width, size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,

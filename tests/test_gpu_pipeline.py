@@ -188,6 +188,56 @@ def test_solve_operator_through_the_bag(f3d, oracle, outer):
     cont.free()
 
 
+@pytest.mark.parametrize("alpha", [-0.02, float("inf")])
+def test_solve_operator_with_weights_the_fused_launches_refuse(f3d, oracle, alpha):
+    """alpha / h^2 negative or not finite: the fused launches select w or +0 where solve_3d.cu:437-445 multiplies by (float)(flag), which
+    is the same float only for a finite w that is not negative -- so their entry points refuse such parameters (include/f3d.h) and the
+    operator takes the one-sweep launches by itself; the result is what the reference's arithmetic gives, bit pattern for bit pattern
+    (signed zeros and NaN included)."""
+    rng = np.random.default_rng(6)
+    dims, cdims = (37, 21, 9), (64, 24, 12)
+    W, H, D = dims
+    cont = f3d.Containers(*cdims)
+
+    def put(lo, hi):
+        c = np.full((cdims[2], cdims[1], cdims[0]), np.nan, np.float32)
+        c[:D, :H, :W] = rng.uniform(lo, hi, size=(D, H, W)).astype(np.float32)
+        return c, cont.new(c)
+
+    hosts, ptrs = zip(*[put(*r) for r in [(0, 255), (0, 255), (-2, 2), (-2, 2), (-2, 2)]])
+    names = ["dev_flow_du", "dev_flow_dv", "dev_flow_dw", "dev_phi", "dev_ksi", "dev_temp_du", "dev_temp_dv", "dev_temp_dw"]
+    extra = {n: cont.new() for n in names}
+    h = (1.5, 1.2, 2.0)
+    # the fused entries say no ...
+    hip = f3d.hip()
+    outs = [extra[n] for n in ("dev_temp_du", "dev_temp_dv", "dev_temp_dw")]
+    incs = [extra[n] for n in ("dev_flow_du", "dev_flow_dv", "dev_flow_dw")]
+    assert hip.f3d_solve_sweep2(*ptrs, *incs, extra["dev_phi"], extra["dev_ksi"], W, H, D, *h, alpha, *outs, None) != 0
+    assert b"finite and not negative" in hip.f3d_last_error()
+    # ... and the operator computes what the reference would
+    op = f3d.Operation("solve")
+    assert op.initialize(cont)
+    outer, inner = 2, 3
+    vals = op.execute(dev_frame_0=ptrs[0], dev_frame_1=ptrs[1], dev_flow_u=ptrs[2], dev_flow_v=ptrs[3], dev_flow_w=ptrs[4],
+                      outer_iterations_count=outer, inner_iterations_count=inner, equation_alpha=alpha,
+                      equation_smoothness=0.001, equation_data=0.001, hx=h[0], hy=h[1], hz=h[2], data_size=dims, **extra)
+    f3d.sync()
+    du = np.full_like(hosts[0], np.nan); du[:, :, :W] = 0
+    dv, dw = du.copy(), du.copy()
+    for _ in range(outer):
+        phi, ksi = oracle.phi_ksi(*hosts, du, dv, dw, dims, h, 0.001, 0.001)
+        for _ in range(inner):
+            du, dv, dw = oracle.solve_sweep(*hosts, du, dv, dw, phi, ksi, dims, h, alpha)
+    for key, e in (("dev_flow_du", du), ("dev_flow_dv", dv), ("dev_flow_dw", dw), ("dev_phi", phi), ("dev_ksi", ksi)):
+        g = cont.download(vals[key], cdims)[:D, :H, :W]
+        e = e[:D, :H, :W]
+        nan_g, nan_e = np.isnan(g), np.isnan(e)
+        assert np.array_equal(nan_g, nan_e), key
+        assert np.array_equal(g.view(np.uint32)[~nan_g], e.view(np.uint32)[~nan_e]), key
+    op.destroy()
+    cont.free()
+
+
 def test_missing_key_is_reported_not_fatal(f3d, capfd):
     cont = f3d.Containers(16, 8, 8)
     p = cont.new()
