@@ -22,11 +22,14 @@ One JSON line on stdout carries the metric plus
                  host cores on BASELINE config 2 (128^3, full default pyramid), timed fully.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu] [--no-extra]
-For N > 1 the volume is z-slab partitioned over one rank per GPU and the default size is BASELINE config 5 (1024^3).  Two ways
+For N > 1 the SAME volume (512^3 by default, like N = 1: one size per sweep) is z-slab partitioned over one rank per GPU; the line
+then carries both exchange orders timed in this one invocation (`exchange_orders`; `value` = the faster), the measured microseconds
+per exchange (`exchange_us`), the unsplit single-GPU solve of the same volume on rank 0's device (`single_gpu_same_size`) and the
+`speedup` over it, and -- unless --no-config5 / --no-extra -- the same record for BASELINE config 5 (1024^3) under `config5`.  Two ways
 in: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment), or
 bare -- `python bench.py --gpus N` starts the N rank processes itself (launch_ranks: the parent never loads the native
 library or touches the GPU, forwards rank 0's JSON line, and exits non-zero if any rank fails or hangs).
-F3D_SLAB_EXCHANGE=stage in the environment runs the other (bit-identical) halo-exchange order; the line says which one ran.
+F3D_SLAB_EXCHANGE=stage|outer in the environment pins one halo-exchange order instead of timing both.
 """
 import argparse
 import ctypes as C
@@ -53,8 +56,9 @@ def log(*a):
 
 def solver_source_stamp():
     """sha256 (16 hex digits) of the solver kernel source with comments and white space taken out (a reworded comment is not
-    another kernel): the PMC record is only valid for the kernels it was taken on.  tools/pmc_traffic.sh stamps its record
-    with this function."""
+    another kernel) and without the `#ifdef F3D_LAB` blocks (timing builds that only lib/lab/ has): the PMC record is only valid
+    for the kernels it was taken on.  tools/pmc_traffic.sh stamps its record with this function;
+    tests/test_abi.py::test_the_newest_counter_record_is_of_the_shipped_kernels holds the newest record to it."""
     import re
     h = hashlib.sha256()
     for name in ("f3d_solve.hip", "f3d_solve_pair8.h"):
@@ -62,6 +66,7 @@ def solver_source_stamp():
             text = f.read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)     # block comments
         text = re.sub(r"//[^\n]*", " ", text)                  # line comments (no string of these files holds "//")
+        text = re.sub(r"#ifdef F3D_LAB\b.*?#endif", " ", text, flags=re.S)   # lab-only dispatch: not in the shipped library
         h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
@@ -415,11 +420,190 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
-def run_multi(args):
-    """One rank per GPU (launched by torch.distributed.run): the volume is cut into z-slabs, halo planes travel over
-    RCCL (ncclSend/ncclRecv inside libf3d_hip.so); torch.distributed (gloo) only carries the 128-byte RCCL id, the
-    barriers and the max-over-ranks of the timings."""
+ORDERS = (("per_outer_iteration", False, "once per outer iteration: K + 1 = 6 planes of du, dv, dw, sweeps on widened windows "
+                                          "(thin slabs of small levels: 6n planes once per n <= 4 outer iterations)"),
+          ("per_stage", True, "after every solver stage: 2 / 1 / 3 planes, stages on the slab itself"))
+
+
+def measure_multi(pkg, dist, torch, rank, world, S, steps, warmup, args):
+    """One size of the multi-GPU sweep: the SAME S^3 volume on `world` z-slabs (strong scaling), BOTH exchange orders timed in this
+    one invocation (bit-identical; which wins is a property of the machine's exchange latency), then -- outside every timed
+    region -- one solve per order with HIP events around the exchanges (microseconds per exchange) and, on rank 0's device, the
+    unsplit single-GPU solve of the same volume, so that the line carries its own speedup."""
     import numpy as np
+    hip = pkg.hip()
+    halo = 32  # room for four outer iterations per exchange on thin slabs (24 planes) plus the warp reach
+    lo, hi = pkg.plan_owned(S, rank, world)
+    zlo, zhi = max(0, lo - halo), min(S, hi + halo)
+    if rank == 0:
+        log(f"[bench] {world} ranks, {S}^3 volume, rank 0 owns planes [{lo},{hi})")
+    f0 = np.empty((S, S, S), np.float32)  # only the slab's pages are ever touched
+    f1 = np.empty((S, S, S), np.float32)
+    local_max = pkg.synth_planes(S, S, S, zlo, zhi, f0, f1)
+    t = torch.tensor([local_max], dtype=torch.float32)
+    # the global maximum needs every plane once: each rank also scans its OWN planes (halos overlap, max is idempotent)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    scale = np.float32(255.0) / np.float32(t.item())
+    f0[zlo:zhi] *= scale
+    f1[zlo:zhi] *= scale
+
+    flow = pkg.SlabOpticalFlow(world, [rank], halo_capacity=halo)
+    flow.initialize(S, S, S)
+    flow.upload(f0, f1)
+    del f0, f1
+    env_order = os.environ.get("F3D_SLAB_EXCHANGE")          # an explicit choice in the environment pins the order
+    orders = [o for o in ORDERS if env_order is None or (o[1] == (env_order == "stage"))]
+    if args.one_order:
+        orders = orders[:1]
+    measured = {}
+    for name, per_stage, what in orders:
+        flow.set_exchange_per_stage(per_stage)
+        for i in range(warmup):
+            tsec = flow.compute_resident()
+            if rank == 0:
+                log(f"[bench] {S}^3 {name} warmup {i}: {tsec:.3f} s")
+        before = pkg.comm_info()
+        hip.f3d_prof_reset()
+        hip.f3d_prof_select(0x6)   # events on the sweep kernels only (ids 1 and 2): they are what the roofline line reports
+        hip.f3d_prof_enable(1)
+        pkg.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            flow.compute_resident()
+        pkg.sync()
+        dist.barrier()
+        wall = time.perf_counter() - t0
+        hip.f3d_prof_enable(0)
+        tw = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = tw.item()
+        after = pkg.comm_info()
+        tot_ms, tot_bytes, launches = 0.0, 0.0, 0
+        per_kernel = {}
+        for kid, bpv in ((1, SWEEP_BYTES_PER_VOXEL), (2, 2 * SWEEP_BYTES_PER_VOXEL)):
+            ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
+            pkg.check(hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox)))
+            tot_ms += ms.value
+            tot_bytes += bpv * vox.value
+            launches += n.value
+            per_kernel[kid] = (ms.value, n.value, vox.value)
+        # outside the timed region: every rank hashes the planes it owns, rank 0 compares the whole with the single-GPU digest
+        mine = pkg.flow_plane_digests(flow.download(), lo, hi)
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        mine_comm = {"rank": after["rank"], "device": after["device"], "sent_bytes": after["sent_bytes"] - before["sent_bytes"],
+                     "exchanges": after["exchanges"] - before["exchanges"]}
+        comms = [None] * world if rank == 0 else None
+        dist.gather_object(mine_comm, comms, dst=0)
+        # one more solve, untimed, with events around every exchange: what an exchange costs on THIS machine
+        pkg.comm_timing(True)
+        flow.compute_resident()
+        timing = pkg.comm_timing_read()
+        pkg.comm_timing(False)
+        timings = [None] * world if rank == 0 else None
+        dist.gather_object(timing, timings, dst=0)
+        if rank == 0:
+            parity = parity_record(S, pkg.combine_plane_digests([[d for part in gathered for d in part[c]] for c in range(3)]))
+            log(f"[bench] {S}^3 {name}: {wall / steps * 1e3:.1f} ms per step; digest {parity['digest'][:16]}... matches the committed "
+                f"single-GPU one: {parity['match']}")
+            achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
+            measured[name] = {
+                "exchange_order": what, "ms_per_step": round(wall / steps * 1e3, 3), "value": round(S ** 3 * steps / wall / 1e6, 4),
+                "parity": parity, "rank0_solver_sweeps_GBs": round(achieved, 1), "rank0_sweep_launches": launches,
+                "_per_kernel": per_kernel,
+                "comm": {"per_rank": comms, "halo_GB_sent_per_step": round(sum(c["sent_bytes"] for c in comms) / 1e9 / steps, 4),
+                         "exchanges_per_step_rank0": comms[0]["exchanges"] // max(1, steps)},
+                # microseconds per exchange, measured (HIP events: pack -> grouped send / recv -> unpack on the library stream; the
+                # transfer alone on the stream it was posted to): per rank, from one untimed solve
+                "exchange_us": {"rank0": timings[0],
+                                "worst_rank_mean_us_blocking": max((x["blocking_exchange"]["mean_us"] or 0.0) for x in timings),
+                                "worst_rank_mean_us_transfer_alone": max((x["grouped_send_recv_alone"]["mean_us"] or 0.0) for x in timings)},
+            }
+    comm = pkg.comm_info()
+    flow.destroy()
+    # the unsplit solve of the same volume on rank 0's device (the others wait): every multi-GPU line carries its own baseline
+    single = None
+    if rank == 0 and not args.no_single:
+        log(f"[bench] single-GPU solve of the same {S}^3 volume on rank 0's device ...")
+        g0, g1 = pkg.synth_pair(S, S, S)
+        one = pkg.OpticalFlow()
+        one.initialize(S, S, S)
+        one.upload(g0, g1)
+        del g0, g1
+        one.compute_resident(silent=True)
+        pkg.sync()
+        n1 = max(1, min(steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(n1):
+            one.compute_resident(silent=True)
+        pkg.sync()
+        dt = (time.perf_counter() - t0) / n1
+        digest1 = pkg.combine_plane_digests(pkg.flow_plane_digests(one.download()))
+        one.destroy()
+        single = {"ms_per_step": round(dt * 1e3, 3), "value": round(S ** 3 / dt / 1e6, 4), "unit": "Mvoxels/s", "steps": n1,
+                  "what": f"OpticalFlowE (resident, unsplit) on the same {S}^3 pair on rank 0's device, after the timed regions",
+                  "digest_equals_the_slab_runs": all(m["parity"]["digest"] == digest1 for m in measured.values())}
+    dist.barrier()
+    if rank != 0:
+        return None
+    best = min(measured, key=lambda k: measured[k]["ms_per_step"])
+    b = measured[best]
+    whole = TOTAL_BYTES.get(S)
+    achieved = b["rank0_solver_sweeps_GBs"]
+    roof = {"bound": "hbm", "kernel": "k_pair8 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's slab incl. widened "
+                                      "windows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": b["rank0_sweep_launches"]}
+    traffic = measured_traffic("k_pair8")
+    ms2, n2, vox2 = b["_per_kernel"][2]
+    if traffic and traffic.get("traffic") and n2:
+        # the fused launches of this run priced with the bytes per voxel the memory system moved in the committed counter
+        # passes (one unsplit launch of the finest level): slab windows re-read two more halo planes per chunk, so this is
+        # a lower bound of the real rate
+        tsize = traffic.pop("_size", 512)
+        per_voxel = traffic["traffic"] / float(tsize) ** 3
+        real = per_voxel * vox2 / (ms2 * 1e-3) / 1e9
+        roof.update({"traffic": traffic["traffic"], "traffic_scope": traffic["traffic_scope"],
+                     "hbm_GBs": round(real, 1), "hbm_frac": round(real / HBM_PEAK_GBS, 4),
+                     "hbm_frac_scope": f"the {n2} two-sweep launches of rank 0 at the measured {per_voxel:.1f} B per voxel"})
+    for m in measured.values():
+        m.pop("_per_kernel")
+    shm = os.environ.get("F3D_COMM_BACKEND") == "shm"
+    out = {
+        "metric": "Mvoxels/s full pyramid solve", "value": b["value"],
+        "unit": "Mvoxels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": b["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "parity": b["parity"],
+        "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair"
+                               + (" (BASELINE config 4: the size the metric is quoted on)" if S == 512 else
+                                  " (BASELINE config 5, the z-slab scaling workload)" if S == 1024 else "")
+                               + ", full coarse-to-fine pyramid (40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian "
+                                 "sigma 2), frames resident in HBM; the SAME volume at every N (strong scaling)",
+                   "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL, {b['exchange_order']}"
+                                  + (" -- REHEARSAL: shared-memory transport, ranks share devices" if shm else "")},
+        # both bit-identical exchange orders (DESIGN.md section 5) were timed in this invocation: `value` is the faster one
+        "exchange_order": best, "exchange_orders": measured,
+        # the unsplit solve of the same volume on rank 0's device and what the N GPUs make of it
+        "single_gpu_same_size": single,
+        "speedup": round(b["value"] / single["value"], 4) if single else None,
+        "launched_by": "bench.py itself (one child process per rank)" if os.environ.get("F3D_BENCH_LAUNCHED") == "1"
+                       else "an external launcher (RANK / WORLD_SIZE were set)",
+        # the communicator as the transport reports it: `rccl_ranks` is ncclCommCount's answer on rank 0, not WORLD_SIZE
+        "rccl_ranks": comm["ranks"], "comm_backend": comm["backend"],
+        "comm": b["comm"],
+        "exchange_us": b["exchange_us"],
+        "whole_run_roofline_frac": round(whole / (b["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 4) if whole else None,
+        "roofline": roof,
+    }
+    return out
+
+
+def run_multi(args):
+    """One rank per GPU (launched by torch.distributed.run, or by this script itself when started bare): the volume is cut into
+    z-slabs, halo planes travel over RCCL (ncclSend/ncclRecv inside libf3d_hip.so); torch.distributed (gloo) only carries the
+    128-byte RCCL id, the barriers and the max-over-ranks of the timings.  The sweep is quoted on ONE size for every N -- 512^3, the
+    size BASELINE.json's metric names -- and, time allowing, BASELINE config 5 (1024^3) rides along in the same line under
+    `config5` with its own single-GPU time and speedup."""
     pkg = importlib.import_module("cuda-flow3d_amd")  # load the native library (and /opt/rocm's HIP) before torch
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
@@ -442,118 +626,14 @@ def run_multi(args):
     dist.broadcast_object_list(box, src=0)
     pkg.comm_init(box[0], rank, world, device=device)
 
-    S = args.size
-    halo = 32  # room for four outer iterations per exchange on thin slabs (24 planes) plus the warp reach
-    lo, hi = pkg.plan_owned(S, rank, world)
-    zlo, zhi = max(0, lo - halo), min(S, hi + halo)
-    if rank == 0:
-        log(f"[bench] {world} ranks, {S}^3 volume, rank 0 owns planes [{lo},{hi})")
-    f0 = np.empty((S, S, S), np.float32)  # only the slab's pages are ever touched
-    f1 = np.empty((S, S, S), np.float32)
-    local_max = pkg.synth_planes(S, S, S, zlo, zhi, f0, f1)
-    t = torch.tensor([local_max], dtype=torch.float32)
-    # the global maximum needs every plane once: each rank also scans its OWN planes (halos overlap, max is idempotent)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    scale = np.float32(255.0) / np.float32(t.item())
-    f0[zlo:zhi] *= scale
-    f1[zlo:zhi] *= scale
-
-    flow = pkg.SlabOpticalFlow(world, [rank], halo_capacity=halo)
-    flow.initialize(S, S, S)
-    flow.upload(f0, f1)
-    del f0, f1
-    hip = pkg.hip()
-    for i in range(args.warmup):
-        tsec = flow.compute_resident()
+    out = measure_multi(pkg, dist, torch, rank, world, args.size, args.steps, args.warmup, args)
+    if args.size == 512 and not args.no_extra and not args.no_config5:
+        # BASELINE config 5 in the same invocation, bounded: one warm-up and two steps per exchange order
+        c5 = measure_multi(pkg, dist, torch, rank, world, 1024, min(args.steps, 2), 1, args)
         if rank == 0:
-            log(f"[bench] warmup {i}: {tsec:.3f} s")
-
-    hip.f3d_prof_reset()
-    hip.f3d_prof_select(0x6)   # events on the sweep kernels only (ids 1 and 2): they are what the roofline line reports
-    hip.f3d_prof_enable(1)
-    pkg.sync()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        flow.compute_resident()
-    pkg.sync()
-    dist.barrier()
-    wall = time.perf_counter() - t0
-    hip.f3d_prof_enable(0)
-    tw = torch.tensor([wall], dtype=torch.float64)
-    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-    wall = tw.item()
-
-    tot_ms, tot_bytes, launches = 0.0, 0.0, 0
-    per_kernel = {}
-    for kid, bpv in ((1, SWEEP_BYTES_PER_VOXEL), (2, 2 * SWEEP_BYTES_PER_VOXEL)):
-        ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
-        pkg.check(hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox)))
-        tot_ms += ms.value
-        tot_bytes += bpv * vox.value
-        launches += n.value
-        per_kernel[kid] = (ms.value, n.value, vox.value)
-    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms else 0.0
-    comm = pkg.comm_info()      # what RCCL itself says about the communicator this run used, and what went through it
-    # outside the timed region: every rank hashes the planes it owns, rank 0 compares the whole with the single-GPU digest
-    mine = pkg.flow_plane_digests(flow.download(), lo, hi)
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(mine, gathered, dst=0)
-    comms = [None] * world if rank == 0 else None
-    dist.gather_object(comm, comms, dst=0)
-    parity = None
-    if rank == 0:
-        parity = parity_record(S, pkg.combine_plane_digests([[d for part in gathered for d in part[c]] for c in range(3)]))
-        log(f"[bench] result digest {parity['digest'][:16]}... matches the committed single-GPU one: {parity['match']}")
-    flow.destroy()
+            out["config5"] = c5
     pkg.comm_destroy()
     if rank == 0:
-        whole = TOTAL_BYTES.get(S)
-        roof = {"bound": "hbm", "kernel": "k_pair8 + k_sweep6 (all solver sweeps, 52 B per voxel-sweep) on rank 0's "
-                                          "slab incl. widened windows",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches}
-        traffic = measured_traffic("k_pair8")
-        ms2, n2, vox2 = per_kernel[2]
-        if traffic and traffic.get("traffic") and n2:
-            # the fused launches of this run priced with the bytes per voxel the memory system moved in the committed counter
-            # passes (one unsplit launch of the finest level): slab windows re-read two more halo planes per chunk, so this is
-            # a lower bound of the real rate
-            tsize = traffic.pop("_size", 512)
-            per_voxel = traffic["traffic"] / float(tsize) ** 3
-            real = per_voxel * vox2 / (ms2 * 1e-3) / 1e9
-            roof.update({"traffic": traffic["traffic"], "traffic_scope": traffic["traffic_scope"],
-                         "hbm_GBs": round(real, 1), "hbm_frac": round(real / HBM_PEAK_GBS, 4),
-                         "hbm_frac_scope": f"the {n2} two-sweep launches of rank 0 at the measured {per_voxel:.1f} B per voxel"})
-        out = {
-            "metric": "Mvoxels/s full pyramid solve", "value": round(S ** 3 * args.steps / wall / 1e6, 4),
-            "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "parity": parity,
-            "config": {"workload": f"{S}^3 synthetic translated-Gaussian float32 pair"
-                                   + (" (BASELINE config 5, the multi-GPU scaling workload)" if S == 1024 else "")
-                                   + ", full coarse-to-fine pyramid "
-                                   "(40 levels x 40 outer x 5 inner, alpha 7.5, median 5^3, Gaussian sigma 2), "
-                                   "frames resident in HBM",
-                       "parallelism": f"z-slab decomposition over {world} GPUs, halo exchange on RCCL once per outer "
-                                      "iteration (6 planes of du, dv, dw; thin slabs of small levels: 6n planes once per "
-                                      "n <= 4 outer iterations)"
-                                      + (" -- REHEARSAL: shared-memory transport, ranks share devices"
-                                         if os.environ.get("F3D_COMM_BACKEND") == "shm" else "")},
-            # which of the two bit-identical exchange orders ran: one message of K + 1 planes per outer iteration with
-            # the sweeps on widened windows (default), or one message per solver stage (F3D_SLAB_EXCHANGE=stage) -- to be A/B'd on hardware
-            "exchange_order": "per solver stage (2 / 1 / 3 planes)" if os.environ.get("F3D_SLAB_EXCHANGE") == "stage"
-                              else "per outer iteration (K + 1 planes, widened windows)",
-            "launched_by": "bench.py itself (one child process per rank)" if os.environ.get("F3D_BENCH_LAUNCHED") == "1"
-                           else "an external launcher (RANK / WORLD_SIZE were set)",
-            # the communicator as the transport reports it: `rccl_ranks` is ncclCommCount's answer on rank 0, not WORLD_SIZE
-            "rccl_ranks": comm["ranks"], "comm_backend": comm["backend"],
-            "comm": {"per_rank": comms,
-                     "halo_GB_sent_per_step": round(sum(c["sent_bytes"] for c in comms) / 1e9 / (args.steps + args.warmup), 4),
-                     "exchanges_per_step_rank0": comm["exchanges"] // max(1, args.steps + args.warmup)},
-            "whole_run_roofline_frac": round(whole / (wall / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4) if whole else None,
-            "roofline": roof,
-        }
         if not args.no_extra:
             # the legs of the one-GPU line that do not depend on N, so that every line of a scaling run is self-contained: the
             # like-for-like sample on rank 0's device and the host-CPU baseline (the other ranks wait at the barrier below)
@@ -649,11 +729,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=0, help="volume edge; default 512 on one GPU (BASELINE config 4), "
-                                                      "1024 on several (BASELINE config 5)")
+    ap.add_argument("--size", type=int, default=0, help="volume edge; default 512 for every N (BASELINE config 4: the size the metric "
+                                                      "is quoted on); with several GPUs the 1024^3 leg (config 5) is appended")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU legs (cpu_baseline, fixed_sample.cpu)")
     ap.add_argument("--no-extra", action="store_true", help="only the timed steps: no host-inclusive step, fixed sample, "
                                                            "configs 2/3 or CPU legs (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="--gpus N > 1: do not append the 1024^3 leg (BASELINE config 5) to the 512^3 line")
+    ap.add_argument("--no-single", action="store_true", help="--gpus N > 1: skip the single-GPU solve of the same volume on rank 0 "
+                                                             "(no speedup in the line)")
+    ap.add_argument("--one-order", action="store_true", help="--gpus N > 1: time only the default exchange order")
     ap.add_argument("--launch-timeout", type=int, default=3300, help="--gpus N started bare: seconds the launcher waits for the "
                                                                      "ranks before it ends them")
     args = ap.parse_args()
@@ -666,7 +750,7 @@ def main():
     sys.stdout = os.fdopen(real_stdout, "w")
     multi = args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
     if args.size <= 0:
-        args.size = 1024 if multi else 512
+        args.size = 512   # one size per sweep: the N = 1, 2, 4, 8 lines of a scaling run are lines of the same volume
     force_multi = os.environ.get("F3D_BENCH_FORCE_SLAB") == "1"  # rehearse the multi-GPU code path with one rank
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not force_multi:
         run_single(args)

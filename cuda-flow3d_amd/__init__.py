@@ -147,6 +147,10 @@ def hip():
         "f3d_comm_sendrecv_begin": [_dp, C.POINTER(_sz), C.POINTER(_sz), _dp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(C.c_int), C.c_int],
         "f3d_comm_sendrecv_end": [],
         "f3d_comm_allreduce_max_f32": [_fp],
+        "f3d_comm_timing": [C.c_int],
+        "f3d_comm_mark": [C.c_int, C.c_int],
+        "f3d_comm_timing_read": [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_ulonglong)],
     }
     for name, args in sig.items():
         try:
@@ -218,6 +222,7 @@ def host():
         "f3d_slabflow_batched_exchanges": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_gathered_warps": [C.c_void_p, C.POINTER(_sz)],
         "f3d_slabflow_stage_exchanges": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_slabflow_set_exchange_per_stage": [C.c_void_p, C.c_int],
         "f3d_slabflow_destroy": [C.c_void_p],
         "f3d_plan_owned": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "f3d_plan_exchange": [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5 + [C.c_int],
@@ -856,6 +861,23 @@ def comm_info():
             "device": dev.value, "sent_bytes": sent.value, "exchanges": ex.value}
 
 
+def comm_timing(enable):
+    """HIP-event timing of the halo exchanges (f3d_comm_timing): on also clears the sums"""
+    check(hip().f3d_comm_timing(1 if enable else 0), "f3d_comm_timing")
+
+
+def comm_timing_read():
+    """{class: {count, mean_us, min_us, max_us, mean_bytes_sent}} for the three classes of interval of include/f3d.h"""
+    out = {}
+    for cls, name in ((0, "blocking_exchange"), (1, "overlapped_exchange_incl_interior"), (2, "grouped_send_recv_alone")):
+        us, n, mn, mx, by = C.c_double(), C.c_ulonglong(), C.c_double(), C.c_double(), C.c_ulonglong()
+        check(hip().f3d_comm_timing_read(cls, C.byref(us), C.byref(n), C.byref(mn), C.byref(mx), C.byref(by)), "f3d_comm_timing_read")
+        out[name] = {"count": n.value, "mean_us": round(us.value / n.value, 2) if n.value else None,
+                     "min_us": round(mn.value, 2) if n.value else None, "max_us": round(mx.value, 2) if n.value else None,
+                     "mean_bytes_sent": int(by.value / n.value) if n.value else None}
+    return out
+
+
 class SlabOpticalFlow:
     """OpticalFlowSlab: the same solve on n_ranks z-slabs.  local_ranks = [rank] with RCCL (call comm_init first), or
     list(range(n_ranks)) for the one-GPU rehearsal."""
@@ -908,6 +930,10 @@ class SlabOpticalFlow:
         n = _sz()
         check(host().f3d_slabflow_stage_exchanges(self._h, C.byref(n)))
         return n.value
+
+    def set_exchange_per_stage(self, per_stage):
+        """exchange order of the solves that follow: False = once per outer iteration (default), True = after every solver stage"""
+        check(host().f3d_slabflow_set_exchange_per_stage(self._h, 1 if per_stage else 0), "f3d_slabflow_set_exchange_per_stage")
 
     def gathered_warps(self):
         """pyramid levels of the last compute whose warp needed frame 1 gathered beyond the halo room"""

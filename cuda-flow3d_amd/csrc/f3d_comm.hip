@@ -51,6 +51,33 @@ struct Rccl {
   bool open = false;
 } R;
 
+// Exchange timing (f3d_comm_timing*): HIP events on the stream the work runs on.  Three classes of interval:
+//   0  a whole blocking exchange on the library stream -- f3d_comm_mark(0) before the pack launch ... f3d_comm_mark(1) after the unpack
+//   1  a whole exchange whose transfer runs beside kernels (the overlapped order): the interval includes the interior it hides behind
+//   2  the grouped send / recv alone, on whichever stream it was posted to (recorded by grouped_sendrecv itself)
+// Off by default and outside every timed region: bench.py switches it on for one extra, untimed solve.
+struct ExchangeTimer {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  struct Span { hipEvent_t a, b; int cls; unsigned long long bytes; };
+  std::vector<Span> spans;
+  hipEvent_t open_a = nullptr;
+  int open_cls = 0;
+  unsigned long long open_bytes0 = 0;
+  struct Sum { double us = 0, min_us = 0, max_us = 0; unsigned long long n = 0, bytes = 0; } sum[3];
+  hipEvent_t get()
+  {
+    hipEvent_t e = nullptr;
+    if (!pool.empty()) {
+      e = pool.back();
+      pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+    }
+    return e;
+  }
+} T;
+
 // the shared-memory backend has no second engine: _begin records the request, _end performs it
 struct Pending {
   std::vector<size_t> send_offset, send_count, recv_offset, recv_count;
@@ -352,6 +379,8 @@ int grouped_sendrecv(const float* send_buf, const size_t* send_offset, const siz
   for (int i = 0; i < n_peers; ++i)
     if (peers[i] < 0 || peers[i] >= R.n_ranks)  // the own rank is a legal peer: RCCL pairs the send with the recv locally
       return f3d::fail("%s: bad peer %d", who, peers[i]);
+  hipEvent_t ta = nullptr, tb = nullptr;
+  if (T.on && (ta = T.get()) != nullptr) (void)hipEventRecord(ta, on);
   F3D_NCCL(R.GroupStart());
   ncclResult_t first = ncclSuccess;
   for (int i = 0; i < n_peers && first == ncclSuccess; ++i) {
@@ -367,8 +396,14 @@ int grouped_sendrecv(const float* send_buf, const size_t* send_offset, const siz
     }
     return f3d::fail("%s: RCCL error %d (%s); the communicator was aborted", who, static_cast<int>(e), R.GetErrorString ? R.GetErrorString(e) : "?");
   }
-  for (int i = 0; i < n_peers; ++i) R.sent_bytes += send_count[i] * sizeof(float);
+  unsigned long long bytes = 0;
+  for (int i = 0; i < n_peers; ++i) bytes += send_count[i] * sizeof(float);
+  R.sent_bytes += bytes;
   ++R.exchanges;
+  if (ta && (tb = T.get()) != nullptr) {
+    (void)hipEventRecord(tb, on);
+    T.spans.push_back({ta, tb, 2, bytes});
+  }
   return 0;
 }
 
@@ -644,6 +679,73 @@ int f3d_comm_sendrecv_end(void)
     return shm_sendrecv(Q.send_buf, Q.send_offset.data(), Q.send_count.data(), Q.recv_buf, Q.recv_offset.data(), Q.recv_count.data(),
                         Q.peers.data(), static_cast<int>(Q.peers.size()));
   F3D_HIP(hipStreamWaitEvent(f3d::stream(), R.arrived, 0));
+  return 0;
+}
+
+int f3d_comm_timing(int enable)
+{
+  F3D_REQUIRE_READY("f3d_comm_timing");
+  if (enable) {
+    for (auto& c : T.sum) c = ExchangeTimer::Sum();
+    for (auto& sp : T.spans) {
+      T.pool.push_back(sp.a);
+      T.pool.push_back(sp.b);
+    }
+    T.spans.clear();
+  }
+  T.on = enable != 0;
+  return 0;
+}
+
+int f3d_comm_mark(int what, int cls)
+{
+  if (!T.on) return 0;
+  F3D_REQUIRE_READY("f3d_comm_mark");
+  if (what == 0) {
+    if (!T.open_a) T.open_a = T.get();
+    if (T.open_a) (void)hipEventRecord(T.open_a, f3d::stream());
+    T.open_cls = cls == 1 ? 1 : 0;
+    T.open_bytes0 = R.sent_bytes;
+  } else if (T.open_a) {
+    hipEvent_t b = T.get();
+    if (b) {
+      (void)hipEventRecord(b, f3d::stream());
+      T.spans.push_back({T.open_a, b, T.open_cls, R.sent_bytes - T.open_bytes0});
+      T.open_a = nullptr;
+    }
+  }
+  return 0;
+}
+
+int f3d_comm_timing_read(int cls, double* total_us, unsigned long long* count, double* min_us, double* max_us, unsigned long long* bytes)
+{
+  F3D_REQUIRE_READY("f3d_comm_timing_read");
+  if (cls < 0 || cls > 2) return f3d::fail("f3d_comm_timing_read: class %d (0 blocking exchange, 1 overlapped exchange, 2 transfer alone)", cls);
+  if (!T.spans.empty()) {
+    F3D_HIP(hipStreamSynchronize(f3d::stream()));
+    if (R.side) F3D_HIP(hipStreamSynchronize(R.side));
+    for (auto& sp : T.spans) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+        auto& c = T.sum[sp.cls];
+        const double us = static_cast<double>(ms) * 1e3;
+        c.min_us = c.n == 0 ? us : std::min(c.min_us, us);
+        c.max_us = c.n == 0 ? us : std::max(c.max_us, us);
+        c.us += us;
+        c.bytes += sp.bytes;
+        ++c.n;
+      }
+      T.pool.push_back(sp.a);
+      T.pool.push_back(sp.b);
+    }
+    T.spans.clear();
+  }
+  const auto& c = T.sum[cls];
+  if (total_us) *total_us = c.us;
+  if (count) *count = c.n;
+  if (min_us) *min_us = c.min_us;
+  if (max_us) *max_us = c.max_us;
+  if (bytes) *bytes = c.bytes;
   return 0;
 }
 

@@ -1294,11 +1294,13 @@ void launch_solver(const SolveArgs& args, const F3dGeo& g)
   const dim3 grid(blocks, 1, 1), block(kLanes, kTY3, 1);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, t.xcd_remap); };
   if constexpr (SWEEP) {
+#ifdef F3D_LAB  // timing builds that skip parts of the work (WRONG results): only in lib/lab/libf3d_hip.so (make lab), never in the product
     static const int ablate = std::getenv("F3D_ABLATE") ? std::atoi(std::getenv("F3D_ABLATE")) : 0;
-    if (ablate == 1) go(k_sweep6<1, kTY3>);
-    else if (ablate == 2) go(k_sweep6<2, kTY3>);
-    else if (ablate == 3) go(k_sweep6<3, kTY3>);
-    else go(k_sweep6<0, kTY3>);
+    if (ablate == 1) return go(k_sweep6<1, kTY3>);
+    if (ablate == 2) return go(k_sweep6<2, kTY3>);
+    if (ablate == 3) return go(k_sweep6<3, kTY3>);
+#endif
+    go(k_sweep6<0, kTY3>);
   } else {
     go(k_phiksi6);
   }
@@ -1342,9 +1344,10 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
-  static const int abl = std::getenv("F3D_ABLATE7") ? std::atoi(std::getenv("F3D_ABLATE7")) : 0;
   const dim3 grid(blocks, 1, 1), block(kLanes, TY + 3, 1);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
+#ifdef F3D_LAB  // timing builds (WRONG results): lab library only
+  static const int abl = std::getenv("F3D_ABLATE7") ? std::atoi(std::getenv("F3D_ABLATE7")) : 0;
   if constexpr (TY == 9) {
     if (abl == 1) return go(k_sweep7<TY, 1>);
     if (abl == 2) return go(k_sweep7<TY, 2>);
@@ -1373,6 +1376,7 @@ void launch_sweep2_ty(const SolveArgs& a, const F3dGeo& g, long want_wg, int for
       return;
     }
   }
+#endif
   go(k_sweep7<TY, 0>);
 }
 

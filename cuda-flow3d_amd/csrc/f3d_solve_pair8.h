@@ -914,11 +914,13 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
   const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
-  static const int abl = std::getenv("F3D_ABLATE8") ? std::atoi(std::getenv("F3D_ABLATE8")) : 0;
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
   if constexpr (YM) return go(k_pair8<MODE, TY, 0, false, true>);
   else if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
   else {
+#ifdef F3D_LAB  // timing builds that skip parts of the work (WRONG results): only in lib/lab/libf3d_hip.so (make lab, tools/kbench.py
+                // --ablate); the shipped library has no switch that changes a result and no ABL != 0 instantiation
+    static const int abl = std::getenv("F3D_ABLATE8") ? std::atoi(std::getenv("F3D_ABLATE8")) : 0;
     if constexpr (TY == 12) {
       if (abl == 16) return go(k_pair8<MODE, TY, 16>);
     }
@@ -930,6 +932,7 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
       if (abl == 8) return go(k_pair8<MODE, TY, 8>);
       if (abl == 40) return go(k_pair8<MODE, TY, 40>);
     }
+#endif
     go(k_pair8<MODE, TY, 0>);
   }
 }

@@ -564,6 +564,13 @@ int f3d_slabflow_stage_exchanges(f3d_slabflow flow, size_t* count)
   return 0;
 }
 
+int f3d_slabflow_set_exchange_per_stage(f3d_slabflow flow, int per_stage)
+{
+  if (!flow || !flow->driver) return 1;
+  flow->driver->SetExchangePerStage(per_stage != 0);
+  return 0;
+}
+
 int f3d_slabflow_gathered_warps(f3d_slabflow flow, size_t* count)
 {
   if (!flow || !flow->driver || !count) return 1;

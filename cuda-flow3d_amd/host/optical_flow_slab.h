@@ -96,6 +96,11 @@ class OpticalFlowSlab : public OpticalFlowBase {
   size_t GatheredWarps() const { return wide_warps_; }
   // exchanges of the last solve made after a solver STAGE (a fused pair or a single sweep) rather than once per outer iteration
   size_t StageExchanges() const { return stage_exchanges_; }
+  // which of the two bit-identical exchange orders the next solve takes: false = K + 1 planes once per outer iteration with the
+  // sweeps on widened windows (default), true = one message per solver stage (what F3D_SLAB_EXCHANGE=stage selects at construction);
+  // bench.py times both in one invocation
+  void SetExchangePerStage(bool per_stage) { exchange_per_stage_ = per_stage; }
+  bool ExchangePerStage() const { return exchange_per_stage_; }
  private:
   // F3D_SLAB_EXCHANGE=stage: exchange the increments after every solver stage, as deep as the next stage reads (2 planes before a
   // fused pair, 1 before a single sweep, 3 before the next weights), instead of K + 1 = 6 planes once per outer iteration with the

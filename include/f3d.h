@@ -358,6 +358,19 @@ int f3d_comm_sendrecv(f3d_devptr send_buf, const size_t* send_offset, const size
 int f3d_comm_sendrecv_begin(f3d_devptr send_buf, const size_t* send_offset, const size_t* send_count, f3d_devptr recv_buf,
                             const size_t* recv_offset, const size_t* recv_count, const int* peers, int n_peers);
 int f3d_comm_sendrecv_end(void);
+/* Measured cost of an exchange (nothing in the reference to match: src/utils/cuda_utils.cpp:38,52 use one device).  While
+ * f3d_comm_timing(1) is in force HIP events bracket three kinds of interval on the stream the work runs on:
+ *   class 0  a whole blocking exchange -- the caller marks it: f3d_comm_mark(0, 0) before the pack launch, f3d_comm_mark(1, 0) after
+ *            the unpack launch (host/optical_flow_slab.cpp: Exchange)
+ *   class 1  the same marks around an exchange whose transfer runs beside kernels (f3d_comm_sendrecv_begin / _end with the
+ *            interior in between): the interval includes the kernels it hides behind
+ *   class 2  the grouped ncclSend / ncclRecv alone (recorded by the library on the stream it was posted to)
+ * f3d_comm_timing(1) also clears the sums; f3d_comm_timing_read drains the streams and returns total / count / min / max in
+ * microseconds and the bytes this rank sent inside the intervals.  Off by default; with it off f3d_comm_mark does nothing. */
+int f3d_comm_timing(int enable);
+int f3d_comm_mark(int what, int cls);
+int f3d_comm_timing_read(int cls, double* total_us, unsigned long long* count, double* min_us, double* max_us,
+                         unsigned long long* bytes);
 /* max over all ranks of *value (host in/out) */
 int f3d_comm_allreduce_max_f32(float* value);
 /* max |field| over the slab's planes, on the device (feeds the warp halo depth) */

@@ -178,6 +178,9 @@ int f3d_slabflow_gathered_warps(f3d_slabflow flow, size_t* count);
 /* exchanges of the last compute made after a solver stage (F3D_SLAB_EXCHANGE=stage: 2 / 1 / 3 planes after the fused pairs and the
  * last sweep instead of 6 planes once per outer iteration; same bits, fewer redundant planes, three times the messages) */
 int f3d_slabflow_stage_exchanges(f3d_slabflow flow, size_t* count);
+/* the exchange order of the solves that follow: 0 = once per outer iteration (default), 1 = after every solver stage.  Both give the
+ * single-GPU bits; which is faster depends on the machine's exchange latency, so bench.py --gpus N times both in one run. */
+int f3d_slabflow_set_exchange_per_stage(f3d_slabflow flow, int per_stage);
 int f3d_slabflow_destroy(f3d_slabflow flow);
 
 /* the decomposition plan (pure host arithmetic, usable without a device) */

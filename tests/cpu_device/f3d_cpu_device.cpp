@@ -597,6 +597,13 @@ int f3d_comm_sendrecv_begin(f3d_devptr a, const size_t* b, const size_t* c, f3d_
 }
 int f3d_comm_sendrecv_end(void) { return 0; }
 int f3d_comm_allreduce_max_f32(float*) { return 0; }
+int f3d_comm_timing(int) { return 0; }
+int f3d_comm_mark(int, int) { return 0; }
+int f3d_comm_timing_read(int, double* us, unsigned long long* n, double* mn, double* mx, unsigned long long* bytes)
+{
+  if (us) *us = 0; if (n) *n = 0; if (mn) *mn = 0; if (mx) *mx = 0; if (bytes) *bytes = 0;
+  return 0;
+}
 int f3d_abs_max(f3d_devptr field, size_t width, size_t height, size_t depth, const f3d_slab* slab, float* result)
 {
   Geo o;

@@ -87,3 +87,41 @@ def test_a_fatal_signal_leaves_the_load_map_and_still_reaches_the_previous_handl
     text = maps.read_text()
     assert text.startswith("signal 0x000000000000000b\nfault address 0x0000000000000010\n")
     assert "libf3d_hip.so" in text and "[stack]" in text
+
+
+def test_the_shipped_library_has_no_switch_that_changes_a_result():
+    """The timing builds of the solver kernels that skip parts of the work (F3D_ABLATE*: wrong results) are compiled only under
+    -DF3D_LAB into lib/lab/ (make lab, tools/kbench.py --ablate); the product library neither reads those variables nor contains
+    an ablated instantiation (k_pair8<MODE, TY, ABL != 0, ...>, k_sweep7<TY, ABL != 0>, k_sweep6<ABLATE != 0, ...>)."""
+    import subprocess
+    so = os.path.join(ROOT, "cuda-flow3d_amd", "lib", "libf3d_hip.so")
+    blob = open(so, "rb").read()
+    assert b"F3D_ABLATE" not in blob
+    names = subprocess.run(["nm", "-C", so], capture_output=True, text=True).stdout
+    stubs = set(re.findall(r"__device_stub__(k_(?:pair8|sweep7|sweep6)<[^>]*>)", names))
+    assert len(stubs) >= 20, stubs
+    for k in stubs:
+        args = [a.strip() for a in k[k.index("<") + 1:-1].split(",")]
+        abl = {"k_pair8": args[2] if len(args) > 2 else "0", "k_sweep7": args[1] if len(args) > 1 else "0", "k_sweep6": args[0]}[k[:k.index("<")]]
+        assert abl == "0", f"{k} is a timing build and must not ship"
+    # the sources keep every such switch behind the macro
+    for name in ("f3d_solve.hip", "f3d_solve_pair8.h"):
+        text = open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", name)).read()
+        outside = re.sub(r"#ifdef F3D_LAB\b.*?#endif", "", text, flags=re.S)
+        assert 'getenv("F3D_ABLATE' not in outside, name
+
+
+def test_the_newest_counter_record_is_of_the_shipped_kernels():
+    """bench.py's roofline.traffic comes from the newest profiles/*_pmc_traffic.json and is dropped when that record was collected on
+    other kernel sources (round 3's driver line lost it that way): the newest record must carry the stamp of the solver sources in
+    the tree.  After any change to csrc/f3d_solve.hip / f3d_solve_pair8.h: tools/pmc_traffic.sh on the GPU, copy the record."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    assert files
+    doc = json.load(open(files[-1]))
+    assert doc.get("_solver_source_sha16") == bench.solver_source_stamp(), (
+        f"{os.path.basename(files[-1])} was collected on other solver sources: run tools/pmc_traffic.sh and commit the new record")
+    assert bench.measured_traffic("k_pair8")["traffic"]

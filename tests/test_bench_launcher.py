@@ -134,3 +134,22 @@ def test_bench_gpus_2_started_bare_equals_one_gpu(f3d):
     assert all(c["sent_bytes"] > 0 and c["exchanges"] > 0 for c in line["comm"]["per_rank"])
     assert line["parity"]["digest"] == want, "two rank processes did not reproduce the single-GPU bits"
     assert line["value"] == pytest.approx(S ** 3 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    # one size per sweep, and everything a scaling run needs in the one line (round-3 verdict, item 1):
+    assert f"{S}^3" in line["config"]["workload"] and line["scaling"] == "strong"
+    # ... both exchange orders timed in this invocation, each with the single-GPU bits, `value` the faster of the two
+    orders = line["exchange_orders"]
+    assert set(orders) == {"per_outer_iteration", "per_stage"}
+    for name, rec in orders.items():
+        assert rec["parity"]["digest"] == want, name
+        assert all(c["sent_bytes"] > 0 and c["exchanges"] > 0 for c in rec["comm"]["per_rank"]), name
+        # ... microseconds per exchange, measured with events around pack -> transfer -> unpack on every rank
+        blocking = rec["exchange_us"]["rank0"]["blocking_exchange"]
+        assert blocking["count"] > 0 and blocking["mean_us"] > 0 and blocking["mean_bytes_sent"] > 0, (name, blocking)
+        assert rec["exchange_us"]["worst_rank_mean_us_blocking"] >= blocking["mean_us"] * 0.999
+    assert orders["per_stage"]["comm"]["exchanges_per_step_rank0"] > orders["per_outer_iteration"]["comm"]["exchanges_per_step_rank0"]
+    assert line["exchange_order"] in orders and line["ms_per_step"] == min(r["ms_per_step"] for r in orders.values())
+    # ... the unsplit solve of the same volume on rank 0's device, its bits, and the speedup computed from it
+    single = line["single_gpu_same_size"]
+    assert single["digest_equals_the_slab_runs"] is True and single["value"] > 0
+    assert line["speedup"] == pytest.approx(line["value"] / single["value"], rel=1e-3)
+    assert "config5" not in line          # only the 512^3 sweep takes the 1024^3 leg along

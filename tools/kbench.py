@@ -2,6 +2,10 @@
 """Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
 (f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
    python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|phi|both|bothfd|all]
+                          [--ablate N]
+--ablate N: timing-only builds of the solver kernels that skip parts of the work (WRONG results; N as described at k_pair8 / k_sweep7 /
+k_sweep6).  They exist only in the LAB library (make -C cuda-flow3d_amd lab -> lib/lab/), which this option loads instead of the
+product; the shipped library has no such switch.
 """
 import argparse
 import ctypes as C
@@ -20,7 +24,15 @@ def main():
     ap.add_argument("--dims", type=int, nargs=3)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--kernel", default="both")
+    ap.add_argument("--ablate", type=int, default=0)
     a = ap.parse_args()
+    if a.ablate:
+        lab = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-flow3d_amd", "lib", "lab")
+        if not os.path.exists(os.path.join(lab, "libf3d_hip.so")):
+            sys.exit("kbench --ablate: build the lab library first (make -C cuda-flow3d_amd lab)")
+        os.environ["F3D_LIBDIR"] = lab                     # read by the binding when it is imported, below
+        for name in ("F3D_ABLATE", "F3D_ABLATE7", "F3D_ABLATE8"):
+            os.environ.setdefault(name, str(a.ablate))
     W, H, D = a.dims if a.dims else (a.size,) * 3
     pkg = importlib.import_module("cuda-flow3d_amd")
     hip = pkg.hip()
