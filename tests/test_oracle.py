@@ -226,3 +226,30 @@ def test_the_reference_kernels_are_built_from_the_reference_tree():
     # nothing of the reference's text is kept in the repository: the recipe names the sources by path
     recipe = open(os.path.join(root, "oracle", "Makefile")).read()
     assert "$(REF)/src/kernels/%.cu" in recipe and "-D__DEVICE_LAUNCH_PARAMETERS_H__" in recipe
+
+
+def test_the_reference_code_objects_are_what_the_committed_recipe_gives(tmp_path):
+    """tests/golden/ref_hsaco_manifest.json pins the MACHINE CODE of the reference kernels the GPU tests load: the sha256 of the
+    .text section of the gfx950 code object (the bundle around it embeds build paths; tests/hsaco_text.py).  Where the reference
+    tree exists the six files are rebuilt from it into a scratch directory with the committed recipe (oracle/Makefile, HERE
+    redirected) and must give the manifest's hashes -- so must the prebuilt files that travel to the GPU box."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import hsaco_text
+    import ref_kernels
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = {k: v for k, v in hsaco_text.manifest().items() if not k.startswith("_")}
+    assert sorted(want) == sorted(m + ".hsaco" for m in ref_kernels.MODULES)
+    if os.path.isdir("/root/reference/src/kernels") and os.path.exists("/opt/rocm/bin/hipcc"):
+        scratch = str(tmp_path) + "/"
+        targets = [scratch + "_ref/" + name for name in want]
+        subprocess.run(["make", "-f", os.path.join(root, "oracle", "Makefile"), "HERE=" + scratch] + targets, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for name, digest in want.items():
+            assert hsaco_text.text_sha256(scratch + "_ref/" + name) == digest, f"{name}: the recipe no longer gives the pinned code"
+    elif not ref_kernels.available():
+        pytest.skip("no /root/reference here and no prebuilt oracle/_ref")
+    if ref_kernels.available():
+        for name, digest in want.items():
+            assert hsaco_text.text_sha256(os.path.join(ref_kernels.REF_DIR, name)) == digest, f"oracle/_ref/{name} is not the pinned build"
