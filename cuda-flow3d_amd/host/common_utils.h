@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdio>
+#include <initializer_list>
 
 namespace Utils {
 void GetExecutablePath(char* path, size_t size);  // directory of /proc/self/exe (common_utils.cpp:30-47)
@@ -36,5 +37,20 @@ void PrintProgressBar(float complete);            // "\r[====    ]", 40 cells (c
     F3D_PARAM_LOOKUP_(P, N, return)                \
     (PTR) = static_cast<T*>(v_ptr);                \
   } while (0)
+
+// An operator's interface is its key strings.  The drivers describe every call as a LIST of {key, pointer to a
+// variable of theirs}; FillBag empties the bag and pushes the list in order ("first push wins", operation_parameters.cpp:23-30).
+// The bag owns nothing: the variables must outlive the Execute() call.
+struct BagEntry {
+  const char* key;
+  void* value;
+};
+template <typename Bag>
+inline Bag& FillBag(Bag& bag, std::initializer_list<BagEntry> entries)
+{
+  bag.Clear();
+  for (const BagEntry& e : entries) bag.PushValuePtr(e.key, e.value);
+  return bag;
+}
 
 #endif

@@ -9,6 +9,7 @@
 #include <cstdio>
 
 #include "common_utils.h"
+#include "operator_calls.h"
 #include "hip_utils.h"
 
 // ---- base --------------------------------------------------------------------------------------------------
@@ -342,11 +343,7 @@ bool OpticalFlowE::ResultStatistics(Stat3& stat)
   if (!cuop_stat_.Initialize(&init)) return false;
   DataSize4 data_size = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
   OperationParameters bag;
-  bag.PushValuePtr("dev_flow_u", &result_flow_[0]);
-  bag.PushValuePtr("dev_flow_v", &result_flow_[1]);
-  bag.PushValuePtr("dev_flow_w", &result_flow_[2]);
-  bag.PushValuePtr("data_size", &data_size);
-  bag.PushValuePtr("stat", &stat);
+  calls::Statistics(bag, {&result_flow_[0], &result_flow_[1], &result_flow_[2]}, &data_size, &stat);
   cuop_stat_.silent = true;
   cuop_stat_.Execute(bag);
   return true;
@@ -371,16 +368,8 @@ bool OpticalFlowE::FinalResidual(Residual& registered, Residual& unregistered)
   DevicePtr dev_temp = Borrow();
   float h = 1.f;
   OperationParameters op;
-  op.PushValuePtr("dev_frame_0", &resident_frame_[0]);
-  op.PushValuePtr("dev_frame_1", &resident_frame_[1]);
-  op.PushValuePtr("dev_flow_u", &result_flow_[0]);
-  op.PushValuePtr("dev_flow_v", &result_flow_[1]);
-  op.PushValuePtr("dev_flow_w", &result_flow_[2]);
-  op.PushValuePtr("dev_output", &dev_temp);
-  op.PushValuePtr("data_size", &size);
-  op.PushValuePtr("hx", &h);
-  op.PushValuePtr("hy", &h);
-  op.PushValuePtr("hz", &h);
+  calls::Registration(op, &resident_frame_[0], &resident_frame_[1], {&result_flow_[0], &result_flow_[1], &result_flow_[2]}, &dev_temp, &size,
+                      {&h, &h, &h});
   cuop_register_.Execute(op);
   const bool ok = ResidualOf(resident_frame_[0], dev_temp, size, registered) &&
                   ResidualOf(resident_frame_[0], resident_frame_[1], size, unregistered);
@@ -388,6 +377,12 @@ bool OpticalFlowE::FinalResidual(Residual& registered, Residual& unregistered)
   return ok;
 }
 
+// The coarse-to-fine solve on two frames that are already on the device (optical_flow_e.cpp:208-533 is the sequence of operator
+// calls this reproduces: pre-blur; per level frames from the originals, flow from the level before, registration, solve, update,
+// median).  Containers are named by what they hold:
+//   blurred[2]   the two full-size frames the pyramid reads (pre-blurred copies, or the raw frames when sigma <= 0)
+//   level[2]     the two frames at the current level; level[1] is replaced by its registered version
+//   flow[3]      u, v, w so far        step[3]   the level's increments du, dv, dw (and, between levels, ping-pong room)
 bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, DevicePtr raw_1, bool raw_is_pooled)
 {
   size_t warp_levels_count, outer_iterations_count, inner_iterations_count, median_radius;
@@ -401,207 +396,130 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
   GET_PARAM_OR_RETURN_VALUE(params, float, equation_data, "equation_data", false);
   GET_PARAM_OR_RETURN_VALUE(params, size_t, median_radius, "median_radius", false);
   GET_PARAM_OR_RETURN_VALUE(params, float, gaussian_sigma, "gaussian_sigma", false);
+  calls::SolverSettings settings = {&outer_iterations_count, &inner_iterations_count, &equation_alpha, &equation_smoothness, &equation_data};
 
   if (!silent) std::printf("\nStarting optical flow computation...\n");
 
-  DataSize4 original = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
-  const size_t max_warp_level = GetMaxWarpLevel(original.width, original.height, original.depth, warp_scale_factor);
-  int level = static_cast<int>(std::min(warp_levels_count, max_warp_level)) - 1;
+  DataSize4 whole = {dev_container_size_.width, dev_container_size_.height, dev_container_size_.depth, 0};
+  const size_t deepest = GetMaxWarpLevel(whole.width, whole.height, whole.depth, warp_scale_factor);
+  const int first_level = static_cast<int>(std::min(warp_levels_count, deepest)) - 1;
+  const size_t container_rows = dev_container_size_.height * dev_container_size_.depth;
+  const size_t container_row_bytes = dev_container_size_.width * sizeof(float);
+  auto zero_container = [&](DevicePtr p) { CheckDeviceError(f3d_memset2d(p, dev_container_size_.pitch, 0, container_row_bytes, container_rows)); };
+  OperationParameters bag;
 
-  OperationParameters op;
-
-  // ---- pre-blur (optical_flow_e.cpp:213-242): full-size frames -> dev_frame_0/1 ------------------------------
-  DevicePtr dev_frame_0, dev_frame_1;
+  // ---- the frames the pyramid reads ------------------------------------------------------------------------------------------
+  DevicePtr raw[2] = {raw_0, raw_1};
+  DevicePtr blurred[2];
   if (gaussian_sigma > 0.0) {
-    dev_frame_0 = Borrow();
-    dev_frame_1 = Borrow();
-    DevicePtr dev_temp = Borrow();
-    DevicePtr* src[2] = {&raw_0, &raw_1};
-    DevicePtr* dst[2] = {&dev_frame_0, &dev_frame_1};
-    for (int i = 0; i < 2; ++i) {
-      op.Clear();
-      op.PushValuePtr("dev_input", src[i]);
-      op.PushValuePtr("dev_output", dst[i]);
-      op.PushValuePtr("dev_temp", &dev_temp);
-      op.PushValuePtr("data_size", &original);
-      op.PushValuePtr("gaussian_sigma", &gaussian_sigma);
-      cuop_convolution_.Execute(op);
+    DevicePtr scratch = Borrow();
+    for (int f = 0; f < 2; ++f) {
+      blurred[f] = Borrow();
+      cuop_convolution_.Execute(calls::Convolution(bag, &raw[f], &blurred[f], &scratch, &whole, &gaussian_sigma));
     }
-    GiveBack(dev_temp);
-    if (raw_is_pooled) {
-      GiveBack(raw_0);
-      GiveBack(raw_1);
-    }
+    GiveBack(scratch);
+    if (raw_is_pooled)
+      for (DevicePtr p : raw) GiveBack(p);
   } else if (raw_is_pooled) {
-    dev_frame_0 = raw_0;
-    dev_frame_1 = raw_1;
+    blurred[0] = raw[0];   // nothing to blur: the uploaded containers themselves
+    blurred[1] = raw[1];
   } else {
-    dev_frame_0 = Borrow();
-    dev_frame_1 = Borrow();
-    const size_t bytes = dev_container_size_.pitch * dev_container_size_.height * dev_container_size_.depth;
-    CheckDeviceError(f3d_copy_d2d(dev_frame_0, raw_0, bytes));
-    CheckDeviceError(f3d_copy_d2d(dev_frame_1, raw_1, bytes));
+    // resident frames must survive the solve (level 0 takes the containers of `blurred` over): work on copies
+    for (int f = 0; f < 2; ++f) {
+      blurred[f] = Borrow();
+      CheckDeviceError(f3d_copy_d2d(blurred[f], raw[f], dev_container_size_.pitch * container_rows));
+    }
   }
 
-  DevicePtr dev_frame_0_res = Borrow(), dev_frame_1_res_br = Borrow();
-  DevicePtr dev_flow_u = Borrow(), dev_flow_v = Borrow(), dev_flow_w = Borrow();
-  DevicePtr dev_flow_du = Borrow(), dev_flow_dv = Borrow(), dev_flow_dw = Borrow();
+  DevicePtr level_frame[2] = {Borrow(), Borrow()};
+  DevicePtr flow[3] = {Borrow(), Borrow(), Borrow()};
+  DevicePtr step[3] = {Borrow(), Borrow(), Borrow()};
+  const calls::Flow flow_roles = {&flow[0], &flow[1], &flow[2]}, step_roles = {&step[0], &step[1], &step[2]};
 
   level_stats_.clear();
-  DataSize4 prev_data_size = {0, 0, 0, 0};
-  if (level < 0) {  // no level requested: the flow is identically zero
-    const size_t rows = dev_container_size_.height * dev_container_size_.depth;
-    for (DevicePtr p : {dev_flow_u, dev_flow_v, dev_flow_w})
-      CheckDeviceError(f3d_memset2d(p, dev_container_size_.pitch, 0, dev_container_size_.width * sizeof(float), rows));
-  }
+  if (first_level < 0)  // no level requested: the flow is identically zero
+    for (DevicePtr p : flow) zero_container(p);
 
-  // `count` volumes of one size through the three passes together (three launches instead of 3 x count): a temp each
-  auto resample = [&](DevicePtr* const* in, DevicePtr* const* out, size_t count, DataSize4& from, DataSize4& to) {
+  // `count` (<= 3) volumes of one box through the three resampling passes together: three launches, a scratch container each
+  auto resample_together = [&](DevicePtr* in, DevicePtr* out, size_t count, DataSize4& from, DataSize4& to) {
     OperationParameters bags[3];
-    DevicePtr temps[3] = {0, 0, 0};
+    DevicePtr scratch[3] = {0, 0, 0};
     for (size_t i = 0; i < count; ++i) {
-      temps[i] = Borrow();
-      bags[i].PushValuePtr("dev_input", in[i]);
-      bags[i].PushValuePtr("dev_output", out[i]);
-      bags[i].PushValuePtr("dev_temp", &temps[i]);
-      bags[i].PushValuePtr("data_size", &from);
-      bags[i].PushValuePtr("resample_size", &to);
+      scratch[i] = Borrow();
+      calls::Resample(bags[i], &in[i], &out[i], &scratch[i], &from, &to);
     }
     cuop_resample_.ExecuteBatch(bags, count);
-    for (size_t i = 0; i < count; ++i) GiveBack(temps[i]);
+    for (size_t i = 0; i < count; ++i) GiveBack(scratch[i]);
   };
 
-  while (level >= 0) {
-    PyramidLevel lv = GetLevel(original, warp_scale_factor, level);
-    DataSize4 current = lv.size;
-    float hx = lv.hx, hy = lv.hy, hz = lv.hz;
+  DataSize4 coarser = {0, 0, 0, 0};   // the box of the level before (none yet)
+  for (int level = first_level; level >= 0; --level) {
+    PyramidLevel geometry = GetLevel(whole, warp_scale_factor, level);
+    DataSize4 box = geometry.size;
+    const calls::Spacing spacing = {&geometry.hx, &geometry.hy, &geometry.hz};
     char range_name[64];
-    std::snprintf(range_name, sizeof(range_name), "level %d (%zu x %zu x %zu)", level, current.width, current.height, current.depth);
+    std::snprintf(range_name, sizeof(range_name), "level %d (%zu x %zu x %zu)", level, box.width, box.height, box.depth);
     ProfilerRange level_range(range_name);
-    if (!silent)
-      std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", level, current.width, current.height, current.depth);
+    if (!silent) std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", level, box.width, box.height, box.depth);
 
-    // frames of this level: always resampled from the ORIGINAL-size blurred frames (:274-300)
-    if (level == 0) {
-      std::swap(dev_frame_0, dev_frame_0_res);
-      std::swap(dev_frame_1, dev_frame_1_res_br);
+    // 1. the two frames at this size: always from the ORIGINAL-size frames; at the finest level those are the level's frames
+    if (level == 0)
+      for (int f = 0; f < 2; ++f) std::swap(blurred[f], level_frame[f]);
+    else
+      resample_together(blurred, level_frame, 2, whole, box);
+
+    // 2. the flow so far at this size (zero before the first level): resampled into the increments' containers, roles swapped;
+    //    the values are not rescaled -- the flow is kept in original-voxel units
+    if (coarser.width == 0) {
+      for (DevicePtr p : flow) zero_container(p);
     } else {
-      DevicePtr* const frames[2] = {&dev_frame_0, &dev_frame_1};
-      DevicePtr* const resampled[2] = {&dev_frame_0_res, &dev_frame_1_res_br};
-      resample(frames, resampled, 2, original, current);
+      resample_together(flow, step, 3, coarser, box);
+      for (int c = 0; c < 3; ++c) std::swap(flow[c], step[c]);
     }
 
-    // flow of the previous level brought to this size; values stay in original-voxel units (:303-345)
-    if (prev_data_size.width == 0) {
-      const size_t rows = dev_container_size_.height * dev_container_size_.depth;
-      const size_t row_bytes = dev_container_size_.width * sizeof(float);
-      CheckDeviceError(f3d_memset2d(dev_flow_u, dev_container_size_.pitch, 0, row_bytes, rows));
-      CheckDeviceError(f3d_memset2d(dev_flow_v, dev_container_size_.pitch, 0, row_bytes, rows));
-      CheckDeviceError(f3d_memset2d(dev_flow_w, dev_container_size_.pitch, 0, row_bytes, rows));
-    } else {
-      DevicePtr* const coarse[3] = {&dev_flow_u, &dev_flow_v, &dev_flow_w};
-      DevicePtr* const fine[3] = {&dev_flow_du, &dev_flow_dv, &dev_flow_dw};
-      resample(coarse, fine, 3, prev_data_size, current);
-      std::swap(dev_flow_u, dev_flow_du);
-      std::swap(dev_flow_v, dev_flow_dv);
-      std::swap(dev_flow_w, dev_flow_dw);
-    }
-
-    // backward registration of frame 1 with the current flow (:348-369)
+    // 3. frame 1 registered with that flow
     {
-      DevicePtr dev_temp = Borrow();
-      op.Clear();
-      op.PushValuePtr("dev_frame_0", &dev_frame_0_res);
-      op.PushValuePtr("dev_frame_1", &dev_frame_1_res_br);
-      op.PushValuePtr("dev_flow_u", &dev_flow_u);
-      op.PushValuePtr("dev_flow_v", &dev_flow_v);
-      op.PushValuePtr("dev_flow_w", &dev_flow_w);
-      op.PushValuePtr("dev_output", &dev_temp);
-      op.PushValuePtr("data_size", &current);
-      op.PushValuePtr("hx", &hx);
-      op.PushValuePtr("hy", &hy);
-      op.PushValuePtr("hz", &hz);
-      cuop_register_.Execute(op);
-      std::swap(dev_frame_1_res_br, dev_temp);
-      GiveBack(dev_temp);
+      DevicePtr registered = Borrow();
+      cuop_register_.Execute(calls::Registration(bag, &level_frame[0], &level_frame[1], flow_roles, &registered, &box, spacing));
+      std::swap(level_frame[1], registered);
+      GiveBack(registered);
     }
     if (collect_level_statistics) {
       LevelStatistics st;
       st.level = level;
-      st.size = current;
-      ResidualOf(dev_frame_0_res, dev_frame_1_res_br, current, st.before);
+      st.size = box;
+      ResidualOf(level_frame[0], level_frame[1], box, st.before);
       level_stats_.push_back(st);
     }
 
-    // difference problem: increments du, dv, dw (:372-417)
+    // 4. the increments of this level: weights + sweeps; five containers on loan for the duration
     {
-      DevicePtr dev_phi = Borrow(), dev_ksi = Borrow();
-      DevicePtr dev_temp_du = Borrow(), dev_temp_dv = Borrow(), dev_temp_dw = Borrow();
-      op.Clear();
-      op.PushValuePtr("dev_frame_0", &dev_frame_0_res);
-      op.PushValuePtr("dev_frame_1", &dev_frame_1_res_br);
-      op.PushValuePtr("dev_flow_u", &dev_flow_u);
-      op.PushValuePtr("dev_flow_v", &dev_flow_v);
-      op.PushValuePtr("dev_flow_w", &dev_flow_w);
-      op.PushValuePtr("dev_flow_du", &dev_flow_du);
-      op.PushValuePtr("dev_flow_dv", &dev_flow_dv);
-      op.PushValuePtr("dev_flow_dw", &dev_flow_dw);
-      op.PushValuePtr("dev_phi", &dev_phi);
-      op.PushValuePtr("dev_ksi", &dev_ksi);
-      op.PushValuePtr("dev_temp_du", &dev_temp_du);
-      op.PushValuePtr("dev_temp_dv", &dev_temp_dv);
-      op.PushValuePtr("dev_temp_dw", &dev_temp_dw);
-      op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
-      op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
-      op.PushValuePtr("equation_alpha", &equation_alpha);
-      op.PushValuePtr("equation_smoothness", &equation_smoothness);
-      op.PushValuePtr("equation_data", &equation_data);
-      op.PushValuePtr("data_size", &current);
-      op.PushValuePtr("hx", &hx);
-      op.PushValuePtr("hy", &hy);
-      op.PushValuePtr("hz", &hz);
+      DevicePtr phi = Borrow(), ksi = Borrow();
+      DevicePtr partner[3] = {Borrow(), Borrow(), Borrow()};
+      const calls::Flow partner_roles = {&partner[0], &partner[1], &partner[2]};
       cuop_solve_.silent = silent;
-      cuop_solve_.Execute(op);
-      GiveBack(dev_phi);
-      GiveBack(dev_ksi);
-      GiveBack(dev_temp_du);
-      GiveBack(dev_temp_dv);
-      GiveBack(dev_temp_dw);
+      cuop_solve_.Execute(calls::Solve(bag, &level_frame[0], &level_frame[1], flow_roles, step_roles, partner_roles, &phi, &ksi, settings,
+                                       &box, spacing));
+      for (DevicePtr p : {phi, ksi, partner[0], partner[1], partner[2]}) GiveBack(p);
     }
 
-    // flow += increment (:420-438), then median of each component (:444-473)
-    DevicePtr* flow[3] = {&dev_flow_u, &dev_flow_v, &dev_flow_w};
-    DevicePtr* incr[3] = {&dev_flow_du, &dev_flow_dv, &dev_flow_dw};
-    // the three components are independent through both steps: one launch each for the three of them.  The increments are
-    // consumed by "+=", so their containers take the filtered flow and the roles are swapped (the reference filters through one
-    // temp, a component at a time)
+    // 5. flow += increments, then the median of every component.  The components are independent through both, so the three go out
+    //    in one launch each; the increments are consumed by "+=", so their containers receive the filtered flow and the roles swap
+    //    (the reference filters through one scratch container, a component at a time)
     {
       OperationParameters bags[3];
-      for (int i = 0; i < 3; ++i) {
-        bags[i].PushValuePtr("operand_0", flow[i]);
-        bags[i].PushValuePtr("operand_1", incr[i]);
-        bags[i].PushValuePtr("data_size", &current);
-      }
+      for (int c = 0; c < 3; ++c) calls::Add(bags[c], &flow[c], &step[c], &box);
       cuop_add_.ExecuteBatch(bags, 3);
-    }
-    {
-      OperationParameters bags[3];
-      for (int i = 0; i < 3; ++i) {
-        bags[i].PushValuePtr("dev_input", flow[i]);
-        bags[i].PushValuePtr("dev_output", incr[i]);
-        bags[i].PushValuePtr("data_size", &current);
-        bags[i].PushValuePtr("radius", &median_radius);
-      }
+      for (int c = 0; c < 3; ++c) calls::Median(bags[c], &flow[c], &step[c], &box, &median_radius);
       cuop_median_.ExecuteBatch(bags, 3);
-      for (int i = 0; i < 3; ++i) std::swap(*flow[i], *incr[i]);
+      for (int c = 0; c < 3; ++c) std::swap(flow[c], step[c]);
     }
 
     if (collect_level_statistics) {
       float mn = 0.f, mx = 0.f;
       double sum = 0.0;
-      if (!CheckDeviceError(f3d_flow_stats(dev_flow_u, dev_flow_v, dev_flow_w, current.width, current.height, current.depth, nullptr,
-                                           &mn, &mx, &sum))) {
-        const double n = static_cast<double>(current.width) * static_cast<double>(current.height) * static_cast<double>(current.depth);
+      if (!CheckDeviceError(f3d_flow_stats(flow[0], flow[1], flow[2], box.width, box.height, box.depth, nullptr, &mn, &mx, &sum))) {
+        const double n = static_cast<double>(box.width) * static_cast<double>(box.height) * static_cast<double>(box.depth);
         level_stats_.back().flow = {mn, mx, static_cast<float>(sum / n)};
       }
       if (!silent) {
@@ -610,21 +528,12 @@ bool OpticalFlowE::RunPyramid(OperationParameters& params, DevicePtr raw_0, Devi
                     st.before.rms, st.before.mean_abs, st.before.max_abs, st.flow.min, st.flow.max, st.flow.avg);
       }
     }
-    prev_data_size = current;
-    --level;
+    coarser = box;
   }
 
-  // keep (u, v, w) until they are downloaded; everything else returns to the pool
-  result_flow_[0] = dev_flow_u;
-  result_flow_[1] = dev_flow_v;
-  result_flow_[2] = dev_flow_w;
-  GiveBack(dev_frame_0);
-  GiveBack(dev_frame_1);
-  GiveBack(dev_frame_0_res);
-  GiveBack(dev_frame_1_res_br);
-  GiveBack(dev_flow_du);
-  GiveBack(dev_flow_dv);
-  GiveBack(dev_flow_dw);
+  // (u, v, w) stay out until they are downloaded or taken; everything else returns to the pool
+  for (int c = 0; c < 3; ++c) result_flow_[c] = flow[c];
+  for (DevicePtr p : {blurred[0], blurred[1], level_frame[0], level_frame[1], step[0], step[1], step[2]}) GiveBack(p);
   return true;
 }
 

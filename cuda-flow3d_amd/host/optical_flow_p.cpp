@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "common_utils.h"
+#include "operator_calls.h"
 #include "hip_utils.h"
 
 OpticalFlowP::OpticalFlowP() : OpticalFlowBase("Optical Flow Single GPU Piecemeal Processing")
@@ -239,156 +240,103 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     std::printf("Allocating additional memory on the host...\n");
     std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * volume_bytes / (1024.f * 1024.f));
   }
-  Data3D frame_0_res, frame_1_res_br, flow_du, flow_dv, flow_dw, temp_0, temp_1, temp_2;
-  Data3D* own[8] = {&frame_0_res, &frame_1_res_br, &flow_du, &flow_dv, &flow_dw, &temp_0, &temp_1, &temp_2};
-  for (Data3D* v : own) {
-    if (!v->Allocate(W0, H0, D0)) {
+  // Roles of the host volumes in a level (the operator keys they are bound to are the reference's, optical_flow_p.cpp:152-266):
+  //   whole[2]    the two frames at the original size (the caller's, or their blurred copies) -- resampled FROM at every level
+  //   level[2]    the two frames at the level's size; level[1] is replaced by its registered version
+  //   flow[3]     u, v, w: the caller's volumes, resampled in place from level to level
+  //   step[3]     the solver's increments du, dv, dw
+  //   spare[3]    scratch: the registration's output, two (three) of the solver's ping-pong partners
+  Data3D scratch[8];
+  for (Data3D& v : scratch) {
+    if (!v.Allocate(W0, H0, D0)) {
       finish();
       return;
     }
-    pin_volume(v);
+    pin_volume(&v);
   }
-
-  Data3D* p_frame_0 = src_0;
-  Data3D* p_frame_1 = src_1;
-  Data3D* p_frame_0_res = &frame_0_res;
-  Data3D* p_frame_1_res_br = &frame_1_res_br;
+  Data3D* whole[2] = {src_0, src_1};
+  Data3D* level[2] = {&scratch[0], &scratch[1]};
+  Data3D* flow[3] = {&flow_u, &flow_v, &flow_w};
+  Data3D* step[3] = {&scratch[2], &scratch[3], &scratch[4]};
+  Data3D* spare[3] = {&scratch[5], &scratch[6], &scratch[7]};
 
   // every piecemeal Execute drains the stream before it returns, so host clocks around the calls time the device work
-  auto timed = [this](int slot, CudaOperationBase& cuop, OperationParameters& bag) {
+  OperationParameters bag;
+  auto run = [this, &bag](int clock, CudaOperationBase& cuop, std::initializer_list<BagEntry> call) {
+    FillBag(bag, call);
     const auto t0 = std::chrono::steady_clock::now();
     cuop.Execute(bag);
-    op_seconds_[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    op_seconds_[clock] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
+  enum Clock { kFrames = 0, kFlowResample = 1, kRegistration = 2, kSolve = 3, kAddAndMedian = 4 };
   cuop_stat_p_.silent = silent;
-  OperationParameters op;
+  cuop_solve_p_.silent = silent;
 
-  while (current_warp_level >= 0) {
-    const PyramidLevel lv = GetLevel(original_data_size, warp_scale_factor, current_warp_level);
-    current_data_size = lv.size;
-    hx = lv.hx;
-    hy = lv.hy;
-    hz = lv.hz;
+  for (; current_warp_level >= 0; --current_warp_level) {
+    const bool finest = current_warp_level == 0;
+    const PyramidLevel geometry = GetLevel(original_data_size, warp_scale_factor, current_warp_level);
+    current_data_size = geometry.size;
+    hx = geometry.hx;
+    hy = geometry.hy;
+    hz = geometry.hz;
     if (!silent)
       std::printf("Solve level %2d (%4zu x%4zu x%4zu) \n", current_warp_level, current_data_size.width, current_data_size.height,
                   current_data_size.depth);
 
-    /* Data resampling */
-    if (current_warp_level == 0) {
-      std::swap(p_frame_0, p_frame_0_res);
-      std::swap(p_frame_1, p_frame_1_res_br);
-    } else {
-      op.Clear();
-      op.PushValuePtr("input", p_frame_0);
-      op.PushValuePtr("output", p_frame_0_res);
-      op.PushValuePtr("data_size", &original_data_size);
-      op.PushValuePtr("resample_size", &current_data_size);
-      timed(0, cuop_resample_p_, op);
-
-      op.Clear();
-      op.PushValuePtr("input", p_frame_1);
-      op.PushValuePtr("output", p_frame_1_res_br);
-      op.PushValuePtr("data_size", &original_data_size);
-      op.PushValuePtr("resample_size", &current_data_size);
-      timed(0, cuop_resample_p_, op);
+    // 1. the frames of this level: the originals themselves at the finest level (their storage changes roles), area-resampled
+    //    copies of the ORIGINALS everywhere else
+    for (int f = 0; f < 2; ++f) {
+      if (finest)
+        std::swap(whole[f], level[f]);
+      else
+        run(kFrames, cuop_resample_p_,
+            {{"input", whole[f]}, {"output", level[f]}, {"data_size", &original_data_size}, {"resample_size", &current_data_size}});
     }
 
-    /* Flow field resampling (in place) */
-    if (prev_data_size.width == 0) {
-      flow_u.ZeroData();
-      flow_v.ZeroData();
-      flow_w.ZeroData();
-    } else {
-      for (Data3D* flow : {&flow_u, &flow_v, &flow_w}) {
-        op.Clear();
-        op.PushValuePtr("input", flow);
-        op.PushValuePtr("output", flow);
-        op.PushValuePtr("data_size", &prev_data_size);
-        op.PushValuePtr("resample_size", &current_data_size);
-        timed(1, cuop_resample_p_, op);
-      }
+    // 2. the flow so far at this level's size, in place (zero before the first level); values stay in original-voxel units
+    for (Data3D* component : flow) {
+      if (prev_data_size.width == 0)
+        component->ZeroData();
+      else
+        run(kFlowResample, cuop_resample_p_,
+            {{"input", component}, {"output", component}, {"data_size", &prev_data_size}, {"resample_size", &current_data_size}});
     }
 
-    /* Backward registration: *p_frame_1_res_br and temp_0 trade storage, the warped frame ends up in the former */
-    {
-      size_t max_magnitude = static_cast<size_t>(std::ceil(flow_stat.max / warp_scale_factor));
-      op.Clear();
-      op.PushValuePtr("frame_0", p_frame_0_res);
-      op.PushValuePtr("frame_1", p_frame_1_res_br);
-      op.PushValuePtr("flow_u", &flow_u);
-      op.PushValuePtr("flow_v", &flow_v);
-      op.PushValuePtr("flow_w", &flow_w);
-      op.PushValuePtr("temp", &temp_0);
-      op.PushValuePtr("hx", &hx);
-      op.PushValuePtr("hy", &hy);
-      op.PushValuePtr("hz", &hz);
-      op.PushValuePtr("data_size", &current_data_size);
-      op.PushValuePtr("max_mag", &max_magnitude);
-      timed(2, cuop_register_p_, op);
-    }
+    // 3. frame 1 registered with that flow: the operator writes into spare[0] and trades its storage with level[1], which then
+    //    holds the registered frame (spare[0]: the unregistered one)
+    size_t max_magnitude = static_cast<size_t>(std::ceil(flow_stat.max / warp_scale_factor));
+    run(kRegistration, cuop_register_p_,
+        {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]}, {"temp", spare[0]},
+         {"hx", &hx}, {"hy", &hy}, {"hz", &hz}, {"data_size", &current_data_size}, {"max_mag", &max_magnitude}});
 
-    /* Difference problem solver */
-    {
-      op.Clear();
-      op.PushValuePtr("frame_0", p_frame_0_res);
-      op.PushValuePtr("frame_1", p_frame_1_res_br);
-      op.PushValuePtr("flow_u", &flow_u);
-      op.PushValuePtr("flow_v", &flow_v);
-      op.PushValuePtr("flow_w", &flow_w);
-      op.PushValuePtr("flow_du", &flow_du);
-      op.PushValuePtr("flow_dv", &flow_dv);
-      op.PushValuePtr("flow_dw", &flow_dw);
-      op.PushValuePtr("temp_du", &temp_1);
-      op.PushValuePtr("temp_dv", &temp_2);
-      // at level 0 temp_0 holds the caller's unwarped frame 1 (see below), so the third scratch is the free resample buffer
-      Data3D* third = current_warp_level == 0 ? p_frame_1 : &temp_0;
-      op.PushValuePtr("temp_dw", third);
-      op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
-      op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
-      op.PushValuePtr("equation_alpha", &equation_alpha);
-      op.PushValuePtr("equation_smoothness", &equation_smoothness);
-      op.PushValuePtr("equation_data", &equation_data);
-      op.PushValuePtr("data_size", &current_data_size);
-      op.PushValuePtr("hx", &hx);
-      op.PushValuePtr("hy", &hy);
-      op.PushValuePtr("hz", &hz);
-      cuop_solve_p_.silent = silent;
-      timed(3, cuop_solve_p_, op);
-      solve_passes_ += cuop_solve_p_.LastPasses();
-      if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
-    }
+    // 4. the increments.  The third ping-pong partner is spare[0] -- except at the finest level, where spare[0] holds the caller's
+    //    unregistered frame 1 (step 6) and the volume the frames were resampled from is free instead
+    Data3D* third_partner = finest ? whole[1] : spare[0];
+    run(kSolve, cuop_solve_p_,
+        {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]},
+         {"flow_du", step[0]}, {"flow_dv", step[1]}, {"flow_dw", step[2]}, {"temp_du", spare[1]}, {"temp_dv", spare[2]},
+         {"temp_dw", third_partner}, {"outer_iterations_count", &outer_iterations_count},
+         {"inner_iterations_count", &inner_iterations_count}, {"equation_alpha", &equation_alpha},
+         {"equation_smoothness", &equation_smoothness}, {"equation_data", &equation_data}, {"data_size", &current_data_size},
+         {"hx", &hx}, {"hy", &hy}, {"hz", &hz}});
+    solve_passes_ += cuop_solve_p_.LastPasses();
+    if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
 
-    /* Add the solved flow increment to the global flow */
-    {
-      Data3D* flows[3] = {&flow_u, &flow_v, &flow_w};
-      Data3D* incs[3] = {&flow_du, &flow_dv, &flow_dw};
-      for (int i = 0; i < 3; ++i) {
-        op.Clear();
-        op.PushValuePtr("operand_0", flows[i]);
-        op.PushValuePtr("operand_1", incs[i]);
-        op.PushValuePtr("data_size", &current_data_size);
-        timed(4, cuop_add_p_, op);
-      }
-    }
+    // 5. flow += increments
+    for (int c = 0; c < 3; ++c)
+      run(kAddAndMedian, cuop_add_p_, {{"operand_0", flow[c]}, {"operand_1", step[c]}, {"data_size", &current_data_size}});
 
-    // At level 0 the registration swapped the CALLER's frame_1 with temp_0; give the caller its storage (and its data,
-    // which the warp only read) back.  The reference leaves the warped frame in the caller's volume.
-    if (current_warp_level == 0) src_1->Swap(temp_0);
+    // 6. At the finest level step 3 traded the CALLER's frame 1 for spare[0]: the caller gets its storage (and its data, which
+    //    the registration only read) back.  The reference leaves the registered frame in the caller's volume.
+    if (finest) src_1->Swap(*spare[0]);
 
-    /* Flow field median filtering (full pipeline only; commented out in the reference, optical_flow_p.cpp:268-302) */
-    if (level_median != 1) {
-      for (Data3D* flow : {&flow_u, &flow_v, &flow_w}) {
-        op.Clear();
-        op.PushValuePtr("input", flow);
-        op.PushValuePtr("output", flow);
-        op.PushValuePtr("data_size", &current_data_size);
-        op.PushValuePtr("radius", &level_median);
-        timed(4, cuop_median_p_, op);
-      }
-    }
+    // 7. median of every component, in place (full pipeline only: commented out in the reference, optical_flow_p.cpp:268-302)
+    if (level_median != 1)
+      for (Data3D* component : flow)
+        run(kAddAndMedian, cuop_median_p_,
+            {{"input", component}, {"output", component}, {"data_size", &current_data_size}, {"radius", &level_median}});
 
     prev_data_size = current_data_size;
-    --current_warp_level;
   }
 
   finish();
@@ -493,84 +441,37 @@ bool OpticalFlowP::RunResidentLevels(Data3D& frame_0, Data3D& frame_1, Data3D& f
     }
     if (!ok) break;
 
-    // flow of the previous level (values stay in original-voxel units)
-    if (prev.width == 0) {
-      for (int i = FU; i <= FW; ++i)
-        ok = !CheckDeviceError(f3d_memset2d(buf[i], container.pitch, 0, container.width * sizeof(float), rows)) && ok;
-    } else {
-      for (int i = 0; i < 3; ++i) {
-        op.Clear();
-        op.PushValuePtr("dev_input", &buf[FU + i]);
-        op.PushValuePtr("dev_output", &buf[DU + i]);
-        op.PushValuePtr("dev_temp", &buf[TMP]);
-        op.PushValuePtr("data_size", &prev);
-        op.PushValuePtr("resample_size", &current);
-        cuop_resample_e_.Execute(op);
-        std::swap(buf[FU + i], buf[DU + i]);
+    // the flow so far at this size (zero before the first level; values stay in original-voxel units)
+    for (int c = 0; c < 3; ++c) {
+      if (prev.width == 0) {
+        ok = !CheckDeviceError(f3d_memset2d(buf[FU + c], container.pitch, 0, container.width * sizeof(float), rows)) && ok;
+      } else {
+        cuop_resample_e_.Execute(calls::Resample(op, &buf[FU + c], &buf[DU + c], &buf[TMP], &prev, &current));
+        std::swap(buf[FU + c], buf[DU + c]);
       }
     }
+    const calls::Flow flow = {&buf[FU], &buf[FV], &buf[FW]};
+    const calls::Spacing spacing = {&hx, &hy, &hz};
 
-    // backward registration
-    op.Clear();
-    op.PushValuePtr("dev_frame_0", &buf[F0R]);
-    op.PushValuePtr("dev_frame_1", &buf[F1R]);
-    op.PushValuePtr("dev_flow_u", &buf[FU]);
-    op.PushValuePtr("dev_flow_v", &buf[FV]);
-    op.PushValuePtr("dev_flow_w", &buf[FW]);
-    op.PushValuePtr("dev_output", &buf[TMP]);
-    op.PushValuePtr("data_size", &current);
-    op.PushValuePtr("hx", &hx);
-    op.PushValuePtr("hy", &hy);
-    op.PushValuePtr("hz", &hz);
-    cuop_register_e_.Execute(op);
+    // frame 1 registered with it
+    cuop_register_e_.Execute(calls::Registration(op, &buf[F0R], &buf[F1R], flow, &buf[TMP], &current, spacing));
     std::swap(buf[F1R], buf[TMP]);
 
-    // difference problem
-    op.Clear();
-    op.PushValuePtr("dev_frame_0", &buf[F0R]);
-    op.PushValuePtr("dev_frame_1", &buf[F1R]);
-    op.PushValuePtr("dev_flow_u", &buf[FU]);
-    op.PushValuePtr("dev_flow_v", &buf[FV]);
-    op.PushValuePtr("dev_flow_w", &buf[FW]);
-    op.PushValuePtr("dev_flow_du", &buf[DU]);
-    op.PushValuePtr("dev_flow_dv", &buf[DV]);
-    op.PushValuePtr("dev_flow_dw", &buf[DW]);
-    op.PushValuePtr("dev_phi", &buf[PHI]);
-    op.PushValuePtr("dev_ksi", &buf[KSI]);
-    op.PushValuePtr("dev_temp_du", &buf[TDU]);
-    op.PushValuePtr("dev_temp_dv", &buf[TDV]);
-    op.PushValuePtr("dev_temp_dw", &buf[TDW]);
-    op.PushValuePtr("outer_iterations_count", &outer_iterations_count);
-    op.PushValuePtr("inner_iterations_count", &inner_iterations_count);
-    op.PushValuePtr("equation_alpha", &equation_alpha);
-    op.PushValuePtr("equation_smoothness", &equation_smoothness);
-    op.PushValuePtr("equation_data", &equation_data);
-    op.PushValuePtr("data_size", &current);
-    op.PushValuePtr("hx", &hx);
-    op.PushValuePtr("hy", &hy);
-    op.PushValuePtr("hz", &hz);
+    // the increments
     cuop_solve_e_.silent = true;
-    cuop_solve_e_.Execute(op);
+    cuop_solve_e_.Execute(calls::Solve(op, &buf[F0R], &buf[F1R], flow, {&buf[DU], &buf[DV], &buf[DW]}, {&buf[TDU], &buf[TDV], &buf[TDW]},
+                                       &buf[PHI], &buf[KSI],
+                                       {&outer_iterations_count, &inner_iterations_count, &equation_alpha, &equation_smoothness, &equation_data},
+                                       &current, spacing));
     ++solve_passes_;
 
-    for (int i = 0; i < 3; ++i) {
-      op.Clear();
-      op.PushValuePtr("operand_0", &buf[FU + i]);
-      op.PushValuePtr("operand_1", &buf[DU + i]);
-      op.PushValuePtr("data_size", &current);
-      cuop_add_e_.Execute(op);
-    }
-    if (median_radius != 1) {
-      for (int i = 0; i < 3; ++i) {
-        op.Clear();
-        op.PushValuePtr("dev_input", &buf[FU + i]);
-        op.PushValuePtr("dev_output", &buf[TMP]);
-        op.PushValuePtr("data_size", &current);
-        op.PushValuePtr("radius", &median_radius);
-        cuop_median_e_.Execute(op);
-        std::swap(buf[FU + i], buf[TMP]);
+    // flow += increments; median of every component through the scratch container
+    for (int c = 0; c < 3; ++c) cuop_add_e_.Execute(calls::Add(op, &buf[FU + c], &buf[DU + c], &current));
+    if (median_radius != 1)
+      for (int c = 0; c < 3; ++c) {
+        cuop_median_e_.Execute(calls::Median(op, &buf[FU + c], &buf[TMP], &current, &median_radius));
+        std::swap(buf[FU + c], buf[TMP]);
       }
-    }
     prev = current;
   }
 
