@@ -54,20 +54,63 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def solver_source_stamp():
-    """sha256 (16 hex digits) of the solver kernel source with comments and white space taken out (a reworded comment is not
-    another kernel) and without the `#ifdef F3D_LAB` blocks (timing builds that only lib/lab/ has): the PMC record is only valid
-    for the kernels it was taken on.  tools/pmc_traffic.sh stamps its record with this function;
-    tests/test_abi.py::test_the_newest_counter_record_is_of_the_shipped_kernels holds the newest record to it."""
-    import re
+SOLVER_KERNELS = ("k_pair8", "k_sweep6", "k_sweep7", "k_phiksi6")
+
+
+def solver_kernel_stamp(library=None):
+    """sha256 (16 hex digits) over the MACHINE CODE of the solver kernels in the library being timed: every function symbol of the
+    gfx950 code objects inside libf3d_hip.so whose name holds one of SOLVER_KERNELS, name and bytes, sorted by name.  The counter
+    record (profiles/*_pmc_traffic.json) is only valid for the kernels it was taken on; rounds 1-3 stamped the SOURCE files, and a
+    lab-only edit of a kernel template (a timing probe that the shipped instantiations do not contain) invalidated the record of
+    round 3 although no shipped instruction had changed.  What ran is what is hashed now: an edit that leaves the shipped kernels'
+    code alone leaves the stamp alone.  Pure Python (clang offload bundle -> ELF64 symbol table), no tool needed on the GPU box.
+    tools/pmc_traffic.sh stamps its record with this function; tests/test_abi.py holds the newest record to it."""
+    import struct
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    path = library or os.path.join(os.environ.get("F3D_LIBDIR") or os.path.join(ROOT, "cuda-flow3d_amd", "lib"), "libf3d_hip.so")
+    with open(path, "rb") as f:
+        blob = f.read()
+    found = []
+    pos = 0
+    while True:
+        at = blob.find(magic, pos)
+        if at < 0:
+            break
+        pos = at + len(magic)
+        (count,) = struct.unpack_from("<Q", blob, at + len(magic))
+        if not 0 < count < 16:
+            continue
+        p = at + len(magic) + 8
+        for _ in range(count):
+            offset, size, id_len = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p:p + id_len]
+            p += id_len
+            if not (triple.startswith(b"hip") and triple.endswith(b"gfx950") and size):
+                continue
+            elf = blob[at + offset:at + offset + size]
+            shoff, = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+            sections = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+            for sec in sections:
+                if sec[1] != 2:                                   # SHT_SYMTAB
+                    continue
+                strings = sections[sec[6]][4]
+                for k in range(sec[5] // 24):
+                    name, info, _, shndx, value, nbytes = struct.unpack_from("<IBBHQQ", elf, sec[4] + k * 24)
+                    if info & 0xf != 2 or not nbytes or shndx >= shnum:   # STT_FUNC with a body
+                        continue
+                    text = elf[strings + name:elf.index(b"\0", strings + name)].decode()
+                    if any(key in text for key in SOLVER_KERNELS):
+                        home = sections[shndx]
+                        start = home[4] + value - home[3]
+                        found.append((text, elf[start:start + nbytes]))
+    if not found:
+        return None
     h = hashlib.sha256()
-    for name in ("f3d_solve.hip", "f3d_solve_pair8.h"):
-        with open(os.path.join(ROOT, "cuda-flow3d_amd", "csrc", name)) as f:
-            text = f.read()
-        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)     # block comments
-        text = re.sub(r"//[^\n]*", " ", text)                  # line comments (no string of these files holds "//")
-        text = re.sub(r"#ifdef F3D_LAB\b.*?#endif", " ", text, flags=re.S)   # lab-only dispatch: not in the shipped library
-        h.update(" ".join(text.split()).encode())
+    for text, code in sorted(found):
+        h.update(text.encode())
+        h.update(code)
     return h.hexdigest()[:16]
 
 
@@ -87,9 +130,9 @@ def measured_traffic(kernel):
     rec = doc.get(kernel)
     if not rec:
         return None
-    if doc.get("_solver_source_sha16") != solver_source_stamp():
-        return {"traffic": None, "traffic_scope": f"{os.path.basename(files[-1])} was collected on other kernel sources "
-                                                  f"({doc.get('_solver_source_sha16')}); not used"}
+    if doc.get("_solver_kernels_sha16") != solver_kernel_stamp():
+        return {"traffic": None, "traffic_scope": f"{os.path.basename(files[-1])} was collected on other solver kernels "
+                                                  f"({doc.get('_solver_kernels_sha16')}); not used"}
     return {"traffic": rec["hbm_bytes_per_launch"],
             "traffic_scope": f"one {doc.get('_size', 512)}^3 launch of {kernel}; algorithmic bytes of that launch: "
                              f"{rec['algorithmic_bytes_per_launch']}; source {os.path.basename(files[-1])}",

@@ -274,6 +274,9 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
 // ABL (timing experiments only, wrong results): bit 0 = the loader issues nothing after the prologue, bit 1 = no stage
 // arithmetic (LDS traffic, barriers and stores stay), bit 2 = the compute waves only keep the barriers, bit 3 = arithmetic only behind the
 // prologue (no LDS reads, no step barriers), bit 5 (with bit 3: F3D_ABLATE8=40) = the prologue fetches one plane instead of three
+// bit 6 (F3D_ABLATE8=64, two sweeps, TY <= 8): a THIRD stage per step -- what a (sweep, sweep, sweep) launch would cost: stage 2's
+// results go to a third LDS image, a second carry set is kept for the plane before, stage 2's arithmetic runs once more on the
+// neighbours read back from that image, and every chunk marches one plane further (the third stage trails by one more plane)
 // FD: the kernel reads the frame derivatives fx, fy, fz, ft (k_frame_derivatives, once per level) instead of the frames: they
 // are centre values, so the frame entries of every neighbour -- their LDS reads, lane shifts, differences and the three
 // divisions by 4h -- drop out of stage 1 (a seventh of its arithmetic), for two more arrays to stream.
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   constexpr int SB = FD ? 2 : 0;   // ring array = input - SB
   __shared__ float img1[2][3][NR][kLanes];  // stage-1 results of the row waves: S = U + dU' (SS) or dU' (SP)
   __shared__ float hc1[2][3][2][32];        // the same for the two halo columns: [component][side][core row]
+  __shared__ float img3[(ABL & 64) ? 3 : 1][(ABL & 64) ? NR : 1][(ABL & 64) ? kLanes : 1];  // lab: stage-2 results for a third stage
 
   int tile = static_cast<int>(blockIdx.x);
   if (xcd_remap) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const bool colw = r == NR;
   const bool loader = r == NR + 1;
   const int z0 = m_lo + tz * zchunk;
-  const int z1 = min(z0 + zchunk, m_hi);
+  const int z1 = min(z0 + zchunk + ((ABL & 64) ? 1 : 0), m_hi);   // (lab, bit 6: the third stage trails by one more plane)
   const int qs = z0 > 0 ? z0 - 1 : 0;        // first and last plane of stage 1
   const int qe = z1 < MDIM ? z1 : MDIM - 1;
   const int q_end = z1 < MDIM ? qe : qe + 1;  // the top chunk takes one more step: stage 2 of plane D-1 alone
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   S3 hM = {0.f, 0.f, 0.f}, hC = {0.f, 0.f, 0.f};  // stage-1 result of planes q-2 and q-1 (SS: S = U + dU'; SP: dU')
   float hC_dv = 0.f, hC_dw = 0.f;                 // SS: dV', dW' of plane q-1
   Carry kC = {};
+  Carry kC2 = {};   // lab, bit 6: the carry of the plane before (a third stage needs it one step longer)
   CarryP pC = {};
 
   // Raw neighbours of a plane for stage 1 -- the rows above and below and the x-halo column (column wave: its two y
@@ -785,6 +790,24 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
         phi_ksi_stage2(pC, xm, xp, YM ? zm : ym, YM ? zp : yp, YM ? ym : zm, YM ? yp : zp, hC.u, hC.v, hC.w, sdivs, a.eps_s2,
                        a.eps_d2, o0, o1, owner, a.plain_division == 0);
     }
+    if constexpr ((ABL & 64) != 0) {
+      // lab: a third stage with the instruction stream of a real one (WRONG values): publish stage 2's results, read the row
+      // neighbours and the halo column back, shift the lanes, run the sweep's second-stage arithmetic on the carry of plane q-2
+      if (do2) {
+        img3[0][r][lane] = o0; img3[1][r][lane] = o1; img3[2][r][lane] = o2;
+        S3 ym, yp, xm, xp;
+        ym.u = img3[0][r_ym][lane]; ym.v = img3[1][r_ym][lane]; ym.w = img3[2][r_ym][lane];
+        yp.u = img3[0][r_yp][lane]; yp.v = img3[1][r_yp][lane]; yp.w = img3[2][r_yp][lane];
+        const float eu = hc1[b][0][side][r - 1], ev = hc1[b][1][side][r - 1], ew = hc1[b][2][side][r - 1];
+        xm.u = lane_left_or(o0, eu); xm.v = lane_left_or(o1, ev); xm.w = lane_left_or(o2, ew);
+        xp.u = lane_right_or(o0, eu); xp.v = lane_right_or(o1, ev); xp.w = lane_right_or(o2, ew);
+        const S3 zm = hM, zp = {o0, o1, o2};
+        float p0, p1, p2;
+        sweep_stage2(kC2, xm, xp, ym, yp, zm, zp, o1, o2, p0, p1, p2);
+        o0 = p0; o1 = p1; o2 = p2;
+      }
+      kC2 = kC;
+    }
     asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(sN.u), "v"(sN.v), "v"(sN.w));
     hM = hC;
     hC = sN;
@@ -931,6 +954,9 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
       if (abl == 4) return go(k_pair8<MODE, TY, 4>);
       if (abl == 8) return go(k_pair8<MODE, TY, 8>);
       if (abl == 40) return go(k_pair8<MODE, TY, 40>);
+      if constexpr (TY <= 8) {
+        if (abl == 64) return go(k_pair8<MODE, TY, 64>);
+      }
     }
 #endif
     go(k_pair8<MODE, TY, 0>);

@@ -113,8 +113,9 @@ def test_the_shipped_library_has_no_switch_that_changes_a_result():
 
 def test_the_newest_counter_record_is_of_the_shipped_kernels():
     """bench.py's roofline.traffic comes from the newest profiles/*_pmc_traffic.json and is dropped when that record was collected on
-    other kernel sources (round 3's driver line lost it that way): the newest record must carry the stamp of the solver sources in
-    the tree.  After any change to csrc/f3d_solve.hip / f3d_solve_pair8.h: tools/pmc_traffic.sh on the GPU, copy the record."""
+    other kernels (round 3's driver line lost it that way): the newest record must carry the stamp of the solver kernels' machine code
+    in the built library (bench.solver_kernel_stamp: a source edit that leaves the shipped instructions alone leaves it alone).
+    After a change that moves it: tools/pmc_traffic.sh on the GPU, copy the record."""
     import json
     import sys
     sys.path.insert(0, ROOT)
@@ -122,6 +123,6 @@ def test_the_newest_counter_record_is_of_the_shipped_kernels():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     assert files
     doc = json.load(open(files[-1]))
-    assert doc.get("_solver_source_sha16") == bench.solver_source_stamp(), (
-        f"{os.path.basename(files[-1])} was collected on other solver sources: run tools/pmc_traffic.sh and commit the new record")
+    assert doc.get("_solver_kernels_sha16") == bench.solver_kernel_stamp(), (
+        f"{os.path.basename(files[-1])} was collected on other solver kernels: run tools/pmc_traffic.sh and commit the new record")
     assert bench.measured_traffic("k_pair8")["traffic"]

@@ -41,8 +41,8 @@ import hashlib
 import sys
 sys.path.insert(0, "$R")
 sys.argv = ["bench.py"]
-import bench  # the stamp bench.py checks the record against (kernel sources without comments and white space)
-res["_solver_source_sha16"] = bench.solver_source_stamp()
+import bench  # the stamp bench.py checks the record against: the machine code of the solver kernels in the library that just ran
+res["_solver_kernels_sha16"] = bench.solver_kernel_stamp()
 json.dump(res, open("$O/traffic_raw.json", "w"), indent=1)
 # the record bench.py reads (profiles/rNN_pmc_traffic.json): HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
 S = 512
@@ -52,7 +52,7 @@ out = {"_note": "HBM bytes per 512^3 launch = (2 x FETCH_SIZE + WRITE_SIZE) x 10
                 "separate passes over tools/kbench.py --size 512 (tools/pmc_traffic.sh); both counters are in KiB; FETCH_SIZE is doubled as "
                 "MI355X_MICROARCH.md prescribes for gfx950, and the same run calibrates it on tools/lab/stream_lab (k_flat reads 10 x 512 MiB, "
                 "writes 3 x 512 MiB).",
-       "_size": S, "_solver_source_sha16": res["_solver_source_sha16"],
+       "_size": S, "_solver_kernels_sha16": res["_solver_kernels_sha16"],
        "_calibration": {k: v for k, v in res.items() if k.startswith("k_flat")}}
 for k, b in alg.items():
     if k in res and "FETCH_SIZE" in res[k] and "WRITE_SIZE" in res[k]:
