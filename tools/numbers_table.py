@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""The one table of current numbers in DESIGN.md section 7, generated from the committed records under profiles/ (round tag below).
+   python tools/numbers_table.py            prints the table
+   python tools/numbers_table.py --write    replaces the block between the two `numbers` markers in DESIGN.md
+Every row names the file it was read from; a row whose file is missing is left out (nothing is typed in by hand)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "r04"
+P = lambda name: os.path.join(ROOT, "profiles", f"{TAG}_{name}")
+
+
+def last_json_line(path):
+    with open(path) as f:
+        lines = [l for l in f.read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def rows():
+    out = []
+    f = P("bench_steps20_warmup5.json")
+    if os.path.exists(f):
+        b = last_json_line(f)
+        r = b["roofline"]
+        src = os.path.relpath(f, ROOT)
+        out.append(("512³ full default pyramid, 1 GPU (`bench.py --gpus 1 --steps 20 --warmup 5`)",
+                    f"**{b['value']:.2f} Mvoxels/s**, {b['ms_per_step']:.1f} ms per solve device-resident; {b['host_inclusive']['value']:.2f} with "
+                    f"H2D + D2H inside the timer; whole run {100 * b['whole_run_roofline_frac']:.1f} % of 8 TB/s in algorithmic bytes; "
+                    f"`parity.match` {b['parity']['match']}", src))
+        fin = r["finest_level"]
+        out.append(("two-sweep launch `k_pair8<SS>` (dominant kernel)",
+                    f"over the pyramid {r['achieved']:.0f} GB/s algorithmic = **{r['frac']:.3f}** ({r['avg_launch_us']:.1f} µs average over "
+                    f"{r['launches']} launches); 512³ level {fin['avg_launch_us']:.0f} µs = {fin['frac']:.3f}; in counter bytes "
+                    f"{r.get('traffic', 0) / 1e9:.2f} GB per 512³ launch → {r.get('hbm_GBs', 0):.0f} GB/s = `hbm_frac` {r.get('hbm_frac', 0):.3f}", src))
+        sp = r["sweep_phi_ksi"]
+        out.append(("sweep + next phi/ksi `k_pair8<SP>`",
+                    f"over the pyramid {sp['achieved']:.0f} GB/s algorithmic = {sp['achieved'] / 8000:.3f}; 512³ level "
+                    f"{sp['finest_level']['avg_launch_us']:.0f} µs = {sp['finest_level']['frac']:.3f}", src))
+        out.append(("all solver launches at their algorithmic bytes", f"{r['all_solver_launches']['achieved']:.0f} GB/s = "
+                    f"{r['all_solver_launches']['frac']:.3f}", src))
+        for c in b.get("configs", []):
+            out.append((c["workload"], f"{c['ms_per_step']:.1f} ms = {c['value']:.1f} Mvoxels/s = {c['roofline_frac']:.3f} of the roofline", src))
+        if "fixed_sample" in b:
+            fs = b["fixed_sample"]
+            cpu = fs.get("cpu", {})
+            out.append(("SURVEY §8d fixed sample (phi/ksi + 5 sweeps on the 512³ level)",
+                        f"GPU {fs['gpu']['value'] / 1e3:.1f} Gvoxel-updates/s ({fs['gpu']['ms']:.2f} ms); host cores "
+                        f"{cpu.get('value', 0) / 1e3:.2f} ({cpu.get('cores', '?')} threads)", src))
+        if "cpu_baseline" in b:
+            cb = b["cpu_baseline"]
+            out.append(("`cpu_baseline` (BASELINE config 2 in full on the host, oracle)", f"{cb['value']:.4f} Mvoxels/s on {cb['cores']} threads "
+                        f"(`kind: \"{cb['kind']}\"`)", src))
+    f = P("pmc_traffic.json")
+    if os.path.exists(f):
+        d = json.load(open(f))
+        cells = []
+        for k in ("k_pair8_fd", "k_pair8_sweep_phi_ksi_fd", "k_pair8", "k_pair8_sweep_phi_ksi", "k_sweep6", "k_phiksi6"):
+            if k in d:
+                cells.append(f"`{k}` {d[k]['hbm_bytes_per_launch'] / 1e9:.2f} GB ({d[k]['ratio']:.2f} × algorithmic)")
+        out.append(("HBM bytes per 512³ launch (PMC: 2 × FETCH_SIZE + WRITE_SIZE, separate passes)", "; ".join(cells), os.path.relpath(f, ROOT)))
+    f = P("c5_one_gpu.json")
+    if os.path.exists(f):
+        b = last_json_line(f)
+        out.append(("1024³ (BASELINE config 5) on ONE GPU", f"{b['value']:.2f} Mvoxels/s, {b['ms_per_step'] / 1e3:.2f} s per solve; `parity.match` "
+                    f"{b['parity']['match']}", os.path.relpath(f, ROOT)))
+    f = P("bench_gpus2_bare_shm_rehearsal.json")
+    if os.path.exists(f):
+        b = last_json_line(f)
+        o = b["exchange_orders"]
+        cell = (f"REHEARSAL of the line's orchestration, two rank processes on one GPU over shared memory (not a number): both orders "
+                f"`parity.match` {[o[k]['parity']['match'] for k in o]}, `single_gpu_same_size.digest_equals_the_slab_runs` "
+                f"{b['single_gpu_same_size']['digest_equals_the_slab_runs']}, `speedup` field present ({b['speedup']}), exchanges per step "
+                f"{[o[k]['comm']['exchanges_per_step_rank0'] for k in o]}, `config5` leg "
+                f"{'present, parity ' + str(b['config5']['parity']['match']) if 'config5' in b else 'not run'}")
+        out.append(("`bench.py --gpus 2` started bare", cell, os.path.relpath(f, ROOT)))
+    for size in (512, 1024):
+        f = P(f"slab8_onegpu_{size}.json")
+        if os.path.exists(f):
+            d = json.load(open(f))
+            tot = d.get("total", d)
+            out.append((f"8 z-slabs of {size}³ run one after the other on ONE GPU (the work 8 GPUs divide)",
+                        f"kernel time {tot.get('ratio', 0):.3f} × the unsplit solve", os.path.relpath(f, ROOT)))
+    return out
+
+
+def table():
+    lines = ["<!-- numbers:begin (generated by tools/numbers_table.py from profiles/; do not edit by hand) -->",
+             "| what | measured (one MI355X; boxes of the pool differ by ±3 %) | record |", "|---|---|---|"]
+    for what, value, src in rows():
+        lines.append(f"| {what} | {value} | `{src}` |")
+    lines.append("<!-- numbers:end -->")
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    t = table()
+    if "--write" in sys.argv:
+        path = os.path.join(ROOT, "DESIGN.md")
+        s = open(path).read()
+        if "NUMBERS_TABLE" in s:
+            s = s.replace("NUMBERS_TABLE", t)
+        else:
+            a, b = s.index("<!-- numbers:begin"), s.index("<!-- numbers:end -->") + len("<!-- numbers:end -->")
+            s = s[:a] + t + s[b:]
+        open(path, "w").write(s)
+    else:
+        print(t)
