@@ -1693,7 +1693,8 @@ int f3d_frame_derivatives(f3d_devptr frame_0, f3d_devptr frame_1, size_t width, 
 namespace {
 // the two fused launches on precomputed frame derivatives
 int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], size_t width, size_t height, size_t depth, float hx, float hy,
-             float hz, float alpha, float eps_s, float eps_d, const f3d_devptr (&out)[5], const f3d_slab* slab)
+             float hz, float alpha, float eps_s, float eps_d, const f3d_devptr (&out)[5], const f3d_slab* slab, int keep_below = 0,
+             int keep_above = 0)
 {
   F3dGeo g;
   if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
@@ -1705,6 +1706,8 @@ int pair8_fd(const char* who, bool with_weights, const f3d_devptr (&in)[12], siz
   if (g.z_lo == g.z_hi) return 0;
   if (!slab_reach_ok(g, 2, who)) return 1;
   PairArgs a = {};
+  a.keep_below = with_weights && keep_below != 0;
+  a.keep_above = with_weights && keep_above != 0;
   static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
   a.plain_division = plain_division;
   for (int i = 0; i < 12; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
@@ -1755,6 +1758,20 @@ int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_
   const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, phi_next, ksi_next};
   return pair8_fd("f3d_solve_sweep_phi_ksi_fd", true, in, width, height, depth, hx, hy, hz, equation_alpha, equation_smoothness,
                   equation_data, out, slab);
+}
+
+int f3d_solve_sweep_phi_ksi_edges_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v,
+                                     f3d_devptr flow_w, f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi,
+                                     f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                                     float equation_alpha, float equation_smoothness, float equation_data, f3d_devptr temp_du,
+                                     f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab,
+                                     int keep_below, int keep_above)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep_phi_ksi_edges_fd");
+  const f3d_devptr in[12] = {fx, fy, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi, fz, ft};
+  const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, phi_next, ksi_next};
+  return pair8_fd("f3d_solve_sweep_phi_ksi_edges_fd", true, in, width, height, depth, hx, hy, hz, equation_alpha, equation_smoothness,
+                  equation_data, out, slab, keep_below, keep_above);
 }
 
 }  // extern "C"

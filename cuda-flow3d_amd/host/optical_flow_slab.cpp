@@ -57,11 +57,26 @@ bool OpticalFlowSlab::Initialize(const DataSize4& data_size)
   for (int r : local_ranks_) {
     Local l;
     l.rank = r;
-    for (int i = 0; i < kRoles; ++i) {
+    for (int i = 0; i < kRoles; ++i) l.buf[i] = 0;
+    for (int i = 0; i < kRequiredRoles; ++i) {
       size_t pitch = 0;
       if (!Check(f3d_alloc_pitched(&l.buf[i], &pitch, data_size.width * sizeof(float), rows))) return false;
       if (local_container_.pitch && pitch != local_container_.pitch) return false;
       local_container_.pitch = pitch;
+    }
+    // four more for the frame derivatives the fused launches read (round 4; F3D_FRAME_DERIVATIVES=0 does without): optional -- without
+    // them (no room, another pitch) the fused launches form the derivatives from the frames themselves, same bits
+    if (FrameDerivativesEnabled() && FusedSweepsEnabled()) {
+      bool all = true;
+      for (int i = FDX; i <= FDT && all; ++i) {
+        size_t pitch = 0;
+        all = f3d_alloc_pitched(&l.buf[i], &pitch, data_size.width * sizeof(float), rows) == 0 && pitch == local_container_.pitch;
+      }
+      if (!all)
+        for (int i = FDX; i <= FDT; ++i) {
+          if (l.buf[i]) f3d_free(l.buf[i]);
+          l.buf[i] = 0;
+        }
     }
     locals_.push_back(l);
   }
@@ -381,6 +396,37 @@ bool OpticalFlowSlab::CompleteWeights(Local& l, int lo, int hi, int D, size_t W,
   return run(lo, a_hi) && run(b_lo, hi);
 }
 
+// fx, fy, fz, ft of the level on every plane a fused launch of this level computes a stage 1 on: the frames are valid on the slab
+// widened by `valid_halo` planes (the warp's window), a z derivative needs one plane more on either side, so the derivatives are
+// made on the slab widened by valid_halo - 1 (clipped at the faces of the volume, where the mirror plane is the rank's own)
+bool OpticalFlowSlab::FrameDerivatives(Local& l, int D, size_t W, size_t H, float hx, float hy, float hz, int valid_halo)
+{
+  l.derivatives = false;
+  if (!l.buf[FDX] || !FusedSweepsEnabled() || local_container_.pitch % 256 != 0) return true;
+  const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);
+  if (own.empty() || valid_halo < 1) return true;
+  f3d_slab win;
+  win.z_base = ZBase(D, l.rank);
+  win.z_lo = own.lo - valid_halo <= 0 ? 0 : own.lo - valid_halo + 1;
+  win.z_hi = own.hi + valid_halo >= D ? D : own.hi + valid_halo - 1;
+  if (!Check(f3d_frame_derivatives(l.buf[F0R], l.buf[F1R], W, H, D, hx, hy, hz, l.buf[FDX], l.buf[FDY], l.buf[FDZ], l.buf[FDT], &win)))
+    return false;
+  l.derivatives = true;
+  return true;
+}
+
+bool OpticalFlowSlab::Sweeps(Local& l, bool pair, const Role* in, const Role* out, size_t W, size_t H, int D, float hx, float hy, float hz,
+                             float equation_alpha, const f3d_slab& win)
+{
+  if (pair && l.derivatives)
+    return Check(f3d_solve_sweep2_fd(l.buf[FDX], l.buf[FDY], l.buf[FDZ], l.buf[FDT], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]],
+                                     l.buf[in[1]], l.buf[in[2]], l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[out[0]],
+                                     l.buf[out[1]], l.buf[out[2]], &win));
+  auto* fn = pair ? f3d_solve_sweep2 : f3d_solve_sweep;
+  return Check(fn(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]], l.buf[in[2]], l.buf[PHI], l.buf[KSI],
+                  W, H, D, hx, hy, hz, equation_alpha, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]], &win));
+}
+
 bool OpticalFlowSlab::SweepAndNextWeights(Local& l, const Role (&in)[3], const Role (&out)[3], int sweep_lo, int sweep_hi, int D,
                                           size_t W, size_t H, float hx, float hy, float hz, float equation_alpha,
                                           float equation_smoothness, float equation_data, bool& launched)
@@ -394,10 +440,17 @@ bool OpticalFlowSlab::SweepAndNextWeights(Local& l, const Role (&in)[3], const R
   s.z_lo = sweep_lo + (shrink_lo ? 1 : 0);
   s.z_hi = sweep_hi - (shrink_hi ? 1 : 0);
   if (s.z_hi - s.z_lo < 1) return true;
-  if (!Check(f3d_solve_sweep_phi_ksi_edges(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]],
-                                           l.buf[in[2]], l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha,
-                                           equation_smoothness, equation_data, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]],
-                                           l.buf[PHI2], l.buf[KSI2], &s, shrink_lo ? 1 : 0, shrink_hi ? 1 : 0)))
+  const int status =
+      l.derivatives
+          ? f3d_solve_sweep_phi_ksi_edges_fd(l.buf[FDX], l.buf[FDY], l.buf[FDZ], l.buf[FDT], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]],
+                                             l.buf[in[1]], l.buf[in[2]], l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha,
+                                             equation_smoothness, equation_data, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]], l.buf[PHI2],
+                                             l.buf[KSI2], &s, shrink_lo ? 1 : 0, shrink_hi ? 1 : 0)
+          : f3d_solve_sweep_phi_ksi_edges(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]], l.buf[in[2]],
+                                          l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, equation_smoothness, equation_data,
+                                          l.buf[out[0]], l.buf[out[1]], l.buf[out[2]], l.buf[PHI2], l.buf[KSI2], &s, shrink_lo ? 1 : 0,
+                                          shrink_hi ? 1 : 0);
+  if (!Check(status))
     return false;
   std::swap(l.buf[PHI], l.buf[PHI2]);
   std::swap(l.buf[KSI], l.buf[KSI2]);
@@ -461,9 +514,7 @@ bool OpticalFlowSlab::SweepsOverlapped(Local& l, int D, size_t W, size_t H, int 
   auto stage = [&](size_t s, const f3d_slab& win, bool to_edge) {
     const Role* in = (s % 2 == 0) ? cur : tmp;
     const Role* out = to_edge ? edge : ((s % 2 == 0) ? tmp : cur);
-    auto* fn = stages[s].pair ? f3d_solve_sweep2 : f3d_solve_sweep;
-    return Check(fn(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[in[0]], l.buf[in[1]], l.buf[in[2]], l.buf[PHI],
-                    l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[out[0]], l.buf[out[1]], l.buf[out[2]], &win));
+    return Sweeps(l, stages[s].pair, in, out, W, H, D, hx, hy, hz, equation_alpha, win);
   };
   const size_t last = stages.size() - 1;
   const Role* final_out = (last % 2 == 0) ? tmp : cur;
@@ -772,6 +823,11 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
       }
     }
 
+    // the frame derivatives of the level, where the rank holds containers for them: both frames are valid on the slab widened by
+    // `wide` planes now (the exchange of frame 0, the window of the warp)
+    for (Local& l : locals_)
+      if (!FrameDerivatives(l, D, W, H, hx, hy, hz, wide)) return false;
+
     // solver: outer x (phi/ksi + K sweeps on shrinking windows), increments exchanged once per n_ex outer iterations
     for (Local& l : locals_) {
       l.weights_lo = l.weights_hi = 0;
@@ -813,10 +869,8 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
               return false;
           }
           if (!launched) {
-            auto* fn = stages[st].pair ? f3d_solve_sweep2 : f3d_solve_sweep;
-            if (!Check(fn(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW], l.buf[PHI], l.buf[KSI],
-                          W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV], l.buf[TDW], &sw)))
-              return false;
+            const Role from[3] = {DU, DV, DW}, to[3] = {TDU, TDV, TDW};
+            if (!Sweeps(l, stages[st].pair, from, to, W, H, D, hx, hy, hz, equation_alpha, sw)) return false;
           }
           std::swap(l.buf[DU], l.buf[TDU]);
           std::swap(l.buf[DV], l.buf[TDV]);
@@ -868,14 +922,8 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
                 continue;
               }
             }
-            const int status =
-                pair ? f3d_solve_sweep2(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
-                                        l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
-                                        l.buf[TDW], &sw)
-                     : f3d_solve_sweep(l.buf[F0R], l.buf[F1R], l.buf[FU], l.buf[FV], l.buf[FW], l.buf[DU], l.buf[DV], l.buf[DW],
-                                       l.buf[PHI], l.buf[KSI], W, H, D, hx, hy, hz, equation_alpha, l.buf[TDU], l.buf[TDV],
-                                       l.buf[TDW], &sw);
-            if (!Check(status)) return false;
+            const Role from[3] = {DU, DV, DW}, to[3] = {TDU, TDV, TDW};
+            if (!Sweeps(l, pair, from, to, W, H, D, hx, hy, hz, equation_alpha, sw)) return false;
             std::swap(l.buf[DU], l.buf[TDU]);
             std::swap(l.buf[DV], l.buf[TDV]);
             std::swap(l.buf[DW], l.buf[TDW]);

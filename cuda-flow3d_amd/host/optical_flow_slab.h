@@ -50,14 +50,23 @@ class OpticalFlowSlab : public OpticalFlowBase {
   bool silent = true;
 
  private:
-  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, EDU, EDV, EDW, PHI2, KSI2, kRoles };
+  // FDX .. FDT: the frame derivatives fx, fy, fz, ft of the level on the slab (optional: a rank without room for them runs the
+  // fused launches on the frames, as rounds 1-3 did)
+  enum Role { RAW0, RAW1, F0, F1, F0R, F1R, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, TMP, EDU, EDV, EDW, PHI2, KSI2,
+              kRequiredRoles, FDX = kRequiredRoles, FDY, FDZ, FDT, kRoles };
   struct Local {
     int rank;
     DevicePtr buf[kRoles];
     // planes [weights_lo, weights_hi) of PHI / KSI already hold the weights of the coming outer iteration (written by the
     // fused last sweep of the previous one); empty = none
     int weights_lo = 0, weights_hi = 0;
+    bool derivatives = false;   // FDX .. FDT hold the derivatives of the CURRENT level's frames on every plane a fused launch computes on
   };
+  // the solver launches of one window: two sweeps (fused) or one; sweep + next weights with the edge planes kept.  The fused ones read
+  // the frame derivatives when `l.derivatives` says they are there.
+  bool Sweeps(Local& l, bool pair, const Role* in, const Role* out, size_t W, size_t H, int D, float hx, float hy, float hz,
+              float equation_alpha, const f3d_slab& win);
+  bool FrameDerivatives(Local& l, int D, size_t W, size_t H, float hx, float hy, float hz, int valid_halo);
 
   bool Pyramid(OperationParameters& params);
   int ZBase(int depth, int rank) const { return OwnedPlanes(depth, rank, n_ranks_).lo - halo_; }

@@ -226,6 +226,14 @@ int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_
                                f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
                                float equation_alpha, float equation_smoothness, float equation_data, f3d_devptr temp_du,
                                f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
+/* ... and f3d_solve_sweep_phi_ksi_edges on frame derivatives (the z-slab driver: derivative volumes per slab, computed once per level on
+ * the slab widened by the halo depth minus one) */
+int f3d_solve_sweep_phi_ksi_edges_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz, f3d_devptr ft, f3d_devptr flow_u, f3d_devptr flow_v,
+                                     f3d_devptr flow_w, f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi,
+                                     f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz,
+                                     float equation_alpha, float equation_smoothness, float equation_data, f3d_devptr temp_du,
+                                     f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next,
+                                     const f3d_slab* slab, int keep_below, int keep_above);
 
 /* registration_3d, 12 args: cuda_operation_registration.cpp:110-122; kernel src/kernels/registration_3d.cu:28-82 */
 int f3d_warp(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,

@@ -353,6 +353,17 @@ int f3d_solve_sweep_phi_ksi_fd(f3d_devptr fx, f3d_devptr, f3d_devptr, f3d_devptr
   return f3d_solve_sweep_phi_ksi(it->second.first, it->second.second, u, v, w, du, dv, dw, phi, ksi, width, height, depth, hx, hy, hz, alpha,
                                  eps_s, eps_d, tdu, tdv, tdw, phi_next, ksi_next, slab);
 }
+int f3d_solve_sweep_phi_ksi_edges_fd(f3d_devptr fx, f3d_devptr, f3d_devptr, f3d_devptr, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du,
+                                     f3d_devptr dv, f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth,
+                                     float hx, float hy, float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv,
+                                     f3d_devptr tdw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab, int keep_below,
+                                     int keep_above)
+{
+  auto it = g_frames_of.find(fx);
+  if (it == g_frames_of.end()) return fail("f3d_solve_sweep_phi_ksi_edges_fd: these derivatives were not made by f3d_frame_derivatives");
+  return f3d_solve_sweep_phi_ksi_edges(it->second.first, it->second.second, u, v, w, du, dv, dw, phi, ksi, width, height, depth, hx, hy, hz,
+                                       alpha, eps_s, eps_d, tdu, tdv, tdw, phi_next, ksi_next, slab, keep_below, keep_above);
+}
 int f3d_warp(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, size_t width, size_t height, size_t depth, float hx,
              float hy, float hz, f3d_devptr output, const f3d_slab* slab)
 {
