@@ -320,7 +320,8 @@ def run_single(args):
     # Timed region: HIP events around every launch of the DOMINANT kernel only (the fused pair, kernel id 2; the single
     # sweep when fusion is off).  Events on all 6400 solver launches of a solve cost ~2 % of it; the other two solver kernels
     # are timed in one extra, untimed step afterwards.
-    # kernel ids (include/f3d.h): 0 phi/ksi, 1 one sweep, 2 two fused sweeps, 3 sweep + next phi/ksi fused
+    # kernel ids (include/f3d.h): 0 phi/ksi, 1 one sweep, 2 two fused sweeps, 3 sweep + next phi/ksi fused, 4 three fused sweeps,
+    # 5 two sweeps + next phi/ksi fused (the three-stage launches of the small and mid-size levels)
     dominant = 2 if os.environ.get("F3D_FUSED_SWEEPS", "1") != "0" else 1
     hip.f3d_prof_reset()
     hip.f3d_prof_select(1 << dominant)
@@ -334,12 +335,12 @@ def run_single(args):
     wall = time.perf_counter() - t0
     hip.f3d_prof_enable(0)
     if events and not args.no_extra:
-        hip.f3d_prof_select(0xf & ~(1 << dominant))
+        hip.f3d_prof_select(0x3f & ~(1 << dominant))
         hip.f3d_prof_enable(1)
         flow.compute_resident(silent=True)      # untimed: phi/ksi and the other sweep kernel
         pkg.sync()
         hip.f3d_prof_enable(0)
-    hip.f3d_prof_select(0xf)
+    hip.f3d_prof_select(0x3f)
     extra = args.steps                      # their totals cover one step, the dominant kernel's cover `steps`
 
     def prof(kernel, min_vox):
@@ -354,10 +355,14 @@ def run_single(args):
     pk_ms, pk_n, pk_vox = prof(0, 0)
     sp_ms, sp_n, sp_vox = prof(3, 0)          # last sweep of an outer iteration fused with the next phi/ksi
     spf_ms, spf_n, spf_vox = prof(3, S ** 3)  # ... on the finest level alone
+    t3_ms, t3_n, t3_vox = prof(4, 0)          # three fused sweeps (small and mid-size levels)
+    tp_ms, tp_n, tp_vox = prof(5, 0)          # two sweeps + next phi/ksi (the same levels)
     # the kernels of the extra step ran once, the dominant one `steps` times: put them on the same footing
     pk_ms, pk_n, pk_vox = pk_ms * extra, pk_n * extra, pk_vox * extra
     sp_ms, sp_n, sp_vox = sp_ms * extra, sp_n * extra, sp_vox * extra
     spf_ms, spf_n, spf_vox = spf_ms * extra, spf_n * extra, spf_vox * extra
+    t3_ms, t3_n, t3_vox = t3_ms * extra, t3_n * extra, t3_vox * extra
+    tp_ms, tp_n, tp_vox = tp_ms * extra, tp_n * extra, tp_vox * extra
     if dominant == 2:
         s1_ms, s1_n, s1_vox = s1_ms * extra, s1_n * extra, s1_vox * extra
         f1_ms, f1_n, f1_vox = f1_ms * extra, f1_n * extra, f1_vox * extra
@@ -387,8 +392,8 @@ def run_single(args):
     achieved = gbs(dom_b, dom_vox, dom_ms)
     finest = gbs(dom_b, fin_vox, fin_ms)
     # every solver launch priced at its algorithmic bytes: 52 B per voxel-sweep, 40 B per voxel of phi/ksi
-    all_sweeps = gbs(1.0, SWEEP_BYTES_PER_VOXEL * (s1_vox + 2 * s2_vox + sp_vox) + PHI_KSI_BYTES_PER_VOXEL * (sp_vox + pk_vox),
-                     s1_ms + s2_ms + sp_ms + pk_ms)
+    all_sweeps = gbs(1.0, SWEEP_BYTES_PER_VOXEL * (s1_vox + 2 * s2_vox + sp_vox + 3 * t3_vox + 2 * tp_vox) +
+                     PHI_KSI_BYTES_PER_VOXEL * (sp_vox + pk_vox + tp_vox), s1_ms + s2_ms + sp_ms + pk_ms + t3_ms + tp_ms)
     ms_per_step = wall / args.steps * 1e3
     whole = TOTAL_BYTES.get(S)
     out = {
@@ -426,6 +431,12 @@ def run_single(args):
                                                "frac": round(gbs(SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, spf_vox, spf_ms) / HBM_PEAK_GBS, 4),
                                                "launches": spf_n,
                                                "avg_launch_us": round(spf_ms / spf_n * 1e3, 3) if spf_n else None}},
+            "three_stage": {"kernel": "k_tri (three sweeps: f3d_solve_sweep3; two sweeps + next phi/ksi: f3d_solve_sweep2_phi_ksi) on the "
+                                      "levels up to ~144^3",
+                            "three_sweeps": {"achieved": round(gbs(3 * SWEEP_BYTES_PER_VOXEL, t3_vox, t3_ms), 1), "launches": t3_n,
+                                             "avg_launch_us": round(t3_ms / t3_n * 1e3, 3) if t3_n else None},
+                            "two_sweeps_phi_ksi": {"achieved": round(gbs(2 * SWEEP_BYTES_PER_VOXEL + PHI_KSI_BYTES_PER_VOXEL, tp_vox, tp_ms), 1),
+                                                   "launches": tp_n, "avg_launch_us": round(tp_ms / tp_n * 1e3, 3) if tp_n else None}},
             "single_sweep": {"kernel": "k_sweep6", "achieved": round(gbs(SWEEP_BYTES_PER_VOXEL, s1_vox, s1_ms), 1),
                              "launches": s1_n},
             "phi_ksi": {"kernel": "k_phiksi6", "achieved": round(gbs(PHI_KSI_BYTES_PER_VOXEL, pk_vox, pk_ms), 1),

@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_frame_derivatives(const float* __restri
 }
 
 #include "f3d_solve_pair8.h"
+#include "f3d_solve_tri.h"
 
 // k_sweep6 (SWEEP) or k_phiksi6: 64 x 8 tiles, z cut into chunks so that even a coarse pyramid level spreads over all CUs
 template <bool SWEEP>
@@ -1432,6 +1433,60 @@ void launch_sweep2(const SolveArgs& a, const F3dGeo& g)
   if (ty == 8) launch_sweep2_ty<8>(a, g, want, t.zchunk, t.xcd_remap);
   else if (ty == 5) launch_sweep2_ty<5>(a, g, want, t.zchunk, t.xcd_remap);
   else launch_sweep2_ty<9>(a, g, want, t.zchunk, t.xcd_remap);
+}
+
+
+// 4 or 7 owned rows per tile of k_tri (9 or 12 waves per workgroup), whichever the round model prices lower for this level; a 9-wave
+// step is taken at 80 % of a 12-wave one, as for k_pair8.  F3D_TRI_TY=4 / 7 pins one (read per call: the tests force both)
+int tri_rows(const F3dGeo& g)
+{
+  const char* forced_env = std::getenv("F3D_TRI_TY");
+  const int forced = forced_env ? std::atoi(forced_env) : 0;
+  if (forced == 4 || forced == 7) return forced;
+  static const long step4 = std::getenv("F3D_TRI_STEP4") ? std::atol(std::getenv("F3D_TRI_STEP4")) : 80;
+  const int planes = g.z_hi - g.z_lo;
+  const long c4 = tri_plan_dims(g.W, g.H, planes, 4, max_planes_per_chunk(g)).cost * step4;
+  const long c7 = tri_plan_dims(g.W, g.H, planes, 7, max_planes_per_chunk(g)).cost * 100;
+  return c4 < c7 ? 4 : 7;
+}
+
+// the two three-stage launches (f3d_solve_sweep3, f3d_solve_sweep2_phi_ksi)
+int tri_launch(const char* who, bool with_weights, const f3d_devptr (&in)[10], size_t width, size_t height, size_t depth, float hx, float hy,
+               float hz, float alpha, float eps_s, float eps_d, const f3d_devptr (&out)[5], const f3d_slab* slab)
+{
+  F3dGeo g;
+  if (!f3d::make_geo(&g, width, height, depth, slab, who)) return 1;
+  if (g.W < 2 || g.H < 2 || g.D < 2) return f3d::fail("%s: every dimension must be at least 2", who);
+  if (!pair_weights_finite(hx, hy, hz, alpha))
+    return f3d::fail("%s: alpha / h^2 must be finite and not negative (alpha %g, h %g %g %g)", who, alpha, hx, hy, hz);
+  if (g.pitch % kLanes != 0) return f3d::fail("%s: the container pitch must be a multiple of 256 bytes (f3d_alloc_pitched gives that)", who);
+  for (int i = 0; i < (with_weights ? 5 : 3); ++i)
+    for (int k = 0; k < 10; ++k)
+      if (out[i] == in[k]) return f3d::fail("%s: an output buffer is also an input (other tiles still read it)", who);
+  if (g.z_lo == g.z_hi) return 0;
+  if (!slab_reach_ok(g, 3, who)) return 1;
+  PairArgs a = {};
+  static const int plain_division = std::getenv("F3D_UDIV") && std::atoi(std::getenv("F3D_UDIV")) == 0;
+  a.plain_division = plain_division;
+  for (int i = 0; i < 10; ++i) a.in[i] = f3d_ptr<const float>(in[i]);
+  for (int i = 0; i < 5; ++i) a.out[i] = f3d_ptr<float>(out[i]);
+  a.hx = hx; a.hy = hy; a.hz = hz;
+  a.alpha = alpha;
+  a.eps_s = eps_s;
+  a.eps_d = eps_d;
+  const int kid = with_weights ? F3D_K_SWEEP2_PHI_KSI : F3D_K_SWEEP3;
+  f3d::prof_begin(kid, static_cast<size_t>(g.W) * g.H * (g.z_hi - g.z_lo));
+  const int rows = tri_rows(g);
+  if (with_weights) {
+    if (rows == 4) launch_tri<TRI_SSP, 4>(a, g, tuning().zchunk, tuning().xcd_remap);
+    else launch_tri<TRI_SSP, 7>(a, g, tuning().zchunk, tuning().xcd_remap);
+  } else {
+    if (rows == 4) launch_tri<TRI_SSS, 4>(a, g, tuning().zchunk, tuning().xcd_remap);
+    else launch_tri<TRI_SSS, 7>(a, g, tuning().zchunk, tuning().xcd_remap);
+  }
+  f3d::prof_end(kid);
+  F3D_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -1772,6 +1827,30 @@ int f3d_solve_sweep_phi_ksi_edges_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz
   const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, phi_next, ksi_next};
   return pair8_fd("f3d_solve_sweep_phi_ksi_edges_fd", true, in, width, height, depth, hx, hy, hz, equation_alpha, equation_smoothness,
                   equation_data, out, slab, keep_below, keep_above);
+}
+
+int f3d_solve_sweep3(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                     f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                     size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, f3d_devptr temp_du,
+                     f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep3");
+  const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
+  const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, 0, 0};
+  return tri_launch("f3d_solve_sweep3", false, in, width, height, depth, hx, hy, hz, equation_alpha, 0.f, 0.f, out, slab);
+}
+
+int f3d_solve_sweep2_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                             f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                             size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, float equation_smoothness,
+                             float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv, f3d_devptr temp_dw, f3d_devptr phi_next,
+                             f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  F3D_REQUIRE_READY("f3d_solve_sweep2_phi_ksi");
+  const f3d_devptr in[10] = {frame_0, frame_1, flow_u, flow_v, flow_w, flow_du, flow_dv, flow_dw, phi, ksi};
+  const f3d_devptr out[5] = {temp_du, temp_dv, temp_dw, phi_next, ksi_next};
+  return tri_launch("f3d_solve_sweep2_phi_ksi", true, in, width, height, depth, hx, hy, hz, equation_alpha, equation_smoothness,
+                    equation_data, out, slab);
 }
 
 }  // extern "C"

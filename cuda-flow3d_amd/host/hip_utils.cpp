@@ -75,3 +75,19 @@ bool FrameDerivativesEnabled()
   }();
   return on;
 }
+
+bool ThreeStageLaunchesPay(size_t width, size_t height, size_t depth)
+{
+  // The three-stage launches (f3d_solve_sweep3, f3d_solve_sweep2_phi_ksi) win where a launch is bound by its own skeleton, i.e. on
+  // small and mid-size levels (profiles/r04_three_stage_*.txt); above the threshold the 12-row two-stage tiles at four waves per SIMD
+  // are the faster cut.  F3D_TRI=0 switches them off, F3D_TRI_MAX_VOXELS moves the threshold (read once).
+  static const bool on = [] {
+    const char* e = std::getenv("F3D_TRI");
+    return !(e && e[0] == '0');
+  }();
+  static const double max_voxels = [] {
+    const char* e = std::getenv("F3D_TRI_MAX_VOXELS");
+    return e ? std::atof(e) : 3.0e6;
+  }();
+  return on && static_cast<double>(width) * static_cast<double>(height) * static_cast<double>(depth) <= max_voxels;
+}

@@ -44,5 +44,7 @@ bool FusedPhiKsiEnabled();
 // default: measured on the MI355X it trades a seventh of the stage-1 arithmetic for a fifth more bytes through the loader and
 // comes out even; the launchers stay tested because they need 36 registers fewer.
 bool FrameDerivativesEnabled();
+// small and mid-size levels: an outer iteration as (sweep, sweep, sweep) + (sweep, sweep, next phi/ksi) -- two launches instead of three
+bool ThreeStageLaunchesPay(size_t width, size_t height, size_t depth);
 
 #endif

@@ -497,23 +497,57 @@ void CudaOperationSolve::Execute(OperationParameters& params)
 
   const size_t w = data_size.width, h = data_size.height, d = data_size.depth;
   // Launch schedule of one outer iteration (the same bit pattern whichever way it is cut):
-  //   phi/ksi, then the sweeps in fused pairs (f3d_solve_sweep2: the intermediate increment stays on chip, one buffer swap per
-  //   pair); an odd count ends with a single sweep, and when another outer iteration follows that sweep and the phi/ksi of the
-  //   NEXT iteration are one launch (f3d_solve_sweep_phi_ksi) writing into the second weight pair.  Defaults (5 sweeps): 3
-  //   launches per outer iteration instead of the reference's 6.
-  const bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && inner_iterations_count % 2 == 1 &&
-                            outer_iterations_count > 1 && dev_container_size_.pitch % 256 == 0 && EnsureWeightScratch();
+  //   phi/ksi (first outer iteration of a level only), then the sweeps in fused groups -- three per launch on small and mid-size
+  //   levels (f3d_solve_sweep3), two per launch elsewhere (f3d_solve_sweep2) -- with one buffer swap per launch; when another outer
+  //   iteration follows, the last launch also computes the phi/ksi of the NEXT iteration into the second weight pair
+  //   (f3d_solve_sweep2_phi_ksi behind two sweeps, f3d_solve_sweep_phi_ksi behind one).  Defaults (5 sweeps): 2 launches per outer
+  //   iteration on levels up to ~144^3, 3 above, instead of the reference's 6.
+  const bool fuse_weights = FusedSweepsEnabled() && FusedPhiKsiEnabled() && outer_iterations_count > 1 &&
+                            dev_container_size_.pitch % 256 == 0 && EnsureWeightScratch();
+  // Small and mid-size levels take the three-stage launches (k_tri: no z-slab windows yet, frames not derivatives): with them the
+  // last launch of an outer iteration that is not the level's last can carry the next weights behind TWO sweeps, so the default five
+  // sweeps are (S, S, S) + (S, S, P); without them it carries them behind one, and only an odd count ends that way.
+  const bool tri = FusedSweepsEnabled() && slab_ == nullptr && dev_container_size_.pitch % 256 == 0 && inner_iterations_count >= 2 &&
+                   ThreeStageLaunchesPay(w, h, d);
+  // How the `inner` sweeps of an outer iteration are cut into launches: groups of 3 / 2 / 1 sweeps, the last group taking the next
+  // weights along when another outer iteration follows (`more`) and the group is 2 (three-stage) or 1 sweeps.
+  auto next_group = [&](size_t remaining, bool more) -> size_t {
+    if (!FusedSweepsEnabled()) return 1;
+    const bool weights_wanted = more && fuse_weights;
+    if (tri) {
+      if (weights_wanted) {
+        if (remaining == 2) return 2;                 // (S, S, P)
+        if (remaining == 3) return 1;                 // S, then (S, S, P)
+        if (remaining == 4) return 2;                 // (S, S), then (S, S, P)
+      }
+      if (remaining >= 3) return 3;
+    }
+    if (weights_wanted && remaining == 3 && !tri) return 2;   // (S, S), then (S, P)
+    return remaining >= 2 ? 2 : 1;
+  };
+  // the weights of the last outer iteration must end in the caller's dev_phi / dev_ksi (as in the reference): every outer iteration
+  // whose last group carries the next weights hands over to the other pair once; count the hand-overs and start on the right side
+  auto carries_weights = [&](size_t group, size_t remaining_after, bool more) {
+    return more && fuse_weights && remaining_after == 0 && ((tri && group == 2) || group == 1);
+  };
+  size_t hand_overs = 0;
+  for (size_t i = 0; i + 1 < outer_iterations_count; ++i) {
+    size_t remaining = inner_iterations_count, group = 0;
+    while (remaining > 0) {
+      group = next_group(remaining, true);
+      remaining -= group;
+    }
+    if (carries_weights(group, 0, true)) ++hand_overs;
+  }
   DevicePtr phi_cur = dev_phi, ksi_cur = dev_ksi, phi_nxt = phi_alt_, ksi_nxt = ksi_alt_;
-  // every outer iteration but the last hands the weights to the other pair: with an odd number of hand-overs start in the
-  // operator's pair, so that the weights of the LAST outer iteration end in the caller's dev_phi / dev_ksi as in the reference
-  if (fuse_weights && (outer_iterations_count - 1) % 2 == 1) {
+  if (hand_overs % 2 == 1) {
     std::swap(phi_cur, phi_nxt);
     std::swap(ksi_cur, ksi_nxt);
   }
   bool weights_ready = false;
-  // The frame derivatives fx, fy, fz, ft depend on the two frames only: computed once here, read by every fused launch of the level
-  // instead of the frames (the reference recomputes them for every voxel in each of its 240 launches per level).
-  const bool on_derivatives = FusedSweepsEnabled() && FrameDerivativesEnabled() && slab_ == nullptr && inner_iterations_count >= 2 &&
+  // The frame derivatives fx, fy, fz, ft depend on the two frames only: computed once here, read by every two-stage fused launch of the
+  // level instead of the frames (the reference recomputes them for every voxel in each of its 240 launches per level).
+  const bool on_derivatives = !tri && FusedSweepsEnabled() && FrameDerivativesEnabled() && slab_ == nullptr && inner_iterations_count >= 2 &&
                               dev_container_size_.pitch % 256 == 0 && EnsureDerivativeScratch() &&
                               !CheckDeviceError(f3d_frame_derivatives(dev_frame_0, dev_frame_1, w, h, d, hx, hy, hz, fder_[0], fder_[1],
                                                                       fder_[2], fder_[3], nullptr));
@@ -523,14 +557,22 @@ void CudaOperationSolve::Execute(OperationParameters& params)
                                      hx, hy, hz, equation_smoothness, equation_data, phi_cur, ksi_cur, slab_)))
       return;
     weights_ready = false;
+    const bool more = i + 1 < outer_iterations_count;
     for (size_t j = 0; j < inner_iterations_count;) {
-      const bool pair = FusedSweepsEnabled() && j + 2 <= inner_iterations_count;
-      const bool with_weights = !pair && fuse_weights && j + 1 == inner_iterations_count && i + 1 < outer_iterations_count;
+      const size_t group = next_group(inner_iterations_count - j, more);
+      const bool with_weights = carries_weights(group, inner_iterations_count - j - group, more);
       int status;
-      if (pair && on_derivatives)
+      if (group == 3)
+        status = f3d_solve_sweep3(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur, ksi_cur,
+                                  w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
+      else if (group == 2 && with_weights)
+        status = f3d_solve_sweep2_phi_ksi(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur,
+                                          ksi_cur, w, h, d, hx, hy, hz, equation_alpha, equation_smoothness, equation_data, *tdu_ptr,
+                                          *tdv_ptr, *tdw_ptr, phi_nxt, ksi_nxt, slab_);
+      else if (group == 2 && on_derivatives)
         status = f3d_solve_sweep2_fd(fder_[0], fder_[1], fder_[2], fder_[3], dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr,
                                      *dw_ptr, phi_cur, ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
-      else if (pair)
+      else if (group == 2)
         status = f3d_solve_sweep2(dev_frame_0, dev_frame_1, dev_flow_u, dev_flow_v, dev_flow_w, *du_ptr, *dv_ptr, *dw_ptr, phi_cur,
                                   ksi_cur, w, h, d, hx, hy, hz, equation_alpha, *tdu_ptr, *tdv_ptr, *tdw_ptr, slab_);
       else if (with_weights && on_derivatives)
@@ -553,7 +595,7 @@ void CudaOperationSolve::Execute(OperationParameters& params)
         std::swap(ksi_cur, ksi_nxt);
         weights_ready = true;
       }
-      j += pair ? 2 : 1;
+      j += group;
     }
     if (!silent) {
       CheckDeviceError(f3d_stream_sync());

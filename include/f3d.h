@@ -209,6 +209,26 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
                                   f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab,
                                   int keep_below, int keep_above);
 
+/* THREE consecutive solve_3d sweeps in one launch (k_tri, csrc/f3d_solve_tri.h): temp_d* receive what three f3d_solve_sweep calls with
+ * the buffer swaps in between would leave, bit for bit.  Replaces three iterations of the inner loop of
+ * cuda_operation_solve.cpp:222-255; the caller swaps ONCE.  For small and mid-size levels, where a launch is bound by its own
+ * skeleton and a third stage costs a fifth of it (profiles/r04_three_stage_probe.txt); the fused-entry restriction on alpha / h^2
+ * holds.  A slab window [z_lo, z_hi) needs planes z_lo-3 .. z_hi+2 of every input inside the container; the container pitch must be a
+ * multiple of 256 bytes; no output may be one of the inputs. */
+int f3d_solve_sweep3(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                     f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                     size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, f3d_devptr temp_du,
+                     f3d_devptr temp_dv, f3d_devptr temp_dw, const f3d_slab* slab);
+/* The last TWO sweeps of an outer iteration and compute_phi_ksi_3d of the next one in one launch: temp_d* receive the second sweep,
+ * phi_next / ksi_next what f3d_phi_ksi would then compute from temp_d* (cuda_operation_solve.cpp:246-252 twice + :215-221 of the next
+ * i).  With the default five sweeps an outer iteration is f3d_solve_sweep3 + f3d_solve_sweep2_phi_ksi: two launches for the
+ * reference's six.  Same conditions as f3d_solve_sweep3; phi_next / ksi_next must be buffers of their own. */
+int f3d_solve_sweep2_phi_ksi(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
+                             f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
+                             size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha,
+                             float equation_smoothness, float equation_data, f3d_devptr temp_du, f3d_devptr temp_dv,
+                             f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab);
+
 /* The frame derivatives of a level, once: fx, fy, fz = (((F0[+1] - F0[-1]) + F1[+1]) - F1[-1]) / (4 h) and ft = F1 - F0, exactly as
  * compute_phi_ksi_3d and solve_3d form them for every voxel in every launch (src/kernels/solve_3d.cu:205-215, :438-448).  They depend
  * on the two frames of the level only; the _fd launchers below read them instead of the frames.  A slab window [z_lo, z_hi) needs planes
@@ -313,7 +333,8 @@ int f3d_range_pop(void);
 
 /* ---- per-kernel timing (HIP events on the library stream), used by bench.py's roofline leg ----------- */
 
-enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_SWEEP_PHI_KSI = 3, F3D_K_COUNT = 4 };
+enum { F3D_K_PHI_KSI = 0, F3D_K_SWEEP = 1, F3D_K_SWEEP2 = 2, F3D_K_SWEEP_PHI_KSI = 3, F3D_K_SWEEP3 = 4, F3D_K_SWEEP2_PHI_KSI = 5,
+       F3D_K_COUNT = 6 };
 /* enable = 1 brackets every launch of the solver kernels (phi/ksi, one sweep, two fused sweeps) with events on the library stream */
 int f3d_prof_enable(int enable);
 int f3d_prof_reset(void);

@@ -271,6 +271,51 @@ int f3d_solve_sweep2(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f
                   P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, P<float>(tdu), P<float>(tdv), P<float>(tdw), &o.g);
   return 0;
 }
+int f3d_solve_sweep3(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv, f3d_devptr dw,
+                     f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz, float alpha,
+                     f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw, const f3d_slab* slab)
+{
+  Geo o;
+  if (!make_geo(&o, width, height, depth, slab, "f3d_solve_sweep3")) return 1;
+  if (o.g.z_lo == o.g.z_hi) return 0;
+  std::vector<float> a = scratch(), b = scratch(), c = scratch(), d = scratch(), e = scratch(), f = scratch();
+  const orc_geom wide2 = widen(o, 2), wide1 = widen(o, 1);  // the first sweep on two planes more on either side, the second on one
+  orc_solve_sweep(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), P<float>(du), P<float>(dv), P<float>(dw),
+                  P<float>(phi), P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, a.data(), b.data(), c.data(), &wide2);
+  orc_solve_sweep(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), a.data(), b.data(), c.data(), P<float>(phi),
+                  P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, d.data(), e.data(), f.data(), &wide1);
+  orc_solve_sweep(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), d.data(), e.data(), f.data(), P<float>(phi),
+                  P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, P<float>(tdu), P<float>(tdv), P<float>(tdw), &o.g);
+  return 0;
+}
+int f3d_solve_sweep2_phi_ksi(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
+                             f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy,
+                             float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw,
+                             f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab)
+{
+  Geo o;
+  if (!make_geo(&o, width, height, depth, slab, "f3d_solve_sweep2_phi_ksi")) return 1;
+  if (phi_next == phi || ksi_next == ksi || phi_next == ksi || ksi_next == phi)
+    return fail("f3d_solve_sweep2_phi_ksi: phi_next / ksi_next must not alias phi / ksi");
+  if (o.g.z_lo == o.g.z_hi) return 0;
+  std::vector<float> a = scratch(), b = scratch(), c = scratch(), d = scratch(), e = scratch(), f = scratch();
+  const orc_geom wide2 = widen(o, 2), wide1 = widen(o, 1);
+  orc_solve_sweep(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), P<float>(du), P<float>(dv), P<float>(dw),
+                  P<float>(phi), P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, a.data(), b.data(), c.data(), &wide2);
+  orc_solve_sweep(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), a.data(), b.data(), c.data(), P<float>(phi),
+                  P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, d.data(), e.data(), f.data(), &wide1);
+  orc_phi_ksi(P<float>(f0), P<float>(f1), P<float>(u), P<float>(v), P<float>(w), d.data(), e.data(), f.data(), o.W, o.H, o.D, hx, hy, hz,
+              eps_s, eps_d, P<float>(phi_next), P<float>(ksi_next), &o.g);
+  const size_t plane = static_cast<size_t>(o.g.Hc) * o.g.pitch_f;
+  float* outs[3] = {P<float>(tdu), P<float>(tdv), P<float>(tdw)};
+  const float* ins[3] = {d.data(), e.data(), f.data()};
+  for (int k = 0; k < 3; ++k)
+    for (int z = o.g.z_lo; z < o.g.z_hi; ++z)
+      for (int y = 0; y < o.H; ++y)
+        std::memcpy(outs[k] + (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f,
+                    ins[k] + (z - o.g.z_base) * plane + static_cast<size_t>(y) * o.g.pitch_f, o.W * sizeof(float));
+  return 0;
+}
 int f3d_solve_sweep_phi_ksi_edges(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv,
                                   f3d_devptr dw, f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx,
                                   float hy, float hz, float alpha, float eps_s, float eps_d, f3d_devptr tdu, f3d_devptr tdv,

@@ -352,6 +352,123 @@ def test_two_fused_sweeps(f3d, oracle, dims, cdims, h):
         dev.close()
 
 
+# widths around the edges of k_tri's tiles (64 lanes, 56 owned columns, tile column t > 0 starts at 56 t - 4), rows around its 4- and
+# 7-row tiles, depths from 2 planes (every plane a face) up
+TRI_CASES = CASES + BIG_CASES + [
+    ((56, 7, 6), (64, 8, 6)), ((57, 14, 5), (64, 16, 6)), ((60, 9, 4), (64, 12, 4)), ((61, 3, 3), (64, 4, 4)),
+    ((112, 8, 5), (128, 8, 5)), ((113, 11, 4), (128, 12, 4)), ((116, 5, 7), (128, 8, 8)), ((120, 29, 3), (128, 32, 4)),
+    ((168, 6, 2), (192, 8, 2)), ((24, 24, 24), (128, 128, 128)), ((18, 18, 18), (64, 20, 20)), ((100, 66, 17), (128, 70, 20)),
+]
+
+
+@pytest.mark.parametrize("ty", ["4", "7", None])
+@pytest.mark.parametrize("dims,cdims", TRI_CASES)
+def test_three_stage_launches(f3d, oracle, monkeypatch, dims, cdims, ty):
+    """f3d_solve_sweep3 = three f3d_solve_sweep calls with the swaps in between, and f3d_solve_sweep2_phi_ksi = two sweeps followed by
+    f3d_phi_ksi on their result -- bit for bit, against the oracle's separate passes.  k_tri computes the three columns either side of a
+    tile's 56 owned columns and the two rows above and below its owned rows redundantly; widths and heights around those edges, both
+    tile heights (F3D_TRI_TY) and the launcher's own choice."""
+    if ty:
+        monkeypatch.setenv("F3D_TRI_TY", ty)
+    else:
+        monkeypatch.delenv("F3D_TRI_TY", raising=False)
+    W, H, D = dims
+    for h in SPACINGS:
+        rng = np.random.default_rng(hash((dims, h, 33)) % 2**32)
+        arrs = solver_inputs(rng, dims, cdims)
+        alpha, eps_s, eps_d = 7.5, 0.001, 0.002
+        phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, eps_s, eps_d)
+        s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, alpha)
+        s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, alpha)
+        s3 = oracle.solve_sweep(*arrs[:5], *s2, phi_o, ksi_o, dims, h, alpha)
+        phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s2, dims, h, eps_s, eps_d)
+        dev = Dev(f3d, cdims)
+        try:
+            ptr = [dev.put(a) for a in arrs]
+            phi, ksi = dev.put(phi_o), dev.put(ksi_o)
+            outs = [dev.out() for _ in range(5)]
+            f3d.check(f3d.hip().f3d_solve_sweep3(*ptr, phi, ksi, W, H, D, *h, alpha, *outs[:3], None))
+            for name, g, e in zip(("du", "dv", "dw"), outs, s3):
+                got = dev.get(g)[:D, :H, :W]
+                bad = np.argwhere(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))
+                assert len(bad) == 0, (f"three sweeps, {name}, h {h}: {len(bad)} voxels differ; first (z, y, x) {bad[:6].tolist()}, "
+                                       f"x range {bad[:, 2].min()}..{bad[:, 2].max()}, y {bad[:, 1].min()}..{bad[:, 1].max()}, "
+                                       f"z {bad[:, 0].min()}..{bad[:, 0].max()}")
+            outs = [dev.out() for _ in range(5)]
+            f3d.check(f3d.hip().f3d_solve_sweep2_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs, None))
+            for name, g, e in zip(("du", "dv", "dw", "phi", "ksi"), outs, list(s2) + [phi_n, ksi_n]):
+                got = dev.get(g)[:D, :H, :W]
+                bad = np.argwhere(got.view(np.uint32) != np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))
+                assert len(bad) == 0, (f"two sweeps + phi/ksi, {name}, h {h}: {len(bad)} voxels differ; first (z, y, x) {bad[:6].tolist()}, "
+                                       f"x range {bad[:, 2].min()}..{bad[:, 2].max()}, y {bad[:, 1].min()}..{bad[:, 1].max()}, "
+                                       f"z {bad[:, 0].min()}..{bad[:, 0].max()}")
+            # an output that is also an input is refused (other tiles would still be reading it)
+            assert f3d.hip().f3d_solve_sweep3(*ptr, phi, ksi, W, H, D, *h, alpha, ptr[5], *outs[1:3], None) != 0
+            assert f3d.hip().f3d_solve_sweep2_phi_ksi(*ptr, phi, ksi, W, H, D, *h, alpha, eps_s, eps_d, *outs[:3], phi, outs[4], None) != 0
+        finally:
+            dev.close()
+
+
+@pytest.mark.parametrize("dims,cdims", [CASES[0], CASES[2], CASES[4], BIG_CASES[0], ((113, 11, 14), (128, 12, 16))])
+@pytest.mark.parametrize("zchunk", ["1", "2", "5", None])
+def test_three_stage_launches_on_slab_windows_and_forced_chunks(f3d, oracle, monkeypatch, dims, cdims, zchunk):
+    """k_tri on a z window [z_lo, z_hi) with three halo planes either side inside the container, and with the z-chunk pinned (one
+    plane per chunk: every chunk is all prologue and tail; F3D_ZCHUNK is read once per process, so the pinned cases run in a child)"""
+    rng = np.random.default_rng(17)
+    W, H, D = dims
+    h = (1.3, 0.9, 2.0)
+    arrs = solver_inputs(rng, dims, cdims)
+    phi_o, ksi_o = oracle.phi_ksi(*arrs, dims, h, 0.001, 0.001)
+    s1 = oracle.solve_sweep(*arrs, phi_o, ksi_o, dims, h, 7.5)
+    s2 = oracle.solve_sweep(*arrs[:5], *s1, phi_o, ksi_o, dims, h, 7.5)
+    s3 = oracle.solve_sweep(*arrs[:5], *s2, phi_o, ksi_o, dims, h, 7.5)
+    phi_n, ksi_n = oracle.phi_ksi(*arrs[:5], *s2, dims, h, 0.001, 0.001)
+    if zchunk is not None:
+        # the tuning switches are read once per process: run this case in a child process that pins the chunk
+        import pickle, subprocess, sys, tempfile, os
+        with tempfile.TemporaryDirectory() as tmp:
+            blob = os.path.join(tmp, "case.pkl")
+            pickle.dump(dict(arrs=arrs, phi=phi_o, ksi=ksi_o, dims=dims, cdims=cdims, h=h, s3=s3, s2=s2, phi_n=phi_n, ksi_n=ksi_n), open(blob, "wb"))
+            code = ("import importlib, pickle, sys, numpy as np\n"
+                    f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+                    f"sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
+                    "f3d = importlib.import_module('cuda-flow3d_amd')\n"
+                    "from test_gpu_kernels import Dev\n"
+                    f"c = pickle.load(open({blob!r}, 'rb'))\n"
+                    "W, H, D = c['dims']; dev = Dev(f3d, c['cdims'])\n"
+                    "ptr = [dev.put(a) for a in c['arrs']]; phi, ksi = dev.put(c['phi']), dev.put(c['ksi'])\n"
+                    "outs = [dev.out() for _ in range(5)]\n"
+                    "f3d.check(f3d.hip().f3d_solve_sweep3(*ptr, phi, ksi, W, H, D, *c['h'], 7.5, *outs[:3], None))\n"
+                    "same = lambda g, e: np.array_equal(np.ascontiguousarray(dev.get(g)[:D, :H, :W]).view(np.uint32), np.ascontiguousarray(e[:D, :H, :W]).view(np.uint32))\n"
+                    "assert all(same(g, e) for g, e in zip(outs, c['s3'])), 'three sweeps'\n"
+                    "outs = [dev.out() for _ in range(5)]\n"
+                    "f3d.check(f3d.hip().f3d_solve_sweep2_phi_ksi(*ptr, phi, ksi, W, H, D, *c['h'], 7.5, 0.001, 0.001, *outs, None))\n"
+                    "assert all(same(g, e) for g, e in zip(outs, list(c['s2']) + [c['phi_n'], c['ksi_n']])), 'two sweeps + phi/ksi'\n"
+                    "dev.close(); print('ok')\n")
+            out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, F3D_ZCHUNK=zchunk), capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+        return
+    z_lo, z_hi = (1, D - 1) if D < 10 else (3, D - 2)
+    z_base = max(0, z_lo - 3)
+    top = min(D, z_hi + 3)
+    planes = top - z_base
+    sub = lambda a: np.ascontiguousarray(a[z_base:top])
+    dev = Dev(f3d, (cdims[0], cdims[1], planes))
+    try:
+        ptr = [dev.put(sub(a)) for a in arrs] + [dev.put(sub(phi_o)), dev.put(sub(ksi_o))]
+        slab = f3d.Slab(z_base, z_lo, z_hi)
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(f3d.hip().f3d_solve_sweep3(*ptr, W, H, D, *h, 7.5, *outs[:3], C.byref(slab)))
+        for g, e in zip(outs, s3):
+            assert bit_same(dev.get(g)[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+        outs = [dev.out() for _ in range(5)]
+        f3d.check(f3d.hip().f3d_solve_sweep2_phi_ksi(*ptr, W, H, D, *h, 7.5, 0.001, 0.001, *outs, C.byref(slab)))
+        for g, e in zip(outs, list(s2) + [phi_n, ksi_n]):
+            assert bit_same(dev.get(g)[z_lo - z_base:z_hi - z_base, :H, :W], e[z_lo:z_hi, :H, :W])
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("dims,cdims", CASES[:5] + BIG_CASES[:1])
 def test_two_fused_sweeps_slab_window(f3d, oracle, dims, cdims):
     """Slab launch of the fused pair: window [z_lo, z_hi) with two halo planes on either side inside the container."""

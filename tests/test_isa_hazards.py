@@ -73,14 +73,23 @@ def test_pair8_loader_waits_barriers_and_scratch(tmp_path):
     assert tool.pair8_per_plane(12, 0) == 45 and tool.pair8_per_plane(8, 0) == 34 and tool.pair8_per_plane(4, 0) == 23
     assert tool.pair8_per_plane(12, 1) == 32 and tool.pair8_centre_per_plane(12, 1) == 22 and tool.pair8_centre_per_plane(12, 0) == 0
 
+    # k_tri (three stages per launch, csrc/f3d_solve_tri.h): the same loader idiom, so the same rules -- every instantiation ships
+    report3, scratch3 = tool.run_tri(asm)
+    assert {tool.tri_params(name) for name in report3} == {(mode, ty) for mode in (0, 1) for ty in (4, 7)}, list(report3)
+    for name, bad in report3.items():
+        assert not bad, f"{name}: {bad[:5]}"
+    assert len(scratch3) == 4 and all(size == 0 for size in scratch3.values()), scratch3
+    assert tool.tri_per_plane(4) == 30 and tool.tri_per_plane(7) == 40
+
     # the mutant: the same sources with the steady-state wait one short
     src_dir = os.path.join(ROOT, "cuda-flow3d_amd", "csrc")
     for f in os.listdir(src_dir):
         shutil.copy(os.path.join(src_dir, f), tmp_path / f)
-    header = tmp_path / "f3d_solve_pair8.h"
-    text = header.read_text()
-    assert text.count('"n"(L::kPerPlane)') == 1
-    header.write_text(text.replace('"n"(L::kPerPlane)', '"n"(L::kPerPlane - 1)'))
+    for name in ("f3d_solve_pair8.h", "f3d_solve_tri.h"):
+        header = tmp_path / name
+        text = header.read_text()
+        assert text.count('"n"(L::kPerPlane)') == 1
+        header.write_text(text.replace('"n"(L::kPerPlane)', '"n"(L::kPerPlane - 1)'))
     import subprocess
     flags = [f if not f.startswith("-I" + src_dir) else "-I" + str(tmp_path) for f in tool.FLAGS]
     out = tmp_path / "mutant.s"
@@ -88,6 +97,8 @@ def test_pair8_loader_waits_barriers_and_scratch(tmp_path):
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     mutant, _ = tool.run_pair8(str(out))
     assert mutant and all(any(v[0] == "P3" for v in bad) for bad in mutant.values()), "a wrong wait count went unnoticed"
+    mutant3, _ = tool.run_tri(str(out))
+    assert mutant3 and all(any(v[0] == "P3" for v in bad) for bad in mutant3.values()), "a wrong wait count in k_tri went unnoticed"
 
 
 def _loader(pieces, wait, nop="s_nop 4", extra=(), barrier_before_wait=False, read_early=False):

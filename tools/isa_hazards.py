@@ -176,6 +176,22 @@ def pair8_centre_per_plane(ty, fd):
     return 5 * ((ty + 2 + 3) // 4) + (5 * 2 * ty + 63) // 64
 
 
+# ---- k_tri: the same loader idiom (csrc/f3d_solve_tri.h), no halo pieces, no centre-only ring --------------------------------
+
+TRI = "k_tri"
+
+
+def tri_params(name):
+    """(MODE, TY) from the mangled name ..k_triILi<MODE>ELi<TY>EE.."""
+    m = re.search(r"k_triILi(\d+)ELi(\d+)E", name)
+    return tuple(int(g) for g in m.groups()) if m else None
+
+
+def tri_per_plane(ty):
+    """DMA instructions per plane: ten inputs, ring rows y0-3 .. y0+TY+2 in pieces of four rows"""
+    return 10 * ((ty + 6 + 3) // 4)
+
+
 def instructions(body):
     """[(line number, label or None, opcode, operands)] of a kernel body; labels attach to the next instruction"""
     out, pending = [], []
@@ -377,11 +393,11 @@ def check_pair8(body, per_plane, centre=0):
     return bad
 
 
-def pair8_kernels(path):
+def pair8_kernels(path, key=PAIR8):
     name, body = None, []
     for line in open(path):
         m = re.match(r"^(_Z\w+):", line)
-        if m and PAIR8 in m.group(1):
+        if m and key in m.group(1):
             name, body = m.group(1), []
             continue
         if name:
@@ -411,6 +427,25 @@ def run_pair8(path=None):
     return report, {k: v for k, v in scratch.items() if (pair8_params(k) or (0, 0, 1, 0))[2] == 0}
 
 
+def run_tri(path=None):
+    """{kernel: violations} for every k_tri instantiation (all of them ship), and {kernel: scratch bytes}"""
+    path = path or compile_to_asm()
+    report, scratch = {}, {}
+    cur = None
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r";\s*ScratchSize:\s*(\d+)", line)
+        if m and cur and TRI in cur:
+            scratch[cur] = int(m.group(1))
+    for name, body in pair8_kernels(path, TRI):
+        prm = tri_params(name)
+        if prm is not None:
+            report[name] = check_pair8(body, tri_per_plane(prm[1]))
+    return report, scratch
+
+
 def run(path=None):
     path = path or compile_to_asm()
     report = {}
@@ -429,6 +464,9 @@ if __name__ == "__main__":
     rep8, scratch8 = run_pair8(asm)
     rep.update(rep8)
     scratch.update(scratch8)
+    rep3, scratch3 = run_tri(asm)
+    rep.update(rep3)
+    scratch.update(scratch3)
     rc = 0
     for name, bad in rep.items():
         print(f"{name}: {len(bad)} violation(s)")

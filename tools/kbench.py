@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark: times f3d_phi_ksi / f3d_solve_sweep on one W x H x D level with HIP events
 (f3d_prof_*), on random data.  Used for tuning and for the rocprofv3 / PMC runs whose summaries live in profiles/.
-   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|phi|both|bothfd|all]
+   python tools/kbench.py [--size 512 | --dims W H D] [--reps 20] [--kernel sweep|sweep2|sweeppk|sweep2fd|sweeppkfd|sweep3|sweep2pk|tri|phi|both|bothfd|all]
                           [--ablate N]
 --ablate N: timing-only builds of the solver kernels that skip parts of the work (WRONG results; N as described at k_pair8 / k_sweep7 /
 k_sweep6).  They exist only in the LAB library (make -C cuda-flow3d_amd lab -> lib/lab/), which this option loads instead of the
@@ -70,12 +70,18 @@ def main():
             pkg.check(hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, *out, None))
         if a.kernel in ("sweeppkfd", "bothfd", "all"):
             pkg.check(hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
+        if a.kernel in ("sweep3", "tri"):
+            pkg.check(hip.f3d_solve_sweep3(*ptr, phi, ksi, W, H, D, *h, 7.5, *out, None))
+        if a.kernel in ("sweep2pk", "tri"):
+            pkg.check(hip.f3d_solve_sweep2_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
         if a.kernel in ("sweeppk", "both", "all"):
             pkg.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.001, *out, phi2, ksi2, None))
     pkg.sync()
     # sweep2: two sweeps of algorithmic work (2 x 52 B per voxel) per launch
     # sweeppk: one sweep + the next phi/ksi (52 + 40 B per voxel) per launch
-    for kid, name, bpv in ((0, "phi_ksi", 40.0), (1, "sweep", 52.0), (2, "sweep2", 104.0), (3, "sweeppk", 92.0)):
+    # sweep3: three sweeps (3 x 52 B); sweep2pk: two sweeps + the next phi/ksi (2 x 52 + 40 B)
+    for kid, name, bpv in ((0, "phi_ksi", 40.0), (1, "sweep", 52.0), (2, "sweep2", 104.0), (3, "sweeppk", 92.0), (4, "sweep3", 156.0),
+                           (5, "sweep2pk", 144.0)):
         ms, n, vox = C.c_double(), C.c_uint64(), C.c_double()
         hip.f3d_prof_read(kid, 0, C.byref(ms), C.byref(n), C.byref(vox))
         if n.value:
