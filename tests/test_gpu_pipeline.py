@@ -176,11 +176,10 @@ def test_solve_operator_through_the_bag(f3d, oracle, outer):
         phi, ksi = oracle.phi_ksi(*hosts, du, dv, dw, dims, h, 0.001, 0.001)
         for _ in range(inner):
             du, dv, dw = oracle.solve_sweep(*hosts, du, dv, dw, phi, ksi, dims, h, 7.5)
-    # 3 swaps per outer iteration (two fused pairs and a single sweep): 9 or 12 in all
-    if outer % 2 == 1:
-        assert vals["dev_flow_du"] == extra["dev_temp_du"] and vals["dev_temp_du"] == extra["dev_flow_du"]
-    else:
-        assert vals["dev_flow_du"] == extra["dev_flow_du"] and vals["dev_temp_du"] == extra["dev_temp_du"]
+    # one swap per launch: how many there are depends on how the level's sweeps are cut (two launches per outer iteration on a level
+    # this small, three on large ones), so the roles may or may not have changed hands -- but the two containers are still the pair
+    for c in ("u", "v", "w"):
+        assert {vals[f"dev_flow_d{c}"], vals[f"dev_temp_d{c}"]} == {extra[f"dev_flow_d{c}"], extra[f"dev_temp_d{c}"]}
     for key, e in (("dev_flow_du", du), ("dev_flow_dv", dv), ("dev_flow_dw", dw), ("dev_phi", phi), ("dev_ksi", ksi)):
         g = cont.download(vals[key], cdims)
         assert same(g[:D, :H, :W], e[:D, :H, :W]), key
