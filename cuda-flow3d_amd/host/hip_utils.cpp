@@ -78,12 +78,16 @@ bool FrameDerivativesEnabled()
 
 bool ThreeStageLaunchesPay(size_t width, size_t height, size_t depth)
 {
-  // The three-stage launches (f3d_solve_sweep3, f3d_solve_sweep2_phi_ksi) win where a launch is bound by its own skeleton, i.e. on
-  // small and mid-size levels (profiles/r04_three_stage_*.txt); above the threshold the 12-row two-stage tiles at four waves per SIMD
-  // are the faster cut.  F3D_TRI=0 switches them off, F3D_TRI_MAX_VOXELS moves the threshold (read once).
+  // The three-stage launches (f3d_solve_sweep3, f3d_solve_sweep2_phi_ksi: k_tri) are bit-identical to the two-stage schedule and were
+  // built to halve the launches of the small levels.  Measured (profiles/r04_three_stage_kbench.txt, r04_three_stage_solves.txt), they
+  // do NOT pay: a z-chunk of a three-stage march runs its planes + 4 steps where a two-stage march runs planes + 2, and on the levels
+  // where launches dominate a chunk is one plane -- five steps against three -- so two three-stage launches cost what three two-stage
+  // launches cost (24^3: 14.0 + 15.6 us against 2 x 9.7 + 10.3 us), and from ~96^3 up the 56-of-64 tiling and the four halo rows lose
+  // outright (BASELINE config 2: 73.5 -> 82.9 ms).  OFF by default; F3D_TRI=1 takes them on levels of up to F3D_TRI_MAX_VOXELS voxels
+  // (default 3e6) -- the tests run both schedules and demand the same bits.  Read once.
   static const bool on = [] {
     const char* e = std::getenv("F3D_TRI");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   static const double max_voxels = [] {
     const char* e = std::getenv("F3D_TRI_MAX_VOXELS");

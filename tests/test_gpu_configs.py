@@ -104,7 +104,8 @@ def test_c4_digest_is_the_committed_one(f3d, c4):
     {"F3D_PAIR8": "0", "F3D_FUSED_PHI_KSI": "0"},    # the round-1 schedule: k_sweep7 pairs, separate phi/ksi and fifth sweep
     {"F3D_FRAME_DERIVATIVES": "0"},                   # fused launches that form the frame derivatives themselves (the default reads
                                                       # them: computed once per level)
-], ids=["unfused", "round1-kernels", "frames"])
+    {"F3D_TRI": "1", "F3D_TRI_MAX_VOXELS": "2e7"},   # three-stage launches (k_tri) on every level up to 271^3: 27 of the 40
+], ids=["unfused", "round1-kernels", "frames", "three-stage"])
 def test_c4_other_schedules_give_the_same_bits(c4, switches):
     """the same solve under switches that regroup the work, each in a process of its own (the switches are read once)"""
     env = dict(os.environ, **switches)
