@@ -112,10 +112,13 @@ inline void pair_consts(PairArgs& a)
 // (y0-1 .. y0+TY) and the halo columns of the core rows, and only TWO slots: a centre-only plane is read once, at the very start of
 // the step in which it is the z+1 plane, so its slot is free one step earlier than a stencilled plane's -- which is what lets a
 // 12-row tile with twelve inputs fit the 160 KB of a CU (3 x 32 KB + 2 x 19.5 KB + 22.5 KB of stage-1 images).
-template <int TY, int NA = 10, bool FD = false>
+// TIGHT (y-marching builds whose tile holds ALL rows of the volume, i.e. every z plane of a thin volume): the two halo row waves and the
+// four halo ring rows would only hold mirror images of rows the tile has anyway, so they are left out -- TY row waves, TY ring rows,
+// the mirrored neighbour of a face row is read from the opposite row -- and two such workgroups share a CU.
+template <int TY, int NA = 10, bool FD = false, bool TIGHT = false>
 struct Pair8Lds {
-  static constexpr int NR = TY + 2;                   // row waves
-  static constexpr int NJ = TY + 4;                   // ring rows: y0-2 .. y0+TY+1
+  static constexpr int NR = TY + (TIGHT ? 0 : 2);     // row waves
+  static constexpr int NJ = TY + (TIGHT ? 0 : 4);     // ring rows: y0-2 .. y0+TY+1 (TIGHT: y0 .. y0+TY-1)
   static constexpr int NK = (NJ + 3) / 4;             // row pieces (4 rows x 64 floats = 1 KiB) per array and plane
   static constexpr int NJP = NJ;                      // rows per array in the ring (a partial last piece masks its surplus lanes)
   static constexpr int NS = FD ? 7 : NA;              // arrays in the three-slot ring
@@ -280,17 +283,18 @@ __device__ __forceinline__ void phi_ksi_stage2(const CarryP& k, const S3& xm, co
 // FD: the kernel reads the frame derivatives fx, fy, fz, ft (k_frame_derivatives, once per level) instead of the frames: they
 // are centre values, so the frame entries of every neighbour -- their LDS reads, lane shifts, differences and the three
 // divisions by 4h -- drop out of stage 1 (a seventh of its arithmetic), for two more arrays to stream.
-template <int MODE, int TY, int ABL = 0, bool FD = false, bool YM = false>
-__global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
-                                                           int xcd_remap)
+template <int MODE, int TY, int ABL, bool FD, bool YM, bool TIGHT>
+__device__ __forceinline__ void pair8_body(const PairArgs& a, const F3dGeo& g, int zchunk, int ntx, int nty, int n_tiles, int xcd_remap)
 {
   static_assert(!(YM && FD), "the frame-derivative launchers march along z only");
+  static_assert(!TIGHT || (YM && ABL == 0), "a tile without halo rows holds every row of the volume: thin volumes marched along y");
+  constexpr int RH = TIGHT ? 0 : 1;   // halo rows on either side of the tile's rows that get a row wave (and twice that many ring rows)
   // rows of a tile / march direction: (y, z) or, for thin volumes, (z, y).  YM launches cover the whole volume (no slab window).
   const int RDIM = YM ? g.D : g.H;   // extent along the tile's rows
   const int MDIM = YM ? g.H : g.D;   // extent along the march
   const int m_lo = YM ? 0 : g.z_lo, m_hi = YM ? g.H : g.z_hi;
   constexpr int NA = FD ? 12 : 10;
-  using L = Pair8Lds<TY, NA, FD>;
+  using L = Pair8Lds<TY, NA, FD, TIGHT>;
   constexpr int NR = L::NR, NJ = L::NJ, NK = L::NK, NJP = L::NJP, NH = L::NH;
   static_assert(TY <= 32, "the column wave holds one halo voxel per lane: 2 x TY <= 64");
   __shared__ __attribute__((aligned(16))) float ring[L::kSlots][L::kSlotFloats];
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
     for (int k = 0; k < NK; ++k) {
       const int j = 4 * k + (lane >> 4);
       rowv[k] = j < NJ;
-      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + (rowv[k] ? j : 0), RDIM), 0, RDIM - 1);
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 * RH + (rowv[k] ? j : 0), RDIM), 0, RDIM - 1);
       rowb[k] = static_cast<unsigned>(yrow) * row_b + static_cast<unsigned>(x0 + 4 * (lane & 15)) * 4u;
     }
     // halo pieces: lane' = 64 h + lane -> [array][side][row]; four floats left of the tile (x0-4 ..) or right of it (x0+64 ..)
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
 #pragma unroll
       for (int i = SB + 1; i < SB + L::NS; ++i)
         if (arr == i) b = base[i];
-      const int yrow = f3d_clampi(f3d_mir(y0 - 2 + j, RDIM), 0, RDIM - 1);
+      const int yrow = f3d_clampi(f3d_mir(y0 - 2 * RH + j, RDIM), 0, RDIM - 1);
       // tiles at an x face fetch a piece from inside the row instead (never used: the mirror rule substitutes there)
       const int xc = s == 0 ? (left_face ? 0 : x0 - 4) : (right_face ? x0 + kLanes - 4 : x0 + kLanes);
       hptr[h] = b + static_cast<size_t>(yrow) * static_cast<size_t>(row_b >> 2) + xc;
@@ -485,13 +489,16 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   }
 
   // row waves
-  const int y = y0 - 1 + r;
+  const int y = y0 - RH + r;
   const int yy = f3d_clampi(f3d_mir(y, RDIM), 0, RDIM - 1);
   const int x = x0 + lane;
-  const bool core = r >= 1 && r <= TY;
+  const bool core = r >= RH && r < RH + TY;
   const bool owner = core && x < g.W && y < RDIM;
   const int side = lane < 32 ? 0 : 1;
-  const int jr = r + 1;  // ring row of this wave's row
+  const int jr = r + RH;  // ring row of this wave's row
+  // ring rows of its two row neighbours: the rows beside it -- or, in a tile without halo rows, the mirror image at a face of the volume
+  const int jr_m = (TIGHT && y == 0) ? jr + 1 : jr - 1;
+  const int jr_p = (TIGHT && y == RDIM - 1) ? jr - 1 : jr + 1;
   // Stage 2 reads the stage-1 results of rows y-1 and y+1 from the LDS image; at a y face of the volume the missing neighbour is
   // the opposite one (mirror rule), which for a row wave is simply the other image row: chosen here, once, by a scalar select
   // instead of six vector selects per step.
@@ -503,7 +510,9 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   const int crow = cactive ? (lane & 31) : TY - 1;
   const int cy = y0 + crow;
   const int cx = side == 0 ? x0 - 1 : x0 + kLanes;
-  const int jc = crow + 2;  // ring row of the column wave's voxel
+  const int jc = crow + 2 * RH;  // ring row of the column wave's voxel
+  const int jc_m = (TIGHT && cy == 0) ? jc + 1 : jc - 1;
+  const int jc_p = (TIGHT && cy == RDIM - 1) ? jc - 1 : jc + 1;
   const int e_near = side == 0 ? 3 : 0;  // element of the 4-float halo piece next to the tile, and the one beyond it
   const int e_far = side == 0 ? 2 : 1;
 
@@ -603,12 +612,12 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       nIn = plane_face(T);
     }
     if constexpr (CW) {
-      halo_raw(T0, S, side, jc - 1, e_near, false);
-      halo_raw(T1, S, side, jc + 1, e_near, false);
+      halo_raw(T0, S, side, jc_m, e_near, false);
+      halo_raw(T1, S, side, jc_p, e_near, false);
       halo_raw(T2, S, side, jc, e_far, false);
     } else {
-      row_raw(T0, S, jr - 1, false);
-      row_raw(T1, S, jr + 1, false);
+      row_raw(T0, S, jr_m, false);
+      row_raw(T1, S, jr_p, false);
       halo_raw(T2, S, side, jr, e_near, false);
     }
     if (MODE == PAIR_SP) {
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   auto step = [&](auto colw_c, auto slot_c, PlaneRegs& M, PlaneRegs& C, PlaneRegs& P, int q) __attribute__((always_inline)) {
     constexpr bool CW = decltype(colw_c)::value;  // the column wave runs a loop of its own: no value merges with the row waves
     constexpr int SLOT = decltype(slot_c)::value;
-    if constexpr (TY > 8) lane = fresh_lane();
+    if constexpr (TY > 8 || TIGHT) lane = fresh_lane();
     if (!(ABL & 8)) __syncthreads();  // B_q: plane q+1 is in the ring, img1 / hc1 of plane q-1 are complete
     if (ABL & 4) return;
     const float* Sp = &ring[SLOT][0];
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
       } else {
         ym.u = img1[pb][0][r_ym][lane]; ym.v = img1[pb][1][r_ym][lane]; ym.w = img1[pb][2][r_ym][lane];
         yp.u = img1[pb][0][r_yp][lane]; yp.v = img1[pb][1][r_yp][lane]; yp.w = img1[pb][2][r_yp][lane];
-        eu = hc1[pb][0][side][r - 1]; ev = hc1[pb][1][side][r - 1]; ew = hc1[pb][2][side][r - 1];
+        eu = hc1[pb][0][side][r - RH]; ev = hc1[pb][1][side][r - RH]; ew = hc1[pb][2][side][r - RH];
       }
       xm.u = lane_left_or(hC.u, eu); xm.v = lane_left_or(hC.v, ev); xm.w = lane_left_or(hC.w, ew);
       xp.u = lane_right_or(hC.u, eu); xp.v = lane_right_or(hC.v, ev); xp.w = lane_right_or(hC.w, ew);
@@ -862,6 +871,23 @@ __global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores issued by hand
 }
 
+// the kernels: one body, two sets of launch attributes
+template <int MODE, int TY, int ABL = 0, bool FD = false, bool YM = false>
+__global__ __launch_bounds__(kLanes*(TY + 4)) void k_pair8(PairArgs a, F3dGeo g, int zchunk, int ntx, int nty, int n_tiles,
+                                                           int xcd_remap)
+{
+  pair8_body<MODE, TY, ABL, FD, YM, false>(a, g, zchunk, ntx, nty, n_tiles, xcd_remap);
+}
+// ... a tile without halo rows (thin volumes marched along y, all planes in the tile): TY + 2 waves and ~50 KB of LDS per workgroup, held to
+// 128 registers so that TWO workgroups share a CU (four waves per SIMD) -- a level of BASELINE config 3 is then spread over twice as
+// many concurrent row waves
+template <int MODE, int TY>
+__global__ __launch_bounds__(kLanes*(TY + 2)) __attribute__((amdgpu_waves_per_eu(4))) void k_pair8t(PairArgs a, F3dGeo g, int zchunk, int ntx,
+                                                                                                   int nty, int n_tiles, int xcd_remap)
+{
+  pair8_body<MODE, TY, 0, false, true, true>(a, g, zchunk, ntx, nty, n_tiles, xcd_remap);
+}
+
 // one workgroup per CU at a time: z-chunks by the round model of k_sweep7 (a chunk costs its planes plus ~7 steps of prologue
 // and repeated stage-1 planes, 256 workgroups run per round).  `cost` is in plane steps of ONE
 // workgroup; a step of a 16-wave workgroup (TY = 12) takes ~1.28 x a step of a 12-wave one (TY = 8) -- measured at 128^3 ... 512^3
@@ -919,7 +945,7 @@ inline int pair8_ymarch_rows(const F3dGeo& g)
   return g.D <= 4 ? 4 : (g.D == 5 ? 5 : 8);
 }
 
-template <int MODE, int TY, bool FD = false, bool YM = false>
+template <int MODE, int TY, bool FD = false, bool YM = false, bool TIGHT = false>
 void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
   PairArgs a = args;
@@ -929,16 +955,18 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
   const int ntx = (g.W + kLanes - 1) / kLanes;
   const int nty = (rows + TY - 1) / TY;
   const int zc_limit = YM ? planes : max_planes_per_chunk(g);
-  int zchunk = pair8_plan_dims(g.W, rows, planes, TY, zc_limit).zchunk;
+  // (two workgroups of a tile without halo rows share a CU: 512 per round)
+  int zchunk = pair8_plan_dims(g.W, rows, planes, TY, zc_limit, TIGHT ? 512 : 256).zchunk;
   if (force_zchunk > 0) zchunk = force_zchunk;
   zchunk = std::min(zchunk, zc_limit);
   const int nz = (planes + zchunk - 1) / zchunk;
   const int n_tiles = ntx * nty * nz;
   const int per_xcd = (n_tiles + 7) / 8;
   const int blocks = xcd_remap ? per_xcd * 8 : n_tiles;
-  const dim3 grid(blocks, 1, 1), block(kLanes, TY + 4, 1);
+  const dim3 grid(blocks, 1, 1), block(kLanes, TY + (TIGHT ? 2 : 4), 1);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, f3d::stream(), a, g, zchunk, ntx, nty, n_tiles, xcd_remap); };
-  if constexpr (YM) return go(k_pair8<MODE, TY, 0, false, true>);
+  if constexpr (YM && TIGHT) return go(k_pair8t<MODE, TY>);
+  else if constexpr (YM) return go(k_pair8<MODE, TY, 0, false, true>);
   else if constexpr (FD) return go(k_pair8<MODE, TY, 0, true>);
   else {
 #ifdef F3D_LAB  // timing builds that skip parts of the work (WRONG results): only in lib/lab/libf3d_hip.so (make lab, tools/kbench.py
@@ -967,9 +995,19 @@ void launch_pair8(const PairArgs& args, const F3dGeo& g, int force_zchunk, int x
 template <int MODE>
 bool launch_pair8_ymarch(const PairArgs& a, const F3dGeo& g, int force_zchunk, int xcd_remap)
 {
+  // a tile that holds exactly the planes of the volume needs no halo rows (TIGHT): 4 and 5 planes, the depths of BASELINE config 3.
+  // F3D_PAIR8_TIGHT=0 keeps the halo rows (A/B timing; read per call like the march switch)
+  const char* e = std::getenv("F3D_PAIR8_TIGHT");
+  const bool tight = !(e && e[0] == '0');
   switch (pair8_ymarch_rows(g)) {
-    case 4: launch_pair8<MODE, 4, false, true>(a, g, force_zchunk, xcd_remap); return true;
-    case 5: launch_pair8<MODE, 5, false, true>(a, g, force_zchunk, xcd_remap); return true;
+    case 4:
+      if (tight && g.D == 4) launch_pair8<MODE, 4, false, true, true>(a, g, force_zchunk, xcd_remap);
+      else launch_pair8<MODE, 4, false, true>(a, g, force_zchunk, xcd_remap);
+      return true;
+    case 5:
+      if (tight && g.D == 5) launch_pair8<MODE, 5, false, true, true>(a, g, force_zchunk, xcd_remap);
+      else launch_pair8<MODE, 5, false, true>(a, g, force_zchunk, xcd_remap);
+      return true;
     case 8: launch_pair8<MODE, 8, false, true>(a, g, force_zchunk, xcd_remap); return true;
     default: return false;
   }

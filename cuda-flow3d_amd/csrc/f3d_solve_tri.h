@@ -4,13 +4,16 @@
 // there (sweep_stage1 / sweep_stage2 / phi_ksi_stage2, PlaneRegs, Face6, Carry, CarryP, the uniform-divisor helpers) and the loader
 // idiom of k_pair8 (dma16, uniform_ptr, counted s_waitcnt).
 //
-// Why.  Below ~128^3 a fused launch is not bound by bytes or by issue slots but by its own skeleton: ~4 us of dispatch + prologue and a
-// handful of dependent plane steps (LABBOOK.md, "small levels").  A lab build of k_pair8 that runs a THIRD stage in every step
-// (profiles/r04_three_stage_probe.txt) costs 16-23 % more than the two-stage launch at every size from 24^3 to 512^3 -- stage 1 pays
-// for the operand fetch, the finished faces, the J terms and the six face weights; a further sweep of the same voxel is ~180
-// instructions on values that are already in registers -- so an outer iteration cut as (S, S, S) + (S, S, P) instead of
-// (S, S) + (S, S) + (S, P) is two launches instead of three and ~20 % less time wherever the skeleton dominates.  The reference's loop:
-// cuda_operation_solve.cpp:194-266 (phi/ksi, then `inner` sweeps with a buffer swap after each).
+// Why it was built, and what it measured (LABBOOK.md, round 4).  Below ~128^3 a fused launch is not bound by bytes or by issue slots
+// but by its own skeleton: ~4 us of dispatch + prologue and a handful of dependent plane steps.  A lab build of k_pair8 with a THIRD
+// stage in every step (profiles/r04_three_stage_probe.txt) cost 16-23 % more than the two-stage launch, which argued for cutting an
+// outer iteration as (S, S, S) + (S, S, P) -- two launches -- instead of (S, S) + (S, S) + (S, P).  This kernel is that cut, bit for
+// bit; measured (profiles/r04_three_stage_kbench.txt, r04_three_stage_solves.txt) it is NOT faster: a three-stage z-chunk marches its
+// planes + 4 steps where a two-stage chunk marches planes + 2 (the probe had added one), and the small levels are cut into one-plane
+// chunks -- five steps against three -- so two launches of this kernel cost what three of k_pair8 cost (24^3: 29.6 against 29.7 us per
+// outer iteration), and from ~96^3 up its tile shape loses outright.  It is therefore OPT-IN (F3D_TRI=1, host/hip_utils.cpp), kept
+// tested and ISA-checked for a machine whose launches cost more.  The reference's loop: cuda_operation_solve.cpp:194-266 (phi/ksi,
+// then `inner` sweeps with a buffer swap after each).
 //
 //   TRI_SSS  three consecutive sweeps                      -- f3d_solve_sweep3
 //   TRI_SSP  two sweeps, then phi/ksi of the NEXT outer iteration from the increments they leave   -- f3d_solve_sweep2_phi_ksi

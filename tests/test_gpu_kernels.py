@@ -872,15 +872,25 @@ THIN_CASES = [
     ((31, 64, 7), (64, 64, 8)),
     ((200, 17, 8), (256, 20, 8)),
     ((5, 9, 4), (16, 9, 4)),
+    ((129, 40, 5), (192, 40, 5)),     # five planes, W = 64 k + 1 (a halo column is the last column of the volume), several y chunks
+    ((64, 70, 4), (64, 72, 6)),       # four planes in a deeper container, one tile column exactly
+    ((200, 33, 5), (256, 36, 5)),
 ]
 
 
 @pytest.mark.parametrize("dims,cdims", THIN_CASES)
 @pytest.mark.parametrize("h", SPACINGS)
-@pytest.mark.parametrize("ymarch", ["1", "0"])
+@pytest.mark.parametrize("ymarch", ["1", "0", "halo-rows"])
 def test_fused_launches_on_thin_volumes_march_along_y(f3d, oracle, dims, cdims, h, ymarch, monkeypatch):
     """Two fused sweeps and sweep + next phi/ksi on volumes of 2 ... 8 planes, forced through the y-marching build (F3D_PAIR8_YMARCH=1,
-    whatever the H / D ratio) and through the ordinary z march (=0): both equal the oracle bit for bit."""
+    whatever the H / D ratio) and through the ordinary z march (=0): both equal the oracle bit for bit.  Volumes of exactly four or five
+    planes take the tile WITHOUT halo rows by default (k_pair8t: the mirrored neighbour of a face plane is read from the opposite row,
+    two workgroups per CU); "halo-rows" runs them through the build with halo rows as well (F3D_PAIR8_TIGHT=0)."""
+    if ymarch == "halo-rows":
+        if dims[2] not in (4, 5):
+            pytest.skip("only volumes of four or five planes have the build without halo rows")
+        monkeypatch.setenv("F3D_PAIR8_TIGHT", "0")
+        ymarch = "1"
     monkeypatch.setenv("F3D_PAIR8_YMARCH", ymarch)
     rng = np.random.default_rng(hash((dims, h, 9)) % 2**32)
     W, H, D = dims

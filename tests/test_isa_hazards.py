@@ -61,11 +61,14 @@ def test_pair8_loader_waits_barriers_and_scratch(tmp_path):
     tool = load_tool()
     asm = tool.compile_to_asm()
     report, scratch = tool.run_pair8(asm)
-    found = {tool.pair8_params(name)[:2] + tool.pair8_params(name)[3:] for name in report}
+    found = {tool.pair8_params(name)[:2] + tool.pair8_params(name)[3:] for name in report if tool.pair8t_params(name) is None}
     assert found == set(SHIPPED_PAIR8), found
+    # the tiles without halo rows (k_pair8t: 4 and 5 planes marched along y, two workgroups per CU)
+    assert {tool.pair8t_params(name) for name in report if tool.pair8t_params(name)} == {(m, ty) for m in (0, 1) for ty in (4, 5)}
+    assert tool.pair8t_per_plane(4) == 12 and tool.pair8t_per_plane(5) == 22
     for name, bad in report.items():
         assert not bad, f"{name}: {bad[:5]}"
-    assert len(scratch) >= len(SHIPPED_PAIR8)
+    assert len(scratch) >= len(SHIPPED_PAIR8) + 4
     for name, size in scratch.items():
         assert size == 0, f"{name} uses {size} bytes of scratch per lane"
     for mode, ty, fd, ym in SHIPPED_PAIR8:

@@ -160,6 +160,17 @@ def pair8_params(name):
     return tuple(int(g) for g in m.groups()) if m else None
 
 
+def pair8t_params(name):
+    """(MODE, TY) of a k_pair8t instantiation (thin volumes marched along y, tile without halo rows): ..k_pair8tILi<MODE>ELi<TY>EE.."""
+    m = re.search(r"k_pair8tILi(\d+)ELi(\d+)E", name)
+    return tuple(int(g) for g in m.groups()) if m else None
+
+
+def pair8t_per_plane(ty):
+    """ten inputs, TY ring rows in pieces of four, x-halo pieces of the TY rows on both sides"""
+    return 10 * ((ty + 3) // 4) + (10 * 2 * ty + 63) // 64
+
+
 def pair8_per_plane(ty, fd):
     """DMA instructions per plane of the three-slot ring: the count the steady-state wait must carry.  The frame-derivative builds
     keep only their seven stencilled inputs there"""
@@ -420,11 +431,15 @@ def run_pair8(path=None):
         if m and cur and PAIR8 in cur:
             scratch[cur] = int(m.group(1))
     for name, body in pair8_kernels(path):
+        tight = pair8t_params(name)
+        if tight is not None:
+            report[name] = check_pair8(body, pair8t_per_plane(tight[1]))
+            continue
         prm = pair8_params(name)
         if prm is None or prm[2] != 0:
             continue        # ablation builds (ABL != 0): timing experiments with wrong results, never launched by default
         report[name] = check_pair8(body, pair8_per_plane(prm[1], prm[3]), pair8_centre_per_plane(prm[1], prm[3]))
-    return report, {k: v for k, v in scratch.items() if (pair8_params(k) or (0, 0, 1, 0))[2] == 0}
+    return report, {k: v for k, v in scratch.items() if pair8t_params(k) is not None or (pair8_params(k) or (0, 0, 1, 0))[2] == 0}
 
 
 def run_tri(path=None):
