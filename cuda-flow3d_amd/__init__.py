@@ -110,6 +110,7 @@ def hip():
         "f3d_frame_derivatives": [_dp, _dp, _sz, _sz, _sz, C.c_float, C.c_float, C.c_float, _dp, _dp, _dp, _dp, _slabp],
         "f3d_solve_sweep_phi_ksi_edges_fd": [_dp] * 12 + [_sz] * 3 + [C.c_float] * 6 + [_dp] * 5 + [_slabp, C.c_int, C.c_int],
         "f3d_solve_sweep2_fd": [_dp] * 12 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
+        "f3d_fused_launches_march_along_y": [_sz, _sz, _sz],
         "f3d_solve_sweep3": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 4 + [_dp] * 3 + [_slabp],
         "f3d_solve_sweep2_phi_ksi": [_dp] * 10 + [_sz] * 3 + [C.c_float] * 6 + [_dp] * 5 + [_slabp],
         "f3d_solve_sweep_phi_ksi_fd": [_dp] * 12 + [_sz] * 3 + [C.c_float] * 6 + [_dp] * 5 + [_slabp],

@@ -1829,6 +1829,19 @@ int f3d_solve_sweep_phi_ksi_edges_fd(f3d_devptr fx, f3d_devptr fy, f3d_devptr fz
                   equation_data, out, slab, keep_below, keep_above);
 }
 
+int f3d_fused_launches_march_along_y(size_t width, size_t height, size_t depth)
+{
+  // (no device needed: the launchers' own rule on the level's geometry, for a caller that has to choose between the entry points on
+  // frames -- which march thin volumes along y -- and the ones on frame derivatives, which march along z only)
+  F3dGeo g = {};
+  const f3d_size4& c = f3d::container();
+  g.W = static_cast<int>(width); g.H = static_cast<int>(height); g.D = static_cast<int>(depth);
+  g.Hc = static_cast<int>(c.height); g.pitch = static_cast<int>(c.pitch / sizeof(float));
+  g.z_base = 0; g.z_lo = 0; g.z_hi = g.D;
+  if (g.pitch <= 0 || g.pitch % kLanes != 0 || !pair8_enabled()) return 0;
+  return pair8_ymarch_rows(g) != 0 ? 1 : 0;
+}
+
 int f3d_solve_sweep3(f3d_devptr frame_0, f3d_devptr frame_1, f3d_devptr flow_u, f3d_devptr flow_v, f3d_devptr flow_w,
                      f3d_devptr flow_du, f3d_devptr flow_dv, f3d_devptr flow_dw, f3d_devptr phi, f3d_devptr ksi, size_t width,
                      size_t height, size_t depth, float hx, float hy, float hz, float equation_alpha, f3d_devptr temp_du,

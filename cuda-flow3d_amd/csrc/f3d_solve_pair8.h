@@ -941,7 +941,13 @@ inline int pair8_ymarch_rows(const F3dGeo& g)
   // Measured (tools/r3_job2.sh, two sweeps / sweep + phi/ksi): 584 x 388 x 5 34.2 -> 33.8 / 40.4 -> 39.2 us, 555 x 369 x 5 32.6 -> 31.0 /
   // 38.5 -> 36.2 us, but 501 x 333 x 4 21.4 -> 23.0 / 24.7 -> 26.8 us: a level of ~1 M voxels is a handful of steps per CU either way
   // and bound by the latency of a step, not by the march direction.  By default only five planes and more, where it wins.
-  if (mode != 1 && (g.D < 5 || g.H < 8 * g.D)) return 0;
+  // Round 4: a tile that holds exactly the volume's 4 or 5 planes needs no halo rows (k_pair8t, two workgroups per CU) and wins at both
+  // depths (profiles/r04_thin_tile_kbench.txt: 584 x 388 x 5 33.1 -> 28.2 / 38.6 -> 31.1 us, 501 x 333 x 4 21.2 -> 20.3 / 23.6 -> 22.3 us
+  // against the z march), so four planes march along y by default as well -- unless F3D_PAIR8_TIGHT=0 brings the halo rows back.
+  const char* te = std::getenv("F3D_PAIR8_TIGHT");
+  const bool tight = !(te && te[0] == '0');
+  const int min_planes = tight ? 4 : 5;
+  if (mode != 1 && (g.D < min_planes || g.H < 8 * g.D)) return 0;
   return g.D <= 4 ? 4 : (g.D == 5 ? 5 : 8);
 }
 

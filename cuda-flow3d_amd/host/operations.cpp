@@ -547,7 +547,10 @@ void CudaOperationSolve::Execute(OperationParameters& params)
   bool weights_ready = false;
   // The frame derivatives fx, fy, fz, ft depend on the two frames only: computed once here, read by every two-stage fused launch of the
   // level instead of the frames (the reference recomputes them for every voxel in each of its 240 launches per level).
+  // (thin volumes: the launches on frames march along y with all planes in the tile, two workgroups per CU -- faster than the z march
+  // the derivative builds would take, so such a level stays on the frames)
   const bool on_derivatives = !tri && FusedSweepsEnabled() && FrameDerivativesEnabled() && slab_ == nullptr && inner_iterations_count >= 2 &&
+                              f3d_fused_launches_march_along_y(w, h, d) == 0 &&
                               dev_container_size_.pitch % 256 == 0 && EnsureDerivativeScratch() &&
                               !CheckDeviceError(f3d_frame_derivatives(dev_frame_0, dev_frame_1, w, h, d, hx, hy, hz, fder_[0], fder_[1],
                                                                       fder_[2], fder_[3], nullptr));

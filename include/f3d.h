@@ -209,6 +209,11 @@ int f3d_solve_sweep_phi_ksi_edges(f3d_devptr frame_0, f3d_devptr frame_1, f3d_de
                                   f3d_devptr temp_dw, f3d_devptr phi_next, f3d_devptr ksi_next, const f3d_slab* slab,
                                   int keep_below, int keep_above);
 
+/* 1 when f3d_solve_sweep2 / f3d_solve_sweep_phi_ksi on a level of this size (whole volume, current container) take the tile that marches
+ * along y with every z plane in it -- thin volumes, BASELINE config 3 -- which exists for the entry points on FRAMES only: a caller that
+ * would otherwise read frame derivatives (the _fd entries march along z) is better off on the frames there.  Pure geometry, no launch. */
+int f3d_fused_launches_march_along_y(size_t width, size_t height, size_t depth);
+
 /* THREE consecutive solve_3d sweeps in one launch (k_tri, csrc/f3d_solve_tri.h): temp_d* receive what three f3d_solve_sweep calls with
  * the buffer swaps in between would leave, bit for bit.  Replaces three iterations of the inner loop of
  * cuda_operation_solve.cpp:222-255; the caller swaps ONCE.  For small and mid-size levels, where a launch is bound by its own

@@ -271,6 +271,7 @@ int f3d_solve_sweep2(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f
                   P<float>(ksi), o.W, o.H, o.D, hx, hy, hz, alpha, P<float>(tdu), P<float>(tdv), P<float>(tdw), &o.g);
   return 0;
 }
+int f3d_fused_launches_march_along_y(size_t, size_t, size_t) { return 0; }
 int f3d_solve_sweep3(f3d_devptr f0, f3d_devptr f1, f3d_devptr u, f3d_devptr v, f3d_devptr w, f3d_devptr du, f3d_devptr dv, f3d_devptr dw,
                      f3d_devptr phi, f3d_devptr ksi, size_t width, size_t height, size_t depth, float hx, float hy, float hz, float alpha,
                      f3d_devptr tdu, f3d_devptr tdv, f3d_devptr tdw, const f3d_slab* slab)
