@@ -633,6 +633,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   const int K = static_cast<int>(inner_iterations_count), outer = static_cast<int>(outer_iterations_count);
   last_plan_ = SolvePiecemealPlan();
   last_passes_ = 0;
+  last_added_ = false;
   if (W == 0 || H == 0 || D == 0) return;
 
   // The increments start at zero (cuda_operation_solve_p.cpp:152-154); with no sweep to run that is also the result.
@@ -777,6 +778,12 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
           s += pair ? 2 : 1;
         }
       }
+      // the last residency of the chunk: the flow update on the device, on the planes the chunk owns (see add_increments_to_flow)
+      if (add_increments_to_flow && i0 + n >= outer) {
+        const DevicePtr sums[3] = {buf[DU], buf[DV], buf[DW]}, flows[3] = {buf[FU], buf[FV], buf[FW]};
+        const f3d_slab own = {base, z0, z1};
+        if (CheckDeviceError(f3d_add_n(sums, flows, 3, W, H, D, &own))) return;
+      }
       if (plan.overlapped) {
         if (CheckDeviceError(f3d_event_record_on(g_pipe.computed[set], nullptr))) return;
         if (CheckDeviceError(f3d_queue_wait_event(q_down, g_pipe.computed[set]))) return;
@@ -793,6 +800,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     if (CheckDeviceError(f3d_stream_sync())) return;
     for (int i = 0; i < 3; ++i) inc[i]->Swap(*next[i]);
     ++last_passes_;
+    if (add_increments_to_flow && i0 + n >= outer) last_added_ = true;
     if (!silent) {
       const float complete = static_cast<float>(i0 + n) / static_cast<float>(outer);
       Utils::PrintProgressBar(complete);

@@ -105,6 +105,12 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   void Execute(OperationParameters& params) override;
 
   bool silent = false;
+  // The driver's next step after the solve is "flow += increment" (cuda_operation_add_p: two uploads and a download per component and
+  // chunk).  With this set, the LAST residency of a chunk -- which holds u, v, w and the final du, dv, dw on the device anyway -- adds
+  // them there and hands back the SUMS in the increments' volumes (IEEE addition commutes: du + u is the u + du the add operator
+  // forms, bit for bit); LastAddedToFlow() says whether it did.  The flow volumes themselves are only read.
+  bool add_increments_to_flow = false;
+  bool LastAddedToFlow() const { return last_added_; }
   // what the last Execute did (tests and the driver's log)
   const SolvePiecemealPlan& LastPlan() const { return last_plan_; }
   size_t LastPasses() const { return last_passes_; }
@@ -115,6 +121,7 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   SolvePiecemealPlan last_plan_;
   size_t last_passes_ = 0;
   bool last_fused_weights_ = false;
+  bool last_added_ = false;
 };
 
 // The two filters the reference's piecemeal driver leaves out (its median is commented out, optical_flow_p.cpp:268-302, and

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "common_utils.h"
 #include "operator_calls.h"
@@ -271,6 +272,16 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   enum Clock { kFrames = 0, kFlowResample = 1, kRegistration = 2, kSolve = 3, kAddAndMedian = 4 };
   cuop_stat_p_.silent = silent;
   cuop_solve_p_.silent = silent;
+  // "flow += increments" inside the solver's last residency (9 field transfers per level less: CudaOperationSolveP::
+  // add_increments_to_flow).  The sums come back in the increments' volumes, so such a level trades the STORAGE of flow[c] and
+  // step[c] (Data3D::Swap: the caller's objects stay the flow, the solver's pass-to-pass swaps keep to the driver's own volumes); an
+  // even number of trades leaves the caller's objects on their own buffers, so with an odd number of host levels the first -- the
+  // smallest -- keeps the separate add.  F3D_P_FUSED_ADD=0 keeps it everywhere.
+  const char* fa_env = std::getenv("F3D_P_FUSED_ADD");
+  const bool fuse_add_allowed = !(fa_env && fa_env[0] == '0');
+  const int host_levels = current_warp_level + 1;
+  const int first_fused_level = fuse_add_allowed ? host_levels - (host_levels % 2) - 1 : -1;   // levels first_fused_level .. 0 fuse
+  float* const callers_storage[3] = {flow[0]->DataPtr(), flow[1]->DataPtr(), flow[2]->DataPtr()};
 
   for (; current_warp_level >= 0; --current_warp_level) {
     const bool finest = current_warp_level == 0;
@@ -312,6 +323,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     // 4. the increments.  The third ping-pong partner is spare[0] -- except at the finest level, where spare[0] holds the caller's
     //    unregistered frame 1 (step 6) and the volume the frames were resampled from is free instead
     Data3D* third_partner = finest ? whole[1] : spare[0];
+    cuop_solve_p_.add_increments_to_flow = current_warp_level <= first_fused_level;
     run(kSolve, cuop_solve_p_,
         {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]},
          {"flow_du", step[0]}, {"flow_dv", step[1]}, {"flow_dw", step[2]}, {"temp_du", spare[1]}, {"temp_dv", spare[2]},
@@ -322,9 +334,14 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     solve_passes_ += cuop_solve_p_.LastPasses();
     if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
 
-    // 5. flow += increments
-    for (int c = 0; c < 3; ++c)
-      run(kAddAndMedian, cuop_add_p_, {{"operand_0", flow[c]}, {"operand_1", step[c]}, {"data_size", &current_data_size}});
+    // 5. flow += increments: done by the solver's last residency where it was asked to (the sums are in step[]: trade the storage),
+    //    by the add operator otherwise
+    if (cuop_solve_p_.LastAddedToFlow()) {
+      for (int c = 0; c < 3; ++c) flow[c]->Swap(*step[c]);
+    } else {
+      for (int c = 0; c < 3; ++c)
+        run(kAddAndMedian, cuop_add_p_, {{"operand_0", flow[c]}, {"operand_1", step[c]}, {"data_size", &current_data_size}});
+    }
 
     // 6. At the finest level step 3 traded the CALLER's frame 1 for spare[0]: the caller gets its storage (and its data, which
     //    the registration only read) back.  The reference leaves the registered frame in the caller's volume.
@@ -337,6 +354,29 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
             {{"input", component}, {"output", component}, {"data_size", &current_data_size}, {"radius", &level_median}});
 
     prev_data_size = current_data_size;
+  }
+  cuop_solve_p_.add_increments_to_flow = false;
+  // The flow must end in the caller's own buffers.  A trade hands the caller's buffer to the driver's volumes, among which the
+  // solver's pass-to-pass swaps move it on, so after the last level it may sit in any of them: find it, trade it back and copy the
+  // result across (all cores; a fraction of what the saved transfers cost).  Volumes that never left are left alone.
+  for (int c = 0; c < 3; ++c) {
+    if (flow[c]->DataPtr() == callers_storage[c]) continue;
+    Data3D* holder = nullptr;
+    for (Data3D& v : scratch)
+      if (v.DataPtr() == callers_storage[c]) holder = &v;
+    if (!holder) {
+      std::printf("'%s': Error. A caller volume was lost among the host scratch volumes.\n", GetName());
+      break;
+    }
+    flow[c]->Swap(*holder);   // flow[c]: the caller's buffer (stale), *holder: the result
+    const float* from = holder->DataPtr();
+    float* to = flow[c]->DataPtr();
+    const long long count = static_cast<long long>(W0) * static_cast<long long>(H0) * static_cast<long long>(D0);
+#pragma omp parallel for schedule(static)
+    for (long long block = 0; block < (count + (1 << 20) - 1) / (1 << 20); ++block) {
+      const long long lo = block << 20, n = std::min<long long>(1 << 20, count - lo);
+      std::memcpy(to + lo, from + lo, static_cast<size_t>(n) * sizeof(float));
+    }
   }
 
   finish();
