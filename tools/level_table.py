@@ -9,7 +9,7 @@ Columns: microseconds per level of the two-sweep launches (k_pair8<0>), sweep + 
 one sweep, everything else; `n` = solver launches."""
 import argparse, collections, csv, json, sys
 
-CLASSES = (("k_pair8<0", "pair_ss"), ("k_pair8<1", "pair_sp"), ("k_phiksi6", "phi_ksi"), ("k_sweep6", "sweep"), ("k_sweep7", "pair7"))
+CLASSES = (("k_pair8<0", "pair_ss"), ("k_pair8<1", "pair_sp"), ("k_pair8t<0", "pair_ss"), ("k_pair8t<1", "pair_sp"), ("k_phiksi6", "phi_ksi"), ("k_sweep6", "sweep"), ("k_sweep7", "pair7"))
 
 
 def classify(name):

@@ -3,12 +3,13 @@
 
 Per pyramid level: time(N) = kernel time of the level on N slabs / N  +  what the exchanges cost where they are not hidden.
 For 8 slabs the first term is MEASURED where a one-GPU trace of the 8-slab decomposition exists for the size
-(profiles/r03_slab8_onegpu_<S>.json: kernel time of the eight slabs run one after the other on one GPU, per level, against the
+(profiles/rNN_slab8_onegpu_<S>.json, the newest round's: kernel time of the eight slabs run one after the other on one GPU, per level, against the
 unsplit solve -- it contains the redundant planes of the communication-avoiding windows, the zone launches and the latency
 floor every rank pays); other rank counts scale the measured excess by the halo depth per owned plane, sizes without a trace
 fall back to the formula of round 2 (a ~2 ms latency floor per level that does not divide, widened windows).  The exchange
 term stays an assumption until a multi-GPU box has been measured: --exchange-us per exchange (pack + grouped send/recv +
-unpack), a fifth of it where the slab is thick enough for the overlapped order.
+unpack), a fifth of it where the slab is thick enough for the overlapped order.  `bench.py --gpus N` reports the measured figure
+(`exchange_us.worst_rank_mean_us_blocking`): put it here once a node has produced one.
    python tools/scale_model.py [--size 1024] [--exchange-us 50]"""
 import argparse
 import json
@@ -21,7 +22,9 @@ ap.add_argument("--exchange-us", type=float, default=50.0)
 a = ap.parse_args()
 S, K, OUTER = a.size, 5, 40
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-trace = os.path.join(root, "profiles", f"r03_slab8_onegpu_{S}.json")
+import glob
+traces = sorted(glob.glob(os.path.join(root, "profiles", f"r0*_slab8_onegpu_{S}.json")))   # the newest round's trace of this size
+trace = traces[-1] if traces else os.path.join(root, "profiles", f"r04_slab8_onegpu_{S}.json")
 edges = [math.ceil(S * 0.95 ** l) for l in range(40)][::-1]          # coarsest first, like the trace tables
 measured = json.load(open(trace)) if os.path.exists(trace) else None
 if measured:
