@@ -856,7 +856,55 @@ bool OpticalFlowSlab::Pyramid(OperationParameters& params)
         if (own.empty()) continue;
         if (!CompleteWeights(l, own.lo - p_max, own.hi + p_max, D, W, H, hx, hy, hz, equation_smoothness, equation_data)) return false;
       }
-      for (size_t st = 0; st < stages.size(); ++st) {
+      // One rank per process and a slab thick enough: the exchange that follows a stage is hidden behind the stage's own interior --
+      // the `next` planes at either end of the slab (what the neighbours are waiting for) are computed first, the transfer starts on
+      // the side stream, the interior follows on the library stream, then the halos are unpacked.  Every voxel is computed once by
+      // the same launches on the same inputs; only their order and their cut along z change (tests/test_gpu_slab_procs.py).
+      const PlaneRange own0 = OwnedPlanes(D, locals_[0].rank, n_ranks_);
+      const bool hide_stage_exchanges = locals_.size() == 1 && overlap_min_planes_ > 0 &&
+                                        own0.size() >= std::max(overlap_min_planes_, 4 * K + 4) && (own0.lo > 0 || own0.hi < D);
+      bool hidden_any = false;
+      for (size_t st = 0; hide_stage_exchanges && st < stages.size(); ++st) {
+        const bool last = st + 1 == stages.size();
+        const int next = !last ? (stages[st + 1].pair ? 2 : 1) : (more ? p_max + 1 : 0);
+        Local& l = locals_[0];
+        const int a = own0.lo, b = own0.hi;
+        const bool has_lo = a > 0, has_hi = b < D;
+        const Role from[3] = {DU, DV, DW}, to[3] = {TDU, TDV, TDW};
+        auto part = [&](int lo, int hi) {
+          f3d_slab s;
+          s.z_base = a - halo_;
+          s.z_lo = lo;
+          s.z_hi = hi;
+          return s;
+        };
+        const int cut_lo = (has_lo && next > 0) ? a + next : a, cut_hi = (has_hi && next > 0) ? b - next : b;
+        // the two zones the neighbours need (plain launches of this stage), then the transfer, then the interior
+        if (cut_lo > a && !Sweeps(l, stages[st].pair, from, to, W, H, D, hx, hy, hz, equation_alpha, part(a, cut_lo))) return false;
+        if (cut_hi < b && !Sweeps(l, stages[st].pair, from, to, W, H, D, hx, hy, hz, equation_alpha, part(cut_hi, b))) return false;
+        if (next > 0) {
+          f3d_comm_mark(0, 1);
+          if (!ExchangeBegin(D, W, H, {to[0], to[1], to[2]}, {to[0], to[1], to[2]}, next, next)) return false;
+          ++stage_exchanges_;
+          hidden_any = true;
+        }
+        bool launched = false;
+        if (last && !stages[st].pair && more && fused_weights_ && FusedSweepsEnabled() && FusedPhiKsiEnabled()) {
+          if (!SweepAndNextWeights(l, {DU, DV, DW}, {TDU, TDV, TDW}, cut_lo, cut_hi, D, W, H, hx, hy, hz, equation_alpha, equation_smoothness,
+                                   equation_data, launched))
+            return false;
+        }
+        if (!launched && !Sweeps(l, stages[st].pair, from, to, W, H, D, hx, hy, hz, equation_alpha, part(cut_lo, cut_hi))) return false;
+        if (next > 0) {
+          if (!ExchangeEnd(W, H)) return false;
+          f3d_comm_mark(1, 1);
+        }
+        std::swap(l.buf[DU], l.buf[TDU]);
+        std::swap(l.buf[DV], l.buf[TDV]);
+        std::swap(l.buf[DW], l.buf[TDW]);
+      }
+      if (hidden_any) ++overlapped_iterations_;
+      for (size_t st = 0; !hide_stage_exchanges && st < stages.size(); ++st) {
         const bool last = st + 1 == stages.size();
         for (Local& l : locals_) {
           const PlaneRange own = OwnedPlanes(D, l.rank, n_ranks_);

@@ -129,3 +129,20 @@ def test_exchange_after_every_solver_stage_across_processes(f3d, tmp_path):
     assert run_ranks.overlapped == [0, 0, 0]
     for g, e, c in zip(got, exp, "uvw"):
         assert same(g, e), f"3 processes exchanging per stage: component {c} differs, max {np.abs(g - e).max():.3e}"
+
+
+@pytest.mark.parametrize("n_ranks,dims", [(2, (40, 36, 64)), (3, (33, 30, 84))])
+def test_stage_exchanges_hidden_behind_the_interior(f3d, tmp_path, n_ranks, dims):
+    """F3D_SLAB_EXCHANGE=stage on slabs of 28-32 planes: after every solver stage the planes the neighbours wait for are computed
+    first, the transfer runs beside the stage's interior, then the halos are unpacked (round 4; the per-outer-iteration order has
+    hidden its exchanges since round 1).  Same bits as one GPU, and the path ran on every rank."""
+    kw = dict(warp_levels_count=6, outer_iterations_count=5)
+    f0, f1 = f3d.synth_pair(*dims)
+    flow = f3d.OpticalFlow()
+    flow.initialize(*dims)
+    exp = flow.compute(f0, f1, silent=True, **kw)
+    flow.destroy()
+    got = run_ranks(n_ranks, dims, tmp_path, env={"F3D_SLAB_EXCHANGE": "stage", "F3D_OVERLAP_MIN_PLANES": "24"}, **kw)
+    assert all(c >= 8 for c in run_ranks.overlapped), run_ranks.overlapped     # outer iterations whose stage exchanges were hidden
+    for g, e, c in zip(got, exp, "uvw"):
+        assert same(g, e), f"{n_ranks} processes, stage exchanges hidden: component {c} differs, max {np.abs(g - e).max():.3e}"
