@@ -6,6 +6,9 @@ set -e
 R=$(pwd)
 O=${F3D_OUT:-$R/gpurun_out}/r4/job6b
 mkdir -p $O
+# (first: the tests added after job 6a was staged -- stage exchanges hidden behind the interior, thin volumes without skipped cases)
+timeout -k 10 600 python3 -X faulthandler -m pytest tests/test_gpu_slab_procs.py tests/test_gpu_slab.py tests/test_gpu_kernels.py -q -m gpu -x -k "slab or thin or stage or overlapped" > $O/tests_new.log 2>&1 || { tail -40 $O/tests_new.log; exit 1; }
+tail -3 $O/tests_new.log
 F3D_OUT=$O bash tools/profile_round.sh > $O/profile_round.log 2>&1 || { tail -30 $O/profile_round.log; exit 1; }
 tail -3 $O/profile_round.log
 cd /tmp && export TMPDIR=/tmp

@@ -75,13 +75,37 @@ def rows():
                 f"{[o[k]['comm']['exchanges_per_step_rank0'] for k in o]}, `config5` leg "
                 f"{'present, parity ' + str(b['config5']['parity']['match']) if 'config5' in b else 'not run'}")
         out.append(("`bench.py --gpus 2` started bare", cell, os.path.relpath(f, ROOT)))
+    f = P("piecemeal_1024_16gb.txt")
+    if os.path.exists(f):
+        import re
+        secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
+        if len(secs) >= 2:
+            out.append(("out-of-core `OpticalFlowP`, 1024³ on a 16 GB budget (`tools/pbench.py`; same bits as the resident driver)",
+                        f"{float(secs[1]):.2f} s with the flow update inside the solver's last residency, {float(secs[0]):.2f} s with the separate "
+                        f"add operator (round 3: 46.8 s)", os.path.relpath(f, ROOT)))
+    f = P("thin_tile_solves.txt")
+    if os.path.exists(f):
+        import re
+        ms = re.findall(r"([\d.]+) ms per solve", open(f).read())
+        if len(ms) >= 2:
+            out.append(("BASELINE config 3 with its thin levels on the y-marching tile without halo rows (`k_pair8t`) / with halo rows",
+                        f"{float(ms[0]):.1f} ms / {float(ms[1]):.1f} ms (same call, `tools/trace_size.py --config c3`)", os.path.relpath(f, ROOT)))
     for size in (512, 1024):
         f = P(f"slab8_onegpu_{size}.json")
         if os.path.exists(f):
             d = json.load(open(f))
             tot = d.get("total", d)
+            model = ""
+            try:
+                import subprocess
+                txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_model.py"), "--size", str(size)], capture_output=True,
+                                     text=True).stdout
+                ups = [l.split("speed-up")[1].strip() for l in txt.splitlines() if "speed-up" in l]
+                model = f"; MODEL (`tools/scale_model.py`, 50 µs per exchange assumed): {ups[1]} / {ups[2]} / {ups[3]} × at 2 / 4 / 8 GPUs"
+            except Exception:
+                pass
             out.append((f"8 z-slabs of {size}³ run one after the other on ONE GPU (the work 8 GPUs divide)",
-                        f"kernel time {tot.get('ratio', 0):.3f} × the unsplit solve", os.path.relpath(f, ROOT)))
+                        f"kernel time {tot.get('ratio', 0):.3f} × the unsplit solve{model}", os.path.relpath(f, ROOT)))
     return out
 
 
