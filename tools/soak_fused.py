@@ -18,7 +18,7 @@ while time.time() - t0 < budget:
     it += 1
     kind = rng.integers(0, 4)
     if kind == 0:   W, H, D = int(rng.choice([63, 64, 65, 127, 128, 129, 130, 191, 193])), int(rng.integers(4, 40)), int(rng.integers(4, 24))
-    elif kind == 1: W, H, D = int(rng.integers(4, 200)), int(rng.integers(4, 80)), int(rng.integers(4, 9))      # thin: the y march from 5 planes
+    elif kind == 1: W, H, D = int(rng.integers(4, 200)), int(rng.integers(4, 400)), int(rng.integers(4, 9))     # thin: the y march (4 and 5 planes: the tile without halo rows)
     elif kind == 2: W, H, D = int(rng.integers(8, 90)), int(rng.integers(8, 90)), int(rng.integers(8, 90))      # small cubes: 4-row tiles
     else:           W, H, D = int(rng.integers(100, 330)), int(rng.integers(60, 200)), int(rng.integers(20, 70))  # several rounds of 12-row tiles
     cdims = (W + int(rng.integers(0, 9)), H + int(rng.integers(0, 5)), D + int(rng.integers(0, 3)))
@@ -40,6 +40,12 @@ while time.time() - t0 < budget:
     f3d.check(hip.f3d_phi_ksi(*ptr[:5], *s1, W, H, D, *h, 0.001, 0.002, pn, kn, None))
     f3d.sync()
     exp2 = [get(p) for p in s2]; exp1 = [get(p) for p in s1] + [get(pn), get(kn)]
+    # three sweeps / two sweeps + the next phi/ksi by the separate launches (round 4: k_tri)
+    s3 = [box.new() for _ in range(3)]; pn2, kn2 = box.new(), box.new()
+    f3d.check(hip.f3d_solve_sweep(*ptr[:5], *s2, phi, ksi, W, H, D, *h, 7.5, *s3, None))
+    f3d.check(hip.f3d_phi_ksi(*ptr[:5], *s2, W, H, D, *h, 0.001, 0.002, pn2, kn2, None))
+    f3d.sync()
+    exp3 = [get(p) for p in s3]; exp2p = exp2 + [get(pn2), get(kn2)]
     fd = [box.new() for _ in range(4)]
     f3d.check(hip.f3d_frame_derivatives(ptr[0], ptr[1], W, H, D, *h, *fd, None))
     reps = 6 if W * H * D < 2e5 else 2
@@ -50,8 +56,12 @@ while time.time() - t0 < budget:
         f3d.check(hip.f3d_solve_sweep_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.002, *o1, None))
         f3d.check(hip.f3d_solve_sweep2_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, *q2, None))
         f3d.check(hip.f3d_solve_sweep_phi_ksi_fd(*fd, *ptr[2:], phi, ksi, W, H, D, *h, 7.5, 0.001, 0.002, *q1, None))
-        f3d.sync(); launches += 4
-        for name, got, exp in (("sweep2", o2, exp2), ("sweep+phi/ksi", o1, exp1), ("sweep2_fd", q2, exp2), ("sweep+phi/ksi_fd", q1, exp1)):
+        t3 = [box.new() for _ in range(3)]; t2 = [box.new() for _ in range(5)]
+        f3d.check(hip.f3d_solve_sweep3(*ptr, phi, ksi, W, H, D, *h, 7.5, *t3, None))
+        f3d.check(hip.f3d_solve_sweep2_phi_ksi(*ptr, phi, ksi, W, H, D, *h, 7.5, 0.001, 0.002, *t2, None))
+        f3d.sync(); launches += 6
+        for name, got, exp in (("sweep2", o2, exp2), ("sweep+phi/ksi", o1, exp1), ("sweep2_fd", q2, exp2), ("sweep+phi/ksi_fd", q1, exp1),
+                               ("sweep3", t3, exp3), ("sweep2+phi/ksi", t2, exp2p)):
             for i, (g, e) in enumerate(zip(got, exp)):
                 gg = get(g)
                 if not same(gg, e):
