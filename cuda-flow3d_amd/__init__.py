@@ -240,6 +240,7 @@ def host():
         "f3d_pflow_stats": [C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)], "f3d_pflow_destroy": [C.c_void_p],
         "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_set_full_pipeline": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
+        "f3d_pflow_levels_registered_inside": [C.c_void_p, C.POINTER(_sz)],
         "f3d_host_shutdown": [],
     }
     for name, args in sig.items():
@@ -808,6 +809,12 @@ class PiecemealOpticalFlow:
         a, b, c = _sz(), _sz(), _sz()
         check(host().f3d_pflow_stats(self._h, C.byref(a), C.byref(b), C.byref(c)), "f3d_pflow_stats")
         return a.value, b.value, c.value
+
+    def levels_registered_inside(self):
+        """host levels of the last compute whose frame 1 was registered inside the solver's first residency"""
+        a = _sz()
+        check(host().f3d_pflow_levels_registered_inside(self._h, C.byref(a)), "f3d_pflow_levels_registered_inside")
+        return a.value
 
     def destroy(self):
         if self._h:

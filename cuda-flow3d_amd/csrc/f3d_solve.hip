@@ -322,7 +322,11 @@ __device__ __forceinline__ float gld(const float* base, unsigned byte_off)
 }
 __device__ __forceinline__ void gst(float* base, unsigned byte_off, float v)
 {
-  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+  // `nt`: the results of a launch are read again by the NEXT launch at the earliest, a whole volume later, so they need not
+  // displace the planes the neighbouring tiles are about to re-read in L2 / the memory-side cache.  Measured, paired, on the
+  // 512^3 solve: -0.7 ... -2.4 % (profiles/r04_store_hint_ab.txt, r04_store_hints.txt; sc1 / sc0 sc1 / nt sc1 do not beat it,
+  // and `nt` on the centre-only DMA LOADS costs 5 %).
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 nt" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void gld_lds(const float* base, unsigned byte_off, float* lds_dst)
 {

@@ -346,6 +346,13 @@ int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_level
   return 0;
 }
 
+int f3d_pflow_levels_registered_inside(f3d_pflow flow, size_t* levels)
+{
+  if (!flow || !levels) return 1;
+  *levels = flow->driver.LastLevelsRegisteredInside();
+  return 0;
+}
+
 int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes)
 {
   if (!flow || !yes) return 1;

@@ -183,6 +183,24 @@ DevicePtr Rebase(DevicePtr p, const ChunkBox& b, int old_base, int new_base)
   return static_cast<DevicePtr>(static_cast<int64_t>(p) + shift);
 }
 
+// largest |value| of a level's sub-box of a host volume (all cores); a NaN anywhere gives infinity: "no bound"
+float HostAbsMax(Data3D& v, size_t w, size_t h, int d)
+{
+  float m = 0.f;
+  const long long rows = static_cast<long long>(h) * d;
+#pragma omp parallel for reduction(max : m) schedule(static)
+  for (long long row = 0; row < rows; ++row) {
+    const float* p = PlanePtr(v, static_cast<int>(row / static_cast<long long>(h))) + static_cast<size_t>(row % static_cast<long long>(h)) * v.Width();
+    float rm = 0.f;
+    for (size_t x = 0; x < w; ++x) {
+      const float a = std::fabs(p[x]);
+      rm = !(a <= rm) ? (a == a ? a : std::numeric_limits<float>::infinity()) : rm;
+    }
+    if (rm > m) m = rm;
+  }
+  return m;
+}
+
 void LowMemory(const char* name)
 {
   std::printf("Operation '%s': Error. Low GPU memory. Data cannot be partitioned properly.\n", name);
@@ -634,6 +652,11 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   last_plan_ = SolvePiecemealPlan();
   last_passes_ = 0;
   last_added_ = false;
+  last_registered_ = false;
+  if (register_frame_1 && registered_frame_1 && (!Fits(*registered_frame_1, data_size) || registered_frame_1 == p_frame_1)) {
+    std::printf("Error: Operation '%s'. Wrong volume for the registered frame.\n", GetName());
+    return;
+  }
   if (W == 0 || H == 0 || D == 0) return;
 
   // The increments start at zero (cuda_operation_solve_p.cpp:152-154); with no sweep to run that is also the result.
@@ -651,6 +674,10 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   for (Data3D* v : {p_frame_0, p_frame_1, p_flow_u, p_flow_v, p_flow_w, p_flow_du, p_flow_dv, p_flow_dw, p_temp_du, p_temp_dv, p_temp_dw}) {
     int yes = 0;
     if (f3d_host_is_pinned(v->DataPtr(), &yes) != 0 || !yes) all_pinned = false;
+  }
+  if (register_frame_1 && registered_frame_1) {
+    int yes = 0;
+    if (f3d_host_is_pinned(registered_frame_1->DataPtr(), &yes) != 0 || !yes) all_pinned = false;
   }
   if (!all_pinned) overlap_mode = 0;
   // The last sweep of an outer iteration and the weights of the next one in ONE launch wherever another outer iteration follows
@@ -677,6 +704,20 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   if (plan.chunk < 1) return LowMemory(GetName());
   const int chunk = plan.chunk, halo = plan.halo, planes = std::min(D, chunk + 2 * halo);
   const int n_sets = plan.overlapped ? 2 : 1;
+
+  // Registration inside the first residency (register_frame_1): frame-1 planes a voxel of plane z reads are z - warp_reach ..
+  // z + warp_reach (registration_3d.cu:46-80), bounded for the whole level by the largest |w| (area resampling and the median do not
+  // raise it, but the volume is right here).  The unregistered planes of a residency's window go into the buffers of temp_du / dv /
+  // dw -- nothing writes them before the first sweep -- in up to three pieces of `planes` planes each, the piece's own reach included;
+  // a reach that leaves less than a third of a buffer for the planes themselves cannot be served that way.
+  const bool registering = register_frame_1;
+  int warp_reach = 0;
+  if (registering) {
+    const float deep = std::ceil(HostAbsMax(*p_flow_w, W, H, D) / hz);
+    warp_reach = (deep == deep && deep < static_cast<float>(D)) ? static_cast<int>(deep) + 1 : D;
+    if (planes < D && 3 * (planes - 2 * warp_reach) < planes) return;   // (planes == D: one piece holds the whole frame)
+  }
+  Data3D* const registered_to = registering ? (registered_frame_1 ? registered_frame_1 : p_flow_du) : nullptr;
 
   enum { F0, F1, FU, FV, FW, DU, DV, DW, PHI, KSI, TDU, TDV, TDW, PHI2, KSI2, kAllFields };
   const int kFields = fuse_weights ? 15 : 13;
@@ -717,8 +758,26 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
         if (CheckDeviceError(f3d_queue_wait_event(q_up, g_pipe.downloaded[set]))) return;
         if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.downloaded[set]))) return;
       }
+      const bool register_here = registering && i0 == 0;
       for (int i = 0; i < 5; ++i)
-        if (!Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo, q_up)) return;
+        if (!(register_here && i == 1) && !Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo, q_up)) return;
+      // the unregistered frame 1 for the window lo .. hi, in pieces: piece p serves the output planes s[p] .. s[p+1] from the frame's
+      // planes in_lo[p] .. (at most `planes` of them) held from plane 0 of its buffer
+      int n_pieces = 0, piece_s[4] = {lo, lo, lo, lo}, piece_in[3] = {0, 0, 0};
+      if (register_here) {
+        for (int s0 = lo; s0 < hi;) {
+          if (n_pieces == 3) return LowMemory(GetName());   // (ruled out above)
+          const int in_lo = std::max(0, s0 - warp_reach);
+          int s1 = hi;
+          if (std::min(D, s1 + warp_reach) - in_lo > planes) s1 = in_lo + planes - warp_reach;
+          if (s1 <= s0) return LowMemory(GetName());
+          const int in_hi = std::min(D, s1 + warp_reach);
+          if (!Upload(buf[TDU + n_pieces], box, 0, *fixed[1], W, H, in_lo, in_hi - in_lo, q_up)) return;
+          piece_in[n_pieces] = in_lo;
+          piece_s[++n_pieces] = s1;
+          s0 = s1;
+        }
+      }
       for (int i = 0; i < 3; ++i) {
         if (i0 == 0) {
           if (CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
@@ -730,6 +789,14 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
         if (CheckDeviceError(f3d_event_record_on(g_pipe.uploaded[set], q_up))) return;
         if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.uploaded[set]))) return;
       }
+      // the registered frame of the window: every operand under the chunk's z_base, the piece's buffer rebased to it
+      for (int p = 0; p < n_pieces; ++p) {
+        const f3d_slab piece = {base, piece_s[p], piece_s[p + 1]};
+        if (CheckDeviceError(f3d_warp(buf[F0], Rebase(buf[TDU + p], box, piece_in[p], base), buf[FU], buf[FV], buf[FW], W, H, D, hx, hy, hz,
+                                      buf[F1], &piece)))
+          return;
+      }
+      const DevicePtr registered_planes = buf[F1];   // (the buffer names below trade places with every sweep; F1 does not)
       // Outer iteration j of this pass leaves the increments valid on the chunk widened by g = (n-1-j)(K+1) planes:
       // phi/ksi on g + K, sweep s on g + K-1-s; a fused pair runs on the window of its second sweep.
       bool weights_ready = false;
@@ -790,6 +857,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       }
       for (int i = 0; i < 3; ++i)
         if (!Download(*next[i], W, H, z0, z1 - z0, buf[DU + i], box, z0 - base, q_down)) return;
+      if (register_here && !Download(*registered_to, W, H, z0, z1 - z0, registered_planes, box, z0 - base, q_down)) return;
       if (plan.overlapped) {
         if (CheckDeviceError(f3d_event_record_on(g_pipe.downloaded[set], q_down))) return;
         set_used[set] = true;
@@ -798,6 +866,14 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     // the pass is complete when its last download is: the next pass reads what this one wrote
     if (plan.overlapped && CheckDeviceError(f3d_queue_sync(q_down))) return;
     if (CheckDeviceError(f3d_stream_sync())) return;
+    if (registering && i0 == 0) {
+      // the registered frame is complete on the host.  In a volume of its own: later residencies read that.  In the storage of
+      // flow_du: "frame_1" takes that storage (it IS the registered frame from here on, as after the registration operator) and the
+      // unregistered frame's storage goes where flow_du's would have gone below -- to temp_du, the next pass's download target.
+      if (registered_frame_1) fixed[1] = registered_frame_1;
+      else p_frame_1->Swap(*inc[0]);
+      last_registered_ = true;
+    }
     for (int i = 0; i < 3; ++i) inc[i]->Swap(*next[i]);
     ++last_passes_;
     if (add_increments_to_flow && i0 + n >= outer) last_added_ = true;

@@ -111,6 +111,20 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   // forms, bit for bit); LastAddedToFlow() says whether it did.  The flow volumes themselves are only read.
   bool add_increments_to_flow = false;
   bool LastAddedToFlow() const { return last_added_; }
+  // The driver's step BEFORE the solve is the registration of frame 1 (cuda_operation_register_p: frame 0, u, v, w and frame 1 go up
+  // per chunk, the registered frame comes down -- and the solver's first residency sends frame 0, u, v, w and the registered frame up
+  // again).  With this set, "frame_1" names the UNREGISTERED frame: the first residency of a chunk brings its planes (widened by the
+  // reach of the flow's w) into the three buffers the first sweep has not written yet, warps on the device into the chunk's frame-1
+  // buffer and sends the registered planes the chunk owns down beside the increments; later residencies read that registered frame.
+  // Five field uploads per level less, same bits (f3d_warp on the same operands).  Where the registered frame goes on the host:
+  // `registered_frame_1` if given ("frame_1" is then only read); otherwise the "frame_1" volume itself holds the registered frame
+  // afterwards, as after the registration operator -- during the first pass it collects in the storage of "flow_du", which idles then,
+  // and the unregistered frame's storage becomes the download target that storage would have been (Data3D::Swap, no copy).
+  // LastRegistered() says whether it happened: a flow whose reach does not leave room in those buffers (or a call that ran no sweep)
+  // returns with nothing done and the caller registers the classical way.
+  bool register_frame_1 = false;
+  Data3D* registered_frame_1 = nullptr;
+  bool LastRegistered() const { return last_registered_; }
   // what the last Execute did (tests and the driver's log)
   const SolvePiecemealPlan& LastPlan() const { return last_plan_; }
   size_t LastPasses() const { return last_passes_; }
@@ -122,6 +136,7 @@ class CudaOperationSolveP : public CudaOperationPiecemealBase {
   size_t last_passes_ = 0;
   bool last_fused_weights_ = false;
   bool last_added_ = false;
+  bool last_registered_ = false;
 };
 
 // The two filters the reference's piecemeal driver leaves out (its median is commented out, optical_flow_p.cpp:268-302, and

@@ -136,6 +136,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   if (!silent) std::printf("\nStarting optical flow computation...\n");
   solve_passes_ = 0;
   streamed_levels_ = 0;
+  levels_registered_inside_ = 0;
   resident_levels_ = 0;
   for (double& t : op_seconds_) t = 0.0;
   auto finish = [&]() {
@@ -277,6 +278,8 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   // step[c] (Data3D::Swap: the caller's objects stay the flow, the solver's pass-to-pass swaps keep to the driver's own volumes); an
   // even number of trades leaves the caller's objects on their own buffers, so with an odd number of host levels the first -- the
   // smallest -- keeps the separate add.  F3D_P_FUSED_ADD=0 keeps it everywhere.
+  const char* fw_env = std::getenv("F3D_P_FUSED_WARP");
+  const bool register_inside_allowed = !(fw_env && fw_env[0] == '0');
   const char* fa_env = std::getenv("F3D_P_FUSED_ADD");
   const bool fuse_add_allowed = !(fa_env && fa_env[0] == '0');
   const int host_levels = current_warp_level + 1;
@@ -313,24 +316,38 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
             {{"input", component}, {"output", component}, {"data_size", &prev_data_size}, {"resample_size", &current_data_size}});
     }
 
-    // 3. frame 1 registered with that flow: the operator writes into spare[0] and trades its storage with level[1], which then
-    //    holds the registered frame (spare[0]: the unregistered one)
-    size_t max_magnitude = static_cast<size_t>(std::ceil(flow_stat.max / warp_scale_factor));
-    run(kRegistration, cuop_register_p_,
-        {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]}, {"temp", spare[0]},
-         {"hx", &hx}, {"hy", &hy}, {"hz", &hz}, {"data_size", &current_data_size}, {"max_mag", &max_magnitude}});
+    // 3. frame 1 registered with that flow.  Inside the solver's first residency where that is possible (register_frame_1: the
+    //    solver has frame 0, u, v, w on the device for the chunk anyway) -- level[1] holds the registered frame afterwards; at the
+    //    finest level, where level[1] is the CALLER's frame 1, the registered frame collects in spare[0] and the caller's is only read.
+    //    Otherwise by the operator, which writes into spare[0] and trades its storage with level[1] (spare[0]: the unregistered one).
+    bool registration_traded_storage = false;
+    auto register_separately = [&]() {
+      size_t max_magnitude = static_cast<size_t>(std::ceil(flow_stat.max / warp_scale_factor));
+      run(kRegistration, cuop_register_p_,
+          {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]}, {"temp", spare[0]},
+           {"hx", &hx}, {"hy", &hy}, {"hz", &hz}, {"data_size", &current_data_size}, {"max_mag", &max_magnitude}});
+      registration_traded_storage = true;
+    };
+    if (!register_inside_allowed) register_separately();
 
     // 4. the increments.  The third ping-pong partner is spare[0] -- except at the finest level, where spare[0] holds the caller's
-    //    unregistered frame 1 (step 6) and the volume the frames were resampled from is free instead
+    //    unregistered frame 1 or the registered one (step 6) and the volume the frames were resampled from is free instead
     Data3D* third_partner = finest ? whole[1] : spare[0];
     cuop_solve_p_.add_increments_to_flow = current_warp_level <= first_fused_level;
-    run(kSolve, cuop_solve_p_,
-        {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]},
-         {"flow_du", step[0]}, {"flow_dv", step[1]}, {"flow_dw", step[2]}, {"temp_du", spare[1]}, {"temp_dv", spare[2]},
-         {"temp_dw", third_partner}, {"outer_iterations_count", &outer_iterations_count},
-         {"inner_iterations_count", &inner_iterations_count}, {"equation_alpha", &equation_alpha},
-         {"equation_smoothness", &equation_smoothness}, {"equation_data", &equation_data}, {"data_size", &current_data_size},
-         {"hx", &hx}, {"hy", &hy}, {"hz", &hz}});
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      cuop_solve_p_.register_frame_1 = !registration_traded_storage;
+      cuop_solve_p_.registered_frame_1 = finest ? spare[0] : nullptr;
+      run(kSolve, cuop_solve_p_,
+          {{"frame_0", level[0]}, {"frame_1", level[1]}, {"flow_u", flow[0]}, {"flow_v", flow[1]}, {"flow_w", flow[2]},
+           {"flow_du", step[0]}, {"flow_dv", step[1]}, {"flow_dw", step[2]}, {"temp_du", spare[1]}, {"temp_dv", spare[2]},
+           {"temp_dw", third_partner}, {"outer_iterations_count", &outer_iterations_count},
+           {"inner_iterations_count", &inner_iterations_count}, {"equation_alpha", &equation_alpha},
+           {"equation_smoothness", &equation_smoothness}, {"equation_data", &equation_data}, {"data_size", &current_data_size},
+           {"hx", &hx}, {"hy", &hy}, {"hz", &hz}});
+      if (registration_traded_storage || cuop_solve_p_.LastRegistered()) break;
+      register_separately();   // the solver declined (a reach too deep for its buffers) and has done nothing: the classical order
+    }
+    if (cuop_solve_p_.LastRegistered()) ++levels_registered_inside_;
     solve_passes_ += cuop_solve_p_.LastPasses();
     if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
 
@@ -345,7 +362,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 
     // 6. At the finest level step 3 traded the CALLER's frame 1 for spare[0]: the caller gets its storage (and its data, which
     //    the registration only read) back.  The reference leaves the registered frame in the caller's volume.
-    if (finest) src_1->Swap(*spare[0]);
+    if (finest && registration_traded_storage) src_1->Swap(*spare[0]);
 
     // 7. median of every component, in place (full pipeline only: commented out in the reference, optical_flow_p.cpp:268-302)
     if (level_median != 1)
@@ -356,6 +373,8 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     prev_data_size = current_data_size;
   }
   cuop_solve_p_.add_increments_to_flow = false;
+  cuop_solve_p_.register_frame_1 = false;
+  cuop_solve_p_.registered_frame_1 = nullptr;
   // The flow must end in the caller's own buffers.  A trade hands the caller's buffer to the driver's volumes, among which the
   // solver's pass-to-pass swaps move it on, so after the last level it may sit in any of them: find it, trade it back and copy the
   // result across (all cores; a fraction of what the saved transfers cost).  Volumes that never left are left alone.

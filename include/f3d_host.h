@@ -124,6 +124,9 @@ int f3d_pflow_compute(f3d_pflow flow, const float* frame_0, const float* frame_1
                       const f3d_flow_params* params, int silent, float* u, float* v, float* w, float* device_seconds);
 /* of the last compute: solver residencies, levels cut into chunks, coarse levels that ran wholly on the device */
 int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_levels, size_t* resident_levels);
+/* of the last compute: host levels whose frame 1 was registered inside the solver's first residency instead of by the separate
+ * registration operator (cuda_operation_register_p.cpp:54-139); F3D_P_FUSED_WARP=0 keeps the operator everywhere */
+int f3d_pflow_levels_registered_inside(f3d_pflow flow, size_t* levels);
 /* whether the resident levels of the last compute resampled their frames from device copies of the two originals */
 int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes);
 /* also apply the Gaussian pre-blur and the per-level median, i.e. OpticalFlowE's whole pipeline on host volumes (off by

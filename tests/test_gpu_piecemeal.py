@@ -273,6 +273,38 @@ def run_p(f3d, f0, f1, resident=True, full=False, **kw):
         flow.destroy()
 
 
+def test_registration_inside_the_first_residency(f3d, monkeypatch):
+    """Frame 1 registered inside the solver's first residency (CudaOperationSolveP::register_frame_1, the driver's default) against the
+    separate registration operator (F3D_P_FUSED_WARP=0): same flow bit for bit, the caller's frames untouched -- on a pair that moves
+    two planes along z (the unregistered planes arrive in several pieces) and on one that moves seven (the reach does not leave room in
+    the chunk buffers of the finest levels: the solver declines there and the driver registers the classical way)."""
+    W, H, D = 40, 36, 48
+    f0, _ = f3d.synth_pair(W, H, D)
+    kw = dict(warp_levels_count=10, outer_iterations_count=4, inner_iterations_count=5)
+    for shift, planes in ((2, 26), (2, 17), (7, 26)):
+        f1 = np.ascontiguousarray(np.roll(f0, shift, axis=0))
+        keep0, keep1 = f0.copy(), f1.copy()
+        set_budget(budget_for(13 * planes, W, H, 13))
+        runs = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("F3D_P_FUSED_WARP", fused)
+            flow = f3d.PiecemealOpticalFlow()
+            flow.initialize(W, H, D)
+            flow.set_resident(False)
+            try:
+                runs[fused] = (flow.compute(f0, f1, silent=True, **kw), flow.levels_registered_inside(), flow.stats())
+            finally:
+                flow.destroy()
+            assert same(f0, keep0) and same(f1, keep1), "the caller's frames must come back unchanged"
+        assert runs["0"][1] == 0 and runs["1"][2][1] >= 2, (shift, planes, runs["0"][1:], runs["1"][1:])
+        assert runs["1"][1] >= (runs["1"][2][1] if shift == 2 else 1), (shift, planes, runs["1"][1:])
+        if shift == 7:
+            assert runs["1"][1] < 10, "the deep reach was expected to make the solver decline on the finest levels"
+        assert np.abs(runs["0"][0][2]).max() > 0.25, "the pair was meant to move along z"
+        for a, b, n in zip(runs["1"][0], runs["0"][0], "uvw"):
+            assert same(a, b), f"shift {shift}, {planes} planes per field, {n}: registration inside the solver differs"
+
+
 def test_driver_matches_oracle_small(f3d, oracle):
     """Whole pyramid on 40x36x32 with a budget that streams the upper levels: equals the oracle's pipeline without blur and
     median, which is what the reference's piecemeal driver computes."""

@@ -88,6 +88,30 @@ CASE = textwrap.dedent('''
         got = flow.compute(f0, f1, silent=True, **kw); passes, streamed, resident = flow.stats(); flow.destroy()
         assert streamed >= 1, (passes, streamed, resident)
         assert all(same(g, e) for g, e in zip(got, (eu, ev, ew))), "OpticalFlowP --full on the host backend differs from the oracle"
+        # frame 1 registered inside the solver's first residency (default) against the separate registration operator, on a pair that
+        # moves along z (a warp reach of several planes: the unregistered frame arrives in more than one piece, or the solver declines
+        # and the driver registers the classical way), with and without the caller's frames surviving
+        W2, H2, D2 = 24, 20, 40
+        g0, _ = pkg.synth_pair(W2, H2, D2)
+        for shift, budget in ((2, "1.3"), (2, "1.0"), (7, "1.3")):
+            g1 = np.ascontiguousarray(np.roll(g0, shift, axis=0))
+            kw3 = dict(warp_levels_count=8, outer_iterations_count=3, inner_iterations_count=5)
+            os.environ["F3D_P_BUDGET_MB"] = budget
+            runs = {}
+            for fused in ("1", "0"):
+                os.environ["F3D_P_FUSED_WARP"] = fused
+                a0, a1 = g0.copy(), g1.copy()
+                flow = pkg.PiecemealOpticalFlow(); flow.initialize(W2, H2, D2)
+                runs[fused] = (flow.compute(a0, a1, silent=True, **kw3), flow.levels_registered_inside(), flow.stats())
+                flow.destroy()
+                assert same(a0, g0) and same(a1, g1), "the out-of-core driver changed the caller's frames"
+            del os.environ["F3D_P_FUSED_WARP"]
+            assert runs["0"][1] == 0 and runs["1"][2][1] >= 1, (shift, budget, runs["0"][1:], runs["1"][1:])
+            if shift == 2:
+                assert runs["1"][1] >= 1, (shift, budget, runs["1"][1:])
+            assert np.abs(runs["0"][0][2]).max() > 0.3 * shift / 7
+            assert all(same(a, b) for a, b in zip(runs["1"][0], runs["0"][0])), (shift, budget, "registration inside the solver differs")
+            print(f"piecemeal shift {shift} budget {budget} MB: {runs['1'][1]} level(s) registered inside, stats {runs['1'][2]}")
     elif what == "reinit":
         # a solve operator initialised twice WITHOUT Destroy in between, the second time for a bigger container: the second weight
         # pair of the fused last sweep must follow the container (under the sanitizers a stale, smaller buffer is a heap overflow),
