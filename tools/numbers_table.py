@@ -83,6 +83,14 @@ def rows():
             out.append(("out-of-core `OpticalFlowP`, 1024³ on a 16 GB budget (`tools/pbench.py`; same bits as the resident driver)",
                         f"{float(secs[1]):.2f} s with the flow update inside the solver's last residency, {float(secs[0]):.2f} s with the separate "
                         f"add operator (round 3: 46.8 s)", os.path.relpath(f, ROOT)))
+    f = P("piecemeal_1024_16gb_registration.txt")
+    if os.path.exists(f):
+        import re
+        secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
+        if len(secs) >= 2:
+            out.append(("... and with frame 1 registered inside the solver's first residency as well",
+                        f"**{float(secs[1]):.2f} s**; with the separate registration operator {float(secs[0]):.2f} s (same call)",
+                        os.path.relpath(f, ROOT)))
     f = P("thin_tile_solves.txt")
     if os.path.exists(f):
         import re
