@@ -903,12 +903,14 @@ inline Pair8Plan pair8_plan_dims(int width, int rows, int planes, int ty, int zc
 {
   const long tiles = static_cast<long>((width + kLanes - 1) / kLanes) * ((rows + ty - 1) / ty);
   const int max_chunks = planes > 0 ? planes : 1;  // down to one plane per chunk: three steps instead of four where one round covers it
+  // what a chunk costs beside its planes, in plane steps (F3D_PAIR8_CHUNK_STEPS: launch-geometry experiments)
+  static const int extra = std::getenv("F3D_PAIR8_CHUNK_STEPS") ? std::atoi(std::getenv("F3D_PAIR8_CHUNK_STEPS")) : 7;
   Pair8Plan p = {std::min(planes, zc_limit), -1};
   for (int nzc = 1; nzc <= max_chunks; ++nzc) {
     const int zc = (planes + nzc - 1) / nzc;
     if (zc > zc_limit) continue;
     const long wgs = tiles * ((planes + zc - 1) / zc);
-    const long cost = ((wgs + per_round - 1) / per_round) * (zc + 7);
+    const long cost = ((wgs + per_round - 1) / per_round) * (zc + extra);
     if (p.cost < 0 || cost < p.cost) {
       p.cost = cost;
       p.zchunk = zc;
@@ -916,7 +918,7 @@ inline Pair8Plan pair8_plan_dims(int width, int rows, int planes, int ty, int zc
     }
   }
   if (p.cost < 0) {
-    p.cost = static_cast<long>((tiles + per_round - 1) / per_round) * (p.zchunk + 7);
+    p.cost = static_cast<long>((tiles + per_round - 1) / per_round) * (p.zchunk + extra);
     p.wgs = tiles;
   }
   return p;
