@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "common_utils.h"
 #include "operator_calls.h"
@@ -129,6 +130,22 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     src_1 = &blur_1;
   }
 
+  // Host scratch of the levels that go through the host: eight volumes of the original size (the reference keeps ten: phi and ksi stay
+  // on the device here).  Where coarse levels run on the device first, a helper thread allocates and page-locks them MEANWHILE -- 34 GB
+  // at 1024^3, 1.9 s that the host thread otherwise spends between the resident levels and the first host level with the device idle.
+  Data3D scratch[8];
+  bool scratch_ok = true;
+  std::thread scratch_thread;
+  auto prepare_scratch = [&]() {
+    for (Data3D& v : scratch) {
+      if (!v.Allocate(W0, H0, D0)) {
+        scratch_ok = false;
+        return;
+      }
+      pin_volume(&v);
+    }
+  };
+
   f3d_event ev_start = nullptr, ev_stop = nullptr;
   CheckDeviceError(f3d_event_create(&ev_start));
   CheckDeviceError(f3d_event_create(&ev_stop));
@@ -140,6 +157,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   resident_levels_ = 0;
   for (double& t : op_seconds_) t = 0.0;
   auto finish = [&]() {
+    if (scratch_thread.joinable()) scratch_thread.join();   // (it appends to `pinned`)
     float elapsed_time = 0.f;
     CheckDeviceError(f3d_event_record(ev_stop));
     CheckDeviceError(f3d_event_sync(ev_stop));
@@ -206,6 +224,12 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     const int last = last_plain;
     originals_on_device_ = false;
     if (last <= current_warp_level) {
+      const char* bg_env = std::getenv("F3D_P_SCRATCH_THREAD");
+      if (last > 0 && !(bg_env && bg_env[0] == '0'))   // host levels will follow: their scratch gets ready beside these
+        scratch_thread = std::thread([&]() {
+          f3d_lane_make_current(nullptr);   // (binds the library's device to this thread; registration itself is lane-agnostic)
+          prepare_scratch();
+        });
       const auto t0 = std::chrono::steady_clock::now();
       bool ok = true;
       DataSize4 carried = {0, 0, 0, 0};
@@ -237,10 +261,15 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   }
 
   // ---- the remaining levels go through the host --------------------------------------------------------------------
-  // Host scratch: eight volumes of the original size (the reference keeps ten: phi and ksi stay on the device here).
   if (!silent) {
     std::printf("Allocating additional memory on the host...\n");
     std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * volume_bytes / (1024.f * 1024.f));
+  }
+  if (scratch_thread.joinable()) scratch_thread.join();
+  else prepare_scratch();
+  if (!scratch_ok) {
+    finish();
+    return;
   }
   // Roles of the host volumes in a level (the operator keys they are bound to are the reference's, optical_flow_p.cpp:152-266):
   //   whole[2]    the two frames at the original size (the caller's, or their blurred copies) -- resampled FROM at every level
@@ -248,14 +277,6 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   //   flow[3]     u, v, w: the caller's volumes, resampled in place from level to level
   //   step[3]     the solver's increments du, dv, dw
   //   spare[3]    scratch: the registration's output, two (three) of the solver's ping-pong partners
-  Data3D scratch[8];
-  for (Data3D& v : scratch) {
-    if (!v.Allocate(W0, H0, D0)) {
-      finish();
-      return;
-    }
-    pin_volume(&v);
-  }
   Data3D* whole[2] = {src_0, src_1};
   Data3D* level[2] = {&scratch[0], &scratch[1]};
   Data3D* flow[3] = {&flow_u, &flow_v, &flow_w};
