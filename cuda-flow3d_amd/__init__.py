@@ -241,6 +241,7 @@ def host():
         "f3d_pflow_set_resident": [C.c_void_p, C.c_int], "f3d_pflow_set_full_pipeline": [C.c_void_p, C.c_int], "f3d_pflow_originals_on_device": [C.c_void_p, C.POINTER(C.c_int)],
         "f3d_pflow_operator_seconds": [C.c_void_p, C.POINTER(C.c_double)],
         "f3d_pflow_levels_registered_inside": [C.c_void_p, C.POINTER(_sz)],
+        "f3d_pflow_levels_with_constants_on_device": [C.c_void_p, C.POINTER(_sz)],
         "f3d_host_shutdown": [],
     }
     for name, args in sig.items():
@@ -814,6 +815,12 @@ class PiecemealOpticalFlow:
         """host levels of the last compute whose frame 1 was registered inside the solver's first residency"""
         a = _sz()
         check(host().f3d_pflow_levels_registered_inside(self._h, C.byref(a)), "f3d_pflow_levels_registered_inside")
+        return a.value
+
+    def levels_with_constants_on_device(self):
+        """host levels of the last compute whose solver held the frames and u, v, w on the device for the whole level"""
+        a = _sz()
+        check(host().f3d_pflow_levels_with_constants_on_device(self._h, C.byref(a)), "f3d_pflow_levels_with_constants_on_device")
         return a.value
 
     def destroy(self):

@@ -353,6 +353,13 @@ int f3d_pflow_levels_registered_inside(f3d_pflow flow, size_t* levels)
   return 0;
 }
 
+int f3d_pflow_levels_with_constants_on_device(f3d_pflow flow, size_t* levels)
+{
+  if (!flow || !levels) return 1;
+  *levels = flow->driver.LastLevelsWithConstantsOnDevice();
+  return 0;
+}
+
 int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes)
 {
   if (!flow || !yes) return 1;

@@ -244,7 +244,8 @@ namespace {
 // ~50 GB/s each way (eight fields up with their halos, three down, per pass) and device bytes at ~5 TB/s (300 B per voxel
 // and outer iteration on windows that average chunk + halo planes).  Serial: the three add up.  Overlapped (two chunk
 // sets, half the planes each): the slowest of the three, plus the other two once per level for filling the pipeline.
-SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_iterations, int forced, bool overlapped)
+SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_iterations, int forced, bool overlapped,
+                                double fields_up = 8.0)
 {
   SolvePiecemealPlan plan;
   plan.max_planes = max_planes;
@@ -256,7 +257,7 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
     if (chunk < 1) break;
     const double passes = std::ceil(static_cast<double>(outer_iterations) / n);
     const double wide = static_cast<double>(chunk + 2 * halo) / chunk, mid = static_cast<double>(chunk + halo) / chunk;
-    const double up = passes * 8.0 * wide * 4.0 / 50e9, down = passes * 3.0 * 4.0 / 50e9;
+    const double up = passes * fields_up * wide * 4.0 / 50e9, down = passes * 3.0 * 4.0 / 50e9;
     const double device = outer_iterations * 300.0 * mid / 5e12;
     double cost = up + down + device;
     if (overlapped) {
@@ -277,11 +278,31 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
 }  // namespace
 
 SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode, int fields)
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode, int fields, int constant_fields)
 {
   SolvePiecemealPlan plan;
   const ChunkBox box(width, height);
   const size_t cap = static_cast<size_t>(std::numeric_limits<int>::max());
+  if (constant_fields > 0) {
+    // whole-level fields beside the chunk sets: what is left of the budget is planned as before, with fewer fields per set and fewer
+    // fields up per residency; the one upload of the constants is added to the cost
+    plan.constants_on_device = true;
+    const size_t held = static_cast<size_t>(constant_fields) * box.FieldBytes(static_cast<size_t>(std::max(depth, 0)));
+    if (depth <= 0 || outer_iterations <= 0 || held >= budget_bytes) return plan;
+    const size_t nf = static_cast<size_t>(fields), left = budget_bytes - held;
+    const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(left, nf) / nf, cap));
+    const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(left, 2 * nf) / (2 * nf), cap));
+    if (serial_planes >= depth) return plan;   // (a level that fits whole is one residency anyway: nothing to keep)
+    const int step = inner_iterations + 1;
+    const double up = 8.0 - constant_fields;
+    SolvePiecemealPlan serial = PlanSchedule(serial_planes, depth, step, outer_iterations, forced_outer_per_pass, false, up);
+    SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true, up);
+    SolvePiecemealPlan best = overlap_mode == 0 ? serial : overlap_mode == 1 ? overlapped
+                              : (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
+    best.constants_on_device = true;
+    best.cost += constant_fields * 4.0 / 50e9;
+    return best;
+  }
   // 13 fields per chunk set (eight inputs, phi, ksi, three outputs), 15 with the second weight pair of the fused last sweep
   const size_t nf = static_cast<size_t>(fields);
   const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf) / nf, cap));
@@ -464,59 +485,106 @@ bool CudaOperationResampleP::Run(Data3D* input, DevicePtr src_dev, size_t src_pi
 
   // Buffers per chunk of `c` output planes that read `s` source planes: source, x pass, x+y pass (s planes each), result
   // (c planes), all in one container geometry that holds both boxes.
+  // Host volume to host volume on page-locked memory (the driver's frames and flow components): TWO such buffer sets and the solver's
+  // copy queues -- the upload of chunk k+1 runs beside the kernels and the download of chunk k.  A level's resampling is link time
+  // (the source planes up, the result down, a few kernel passes in between); in order on one stream the two directions add up.
+  // F3D_P_OVERLAP=0 keeps the one-stream order.
   const ChunkBox box(std::max(Wi, Wo), std::max(Hi, Ho));
-  const size_t total = box.TotalPlanes(PiecemealBudgetBytes(), 4);
-  auto source_of = [&](int z0, int z1) { return ResampleSourcePlanes(Di, Do, PlaneRange{z0, z1}); };
-  auto fits = [&](int c) {
-    size_t worst = 0;
-    for (int z0 = 0; z0 < Do; z0 += c) worst = std::max<size_t>(worst, source_of(z0, std::min(Do, z0 + c)).size());
-    return 3 * worst + static_cast<size_t>(c) <= total;
-  };
-  int chunk = Do;
-  if (!fits(chunk)) {  // largest chunk that fits, by bisection (the source span grows with the chunk)
-    int lo = 0, hi = Do;
-    while (hi - lo > 1) {
-      const int mid = lo + (hi - lo) / 2;
-      (fits(mid) ? lo : hi) = mid;
-    }
-    chunk = lo;
+  bool overlapped = input && output;
+  if (overlapped) {
+    const char* e = std::getenv("F3D_P_OVERLAP");
+    int a = 0, b = 0;
+    overlapped = !(e && std::atoi(e) == 0) && f3d_host_is_pinned(input->DataPtr(), &a) == 0 && a &&
+                 f3d_host_is_pinned(output->DataPtr(), &b) == 0 && b && PipelineReady();
   }
+  auto source_of = [&](int z0, int z1) { return ResampleSourcePlanes(Di, Do, PlaneRange{z0, z1}); };
+  auto chunk_for = [&](size_t total) {
+    auto fits = [&](int c) {
+      size_t worst = 0;
+      for (int z0 = 0; z0 < Do; z0 += c) worst = std::max<size_t>(worst, source_of(z0, std::min(Do, z0 + c)).size());
+      return 3 * worst + static_cast<size_t>(c) <= total;
+    };
+    int chunk = Do;
+    if (!fits(chunk)) {  // largest chunk that fits, by bisection (the source span grows with the chunk)
+      int lo = 0, hi = Do;
+      while (hi - lo > 1) {
+        const int mid = lo + (hi - lo) / 2;
+        (fits(mid) ? lo : hi) = mid;
+      }
+      chunk = lo;
+    }
+    return chunk;
+  };
+  int chunk = 0;
+  if (overlapped) {
+    // at least eight chunks where the budget would take the level in fewer: the first upload and the last download are the part that
+    // nothing runs beside.  (Two sets that do not fit, or a level of a few planes, fall back to one set.)
+    chunk = std::min(chunk_for(box.TotalPlanes(PiecemealBudgetBytes(), 8) / 2), std::max(1, (Do + 7) / 8));
+    if (chunk < 1 || (Do + chunk - 1) / chunk < 3) overlapped = false;
+  }
+  if (!overlapped) chunk = chunk_for(box.TotalPlanes(PiecemealBudgetBytes(), 4));
   if (chunk < 1) {
     LowMemory(GetName());
     return false;
   }
+  const int n_sets = overlapped ? 2 : 1;
   size_t span = 0;
   for (int z0 = 0; z0 < Do; z0 += chunk) span = std::max<size_t>(span, source_of(z0, std::min(Do, z0 + chunk)).size());
-  Carver buf(box);
-  for (int i = 0; i < 3; ++i) buf.Add(span);
-  buf.Add(chunk);
-  if (!buf.Commit()) return false;
+  Carver carve(box);
+  for (int s = 0; s < n_sets; ++s) {
+    for (int i = 0; i < 3; ++i) carve.Add(span);
+    carve.Add(chunk);
+  }
+  if (!carve.Commit()) return false;
   ContainerScope scope(box, std::max<size_t>(span, chunk));
   if (!scope.ok()) return false;
+  const f3d_queue q_up = overlapped ? g_pipe.up : nullptr, q_down = overlapped ? g_pipe.down : nullptr;
+  bool set_used[2] = {false, false};
 
   // In place (input == output) a chunk's result lands on host planes [z0, z1) of the volume it is read from.  Going up
   // in z is safe when the depth shrinks or stays (later chunks read planes >= floor(z1 * delta) >= z1), going down when
-  // it grows (earlier chunks read planes < ceil(z0 * delta) <= z0).
+  // it grows (earlier chunks read planes < ceil(z0 * delta) <= z0) -- with the copies of neighbouring chunks in flight at
+  // the same time as well: the planes one chunk writes and the planes a later chunk reads never meet.
   const int n_chunks = (Do + chunk - 1) / chunk;
   const bool descending = Do > Di;
   for (int k = 0; k < n_chunks; ++k) {
     const int z0 = (descending ? n_chunks - 1 - k : k) * chunk, z1 = std::min(Do, z0 + chunk);
     const PlaneRange src = source_of(z0, z1);
     const f3d_slab in_slab = {src.lo, src.lo, src.hi}, out_slab = {z0, z0, z1};
+    const int set = overlapped ? (k & 1) : 0;
+    const DevicePtr b_src = carve[4 * set], b_x = carve[4 * set + 1], b_xy = carve[4 * set + 2], b_out = carve[4 * set + 3];
+    if (overlapped && set_used[set]) {
+      // the set's previous chunk must have left: its result is still being read by the download queue
+      if (CheckDeviceError(f3d_queue_wait_event(q_up, g_pipe.downloaded[set]))) return false;
+      if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.downloaded[set]))) return false;
+    }
     if (input) {
-      if (!Upload(buf[0], box, 0, *input, Wi, Hi, src.lo, src.size())) return false;
-    } else if (CheckDeviceError(f3d_copy_rect_d2d(buf[0], box.pitch, box.H, 0, src_dev, src_pitch, src_rows, src.lo, Wi, Hi, src.size()))) {
+      if (!Upload(b_src, box, 0, *input, Wi, Hi, src.lo, src.size(), q_up)) return false;
+    } else if (CheckDeviceError(f3d_copy_rect_d2d(b_src, box.pitch, box.H, 0, src_dev, src_pitch, src_rows, src.lo, Wi, Hi, src.size()))) {
       return false;
     }
-    if (CheckDeviceError(f3d_resample_x(buf[0], buf[1], Wo, Hi, Di, Wi, &in_slab))) return false;
-    if (CheckDeviceError(f3d_resample_y(buf[1], buf[2], Wo, Ho, Di, Hi, &in_slab))) return false;
-    if (CheckDeviceError(f3d_resample_z(buf[2], buf[3], Wo, Ho, Do, Di, &in_slab, &out_slab))) return false;
+    if (overlapped) {
+      if (CheckDeviceError(f3d_event_record_on(g_pipe.uploaded[set], q_up))) return false;
+      if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.uploaded[set]))) return false;
+    }
+    if (CheckDeviceError(f3d_resample_x(b_src, b_x, Wo, Hi, Di, Wi, &in_slab))) return false;
+    if (CheckDeviceError(f3d_resample_y(b_x, b_xy, Wo, Ho, Di, Hi, &in_slab))) return false;
+    if (CheckDeviceError(f3d_resample_z(b_xy, b_out, Wo, Ho, Do, Di, &in_slab, &out_slab))) return false;
+    if (overlapped) {
+      if (CheckDeviceError(f3d_event_record_on(g_pipe.computed[set], nullptr))) return false;
+      if (CheckDeviceError(f3d_queue_wait_event(q_down, g_pipe.computed[set]))) return false;
+    }
     if (output) {
-      if (!Download(*output, Wo, Ho, z0, z1 - z0, buf[3], box, 0)) return false;
-    } else if (CheckDeviceError(f3d_copy_rect_d2d(dst, dst_pitch, dst_rows, z0, buf[3], box.pitch, box.H, 0, Wo, Ho, z1 - z0))) {
+      if (!Download(*output, Wo, Ho, z0, z1 - z0, b_out, box, 0, q_down)) return false;
+    } else if (CheckDeviceError(f3d_copy_rect_d2d(dst, dst_pitch, dst_rows, z0, b_out, box.pitch, box.H, 0, Wo, Ho, z1 - z0))) {
       return false;
+    }
+    if (overlapped) {
+      if (CheckDeviceError(f3d_event_record_on(g_pipe.downloaded[set], q_down))) return false;
+      set_used[set] = true;
     }
   }
+  if (overlapped && CheckDeviceError(f3d_queue_sync(q_down))) return false;
   return !CheckDeviceError(f3d_stream_sync());
 }
 
@@ -699,6 +767,19 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     fuse_weights = false;
     plan = make_plan(13);
   }
+  // A level that goes through in chunks sends eight fields up per residency, and five of them -- the two frames, u, v, w -- are the
+  // same every time.  Where the budget holds those five for the WHOLE level beside (smaller) chunk sets of the other eight, they go up
+  // once, in the first pass, and a residency moves three fields up and three down; the model prices both layouts (deeper relative
+  // halos and more residencies against five fields less per residency).  F3D_P_CONSTANTS=0 keeps every field in the chunk sets.
+  const char* kc_env = std::getenv("F3D_P_CONSTANTS");
+  if (plan.chunk >= 1 && plan.halo > 0 && !(kc_env && kc_env[0] == '0')) {
+    const int set_fields = fuse_weights ? 10 : 8;
+    SolvePiecemealPlan kept = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode, set_fields, 5);
+    if (kept.overlapped && !PipelineReady()) kept = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0, set_fields, 5);
+    const bool force = kc_env && kc_env[0] == '1';
+    if (kept.chunk >= 1 && kept.halo > 0 && (kept.cost < plan.cost || force) && !(fuse_weights && kept.outer_per_pass < 2)) plan = kept;
+  }
+  const bool constants = plan.constants_on_device && plan.chunk >= 1;
   last_plan_ = plan;
   last_fused_weights_ = fuse_weights;
   if (plan.chunk < 1) return LowMemory(GetName());
@@ -723,13 +804,16 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   const int kFields = fuse_weights ? 15 : 13;
   const ChunkBox box(W, H);
   Carver carve(box);
-  for (int i = 0; i < n_sets * kFields; ++i) carve.Add(planes);
+  const int kConstants = constants ? 5 : 0;   // F0 .. FW hold the whole level (plane z at plane z), once for all chunk sets
+  for (int i = 0; i < kConstants; ++i) carve.Add(static_cast<size_t>(D));
+  for (int i = 0; i < n_sets * (kFields - kConstants); ++i) carve.Add(planes);
   if (!carve.Commit()) return;
   ContainerScope scope(box, planes);
   if (!scope.ok()) return;
   DevicePtr sets[2][kAllFields] = {};
   for (int s = 0; s < n_sets; ++s)
-    for (int i = 0; i < kFields; ++i) sets[s][i] = carve[s * kFields + i];
+    for (int i = kConstants; i < kFields; ++i) sets[s][i] = carve[kConstants + s * (kFields - kConstants) + (i - kConstants)];
+  int constants_up_to = 0, registered_up_to = 0;   // planes of the whole-level fields that have arrived / been registered so far
   // Serial: copies and kernels in order on the library stream.  Overlapped: uploads on one queue, downloads on another,
   // kernels on the library stream; a chunk set is reused once the download of its previous chunk has finished.
   const f3d_queue q_up = plan.overlapped ? g_pipe.up : nullptr, q_down = plan.overlapped ? g_pipe.down : nullptr;
@@ -759,13 +843,24 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
         if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.downloaded[set]))) return;
       }
       const bool register_here = registering && i0 == 0;
-      for (int i = 0; i < 5; ++i)
-        if (!(register_here && i == 1) && !Upload(buf[F0 + i], box, lo - base, *fixed[i], W, H, lo, hi - lo, q_up)) return;
+      // the fields that do not change: the window of this residency into the chunk set -- or, held for the whole level, the planes
+      // that have not arrived yet, in the first pass only (the chunks go up in z; a whole-level buffer is addressed like a chunk
+      // buffer through a pointer under which its plane z sits at container plane z - base)
+      if (constants)
+        for (int i = 0; i < 5; ++i) buf[F0 + i] = Rebase(carve[i], box, 0, base);
+      const int c_lo = constants ? std::max(lo, constants_up_to) : lo;
+      if (!constants || i0 == 0) {
+        for (int i = 0; i < 5; ++i)
+          if (!(register_here && i == 1) && hi > c_lo && !Upload(buf[F0 + i], box, c_lo - base, *fixed[i], W, H, c_lo, hi - c_lo, q_up)) return;
+        if (constants) constants_up_to = std::max(constants_up_to, hi);
+      }
       // the unregistered frame 1 for the window lo .. hi, in pieces: piece p serves the output planes s[p] .. s[p+1] from the frame's
       // planes in_lo[p] .. (at most `planes` of them) held from plane 0 of its buffer
-      int n_pieces = 0, piece_s[4] = {lo, lo, lo, lo}, piece_in[3] = {0, 0, 0};
+      const int r_lo = constants ? std::max(lo, registered_up_to) : lo;   // (held for the whole level: only what is not registered yet)
+      int n_pieces = 0, piece_s[4] = {r_lo, r_lo, r_lo, r_lo}, piece_in[3] = {0, 0, 0};
       if (register_here) {
-        for (int s0 = lo; s0 < hi;) {
+        if (constants) registered_up_to = std::max(registered_up_to, hi);
+        for (int s0 = r_lo; s0 < hi;) {
           if (n_pieces == 3) return LowMemory(GetName());   // (ruled out above)
           const int in_lo = std::max(0, s0 - warp_reach);
           int s1 = hi;

@@ -37,12 +37,18 @@ struct SolvePiecemealPlan {
   int max_planes = 0;       // planes of one field the budget allows (per chunk set when overlapped)
   bool overlapped = false;  // two chunk sets: upload of the next and download of the previous chunk beside the kernels
   double cost = 0.0;        // the model's seconds per owned voxel
+  // the fields that do not change during a level's solve (the two frames, u, v, w) hold the WHOLE level on the device beside the chunk
+  // sets and go up once instead of once per residency (three fields up per residency instead of eight)
+  bool constants_on_device = false;
 };
 // Pure host arithmetic (CPU-testable).  forced_outer_per_pass > 0 pins n (F3D_P_OUTER_PER_PASS); overlap_mode 0 / 1 pins
 // the serial / overlapped schedule, anything else lets the cost model choose (F3D_P_OVERLAP); chunk == 0 means the budget
 // cannot hold even one plane with its halo.
+// `constant_fields` > 0 prices the layout with that many whole-level fields held on the device (`fields` then counts what a chunk set
+// still holds: 8, or 10 with the second weight pair): their bytes come off the budget, their upload is paid once.
 SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t height, int depth, int inner_iterations,
-                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode = -1, int fields = 13);
+                                      int outer_iterations, int forced_outer_per_pass, int overlap_mode = -1, int fields = 13,
+                                      int constant_fields = 0);
 
 class CudaOperationPiecemealBase : public CudaOperationBase {
  public:

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 #include "common_utils.h"
 #include "operator_calls.h"
@@ -103,15 +105,21 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   std::vector<void*> pinned;
   const char* pin_env = std::getenv("F3D_P_PIN");
   const bool pin = pin_host_memory && !(pin_env && pin_env[0] == '0');
+  std::mutex pinned_lock;
   auto pin_volume = [&](Data3D* v) {
     if (!pin) return;
     if (f3d_host_register(v->DataPtr(), volume_bytes) == 0) {
+      std::lock_guard<std::mutex> hold(pinned_lock);
       pinned.push_back(v->DataPtr());
     } else if (!silent) {
       std::printf("'%s': host memory could not be page-locked (%s); copies will be staged.\n", GetName(), f3d_last_error());
     }
   };
-  for (Data3D* v : {&frame_0, &frame_1, &flow_u, &flow_v, &flow_w}) pin_volume(v);
+  // (one after the other: four or eight ranges at once on worker threads made a 1024^3 run 0.6 / 1.0 s SLOWER, profiles/r04_piecemeal_host_side.txt)
+  auto pin_volumes = [&](std::vector<Data3D*> volumes) {
+    for (Data3D* v : volumes) pin_volume(v);
+  };
+  pin_volumes({&frame_0, &frame_1, &flow_u, &flow_v, &flow_w});
 
   // Full pipeline: the pyramid reads Gaussian-blurred copies of the two frames (optical_flow_e.cpp:213-242), made here chunk
   // by chunk into two more host volumes; the caller's frames are only read.
@@ -124,8 +132,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       for (void* p : pinned) f3d_host_unregister(p);
       return;
     }
-    pin_volume(&blur_0);
-    pin_volume(&blur_1);
+    pin_volumes({&blur_0, &blur_1});
     src_0 = &blur_0;
     src_1 = &blur_1;
   }
@@ -137,13 +144,15 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   bool scratch_ok = true;
   std::thread scratch_thread;
   auto prepare_scratch = [&]() {
+    std::vector<Data3D*> all;
     for (Data3D& v : scratch) {
       if (!v.Allocate(W0, H0, D0)) {
         scratch_ok = false;
         return;
       }
-      pin_volume(&v);
+      all.push_back(&v);
     }
+    pin_volumes(all);
   };
 
   f3d_event ev_start = nullptr, ev_stop = nullptr;
@@ -154,6 +163,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   solve_passes_ = 0;
   streamed_levels_ = 0;
   levels_registered_inside_ = 0;
+  levels_with_constants_ = 0;
   resident_levels_ = 0;
   for (double& t : op_seconds_) t = 0.0;
   auto finish = [&]() {
@@ -369,6 +379,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       register_separately();   // the solver declined (a reach too deep for its buffers) and has done nothing: the classical order
     }
     if (cuop_solve_p_.LastRegistered()) ++levels_registered_inside_;
+    if (cuop_solve_p_.LastPlan().constants_on_device && cuop_solve_p_.LastPasses() > 0) ++levels_with_constants_;
     solve_passes_ += cuop_solve_p_.LastPasses();
     if (cuop_solve_p_.LastPlan().halo > 0) ++streamed_levels_;
 

@@ -32,6 +32,8 @@ class OpticalFlowP : public OpticalFlowBase {
   size_t LastStreamedLevels() const { return streamed_levels_; }
   // host levels whose frame 1 was registered inside the solver's first residency (CudaOperationSolveP::register_frame_1; F3D_P_FUSED_WARP=0: none)
   size_t LastLevelsRegisteredInside() const { return levels_registered_inside_; }
+  // host levels whose solver kept the two frames and u, v, w on the device for the whole level (SolvePiecemealPlan::constants_on_device)
+  size_t LastLevelsWithConstantsOnDevice() const { return levels_with_constants_; }
   // coarse levels of the last ComputeFlow that ran entirely on the device (see resident_coarse_levels)
   size_t LastResidentLevels() const { return resident_levels_; }
   // whether the coarsest of those levels resampled their frames from device copies of the two originals (phase A)
@@ -57,7 +59,7 @@ class OpticalFlowP : public OpticalFlowBase {
                          int first_level, int last_level, size_t container_bytes, bool originals_on_device,
                          const DataSize4& carried_flow_size, size_t median_radius);
 
-  size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0, levels_registered_inside_ = 0;
+  size_t solve_passes_ = 0, streamed_levels_ = 0, resident_levels_ = 0, levels_registered_inside_ = 0, levels_with_constants_ = 0;
   bool originals_on_device_ = false;
   double op_seconds_[6] = {0, 0, 0, 0, 0, 0};
 

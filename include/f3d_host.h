@@ -127,6 +127,9 @@ int f3d_pflow_stats(f3d_pflow flow, size_t* solve_passes, size_t* streamed_level
 /* of the last compute: host levels whose frame 1 was registered inside the solver's first residency instead of by the separate
  * registration operator (cuda_operation_register_p.cpp:54-139); F3D_P_FUSED_WARP=0 keeps the operator everywhere */
 int f3d_pflow_levels_registered_inside(f3d_pflow flow, size_t* levels);
+/* of the last compute: host levels whose solver held the two frames and u, v, w on the device for the whole level beside the chunk sets
+ * (three fields up per residency instead of eight; chosen by the cost model, F3D_P_CONSTANTS=0 / 1 pins it) */
+int f3d_pflow_levels_with_constants_on_device(f3d_pflow flow, size_t* levels);
 /* whether the resident levels of the last compute resampled their frames from device copies of the two originals */
 int f3d_pflow_originals_on_device(f3d_pflow flow, int* yes);
 /* also apply the Gaussian pre-blur and the per-level median, i.e. OpticalFlowE's whole pipeline on host volumes (off by

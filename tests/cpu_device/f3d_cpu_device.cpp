@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "f3d.h"
@@ -195,10 +196,22 @@ int f3d_copy_rect_d2d(f3d_devptr dst, size_t dst_pitch, size_t dst_rows, size_t 
       std::memcpy(d + ((dst_plane0 + z) * dst_rows + y) * dst_pitch, s + ((src_plane0 + z) * src_rows + y) * src_pitch, width * sizeof(float));
   return 0;
 }
-int f3d_host_register(void* ptr, size_t bytes) { g_pinned[ptr] = bytes; return 0; }
-int f3d_host_unregister(void* ptr) { return g_pinned.erase(ptr) ? 0 : fail("f3d_host_unregister: not registered"); }
+// (the out-of-core driver registers its scratch volumes from a helper thread while the main thread works)
+static std::mutex g_pinned_lock;
+int f3d_host_register(void* ptr, size_t bytes)
+{
+  std::lock_guard<std::mutex> hold(g_pinned_lock);
+  g_pinned[ptr] = bytes;
+  return 0;
+}
+int f3d_host_unregister(void* ptr)
+{
+  std::lock_guard<std::mutex> hold(g_pinned_lock);
+  return g_pinned.erase(ptr) ? 0 : fail("f3d_host_unregister: not registered");
+}
 int f3d_host_is_pinned(const void* ptr, int* yes)
 {
+  std::lock_guard<std::mutex> hold(g_pinned_lock);
   *yes = 0;
   for (auto& p : g_pinned)
     if (static_cast<const char*>(ptr) >= static_cast<const char*>(p.first) &&

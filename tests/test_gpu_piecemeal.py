@@ -102,6 +102,24 @@ def test_resample_matches_oracle(f3d, oracle, in_dims, out_dims, planes):
     vio = f3d.HostVolume(src.copy())
     op.execute(input=vio, output=vio, data_size=in_dims, resample_size=out_dims)
     assert same(vio.array[:od, :oh, :ow], expect[:od, :oh, :ow])
+    # page-locked volumes: two buffer sets, the upload of the next chunk beside the kernels and the download of this one (three chunks
+    # and more; the same planes in total now make two sets of half the size).  Separate output and in place; F3D_P_OVERLAP=0 = in order.
+    for planes2, overlap in ((planes, None), (2 * planes, None), (2 * planes, "0")):
+        set_budget(budget_for(planes2, wc, hc, 8))
+        if overlap is not None:
+            os.environ["F3D_P_OVERLAP"] = overlap
+        try:
+            pin, pout = f3d.HostVolume(src.copy(), pin=True), f3d.HostVolume(np.full(src.shape, np.nan, np.float32), pin=True)
+            op.execute(input=pin, output=pout, data_size=in_dims, resample_size=out_dims)
+            assert same(pout.array[:od, :oh, :ow], expect[:od, :oh, :ow]), (planes2, overlap)
+            assert same(pin.array[:in_dims[2], :in_dims[1], :in_dims[0]], src[:in_dims[2], :in_dims[1], :in_dims[0]])
+            pio = f3d.HostVolume(src.copy(), pin=True)
+            op.execute(input=pio, output=pio, data_size=in_dims, resample_size=out_dims)
+            assert same(pio.array[:od, :oh, :ow], expect[:od, :oh, :ow]), (planes2, overlap, "in place")
+        finally:
+            os.environ.pop("F3D_P_OVERLAP", None)
+            for v in (pin, pout, pio):
+                v.destroy()
     op.destroy()
     for v in (vin, vout, vio):
         v.destroy()
@@ -303,6 +321,41 @@ def test_registration_inside_the_first_residency(f3d, monkeypatch):
         assert np.abs(runs["0"][0][2]).max() > 0.25, "the pair was meant to move along z"
         for a, b, n in zip(runs["1"][0], runs["0"][0], "uvw"):
             assert same(a, b), f"shift {shift}, {planes} planes per field, {n}: registration inside the solver differs"
+
+
+def test_constant_fields_held_on_the_device(f3d, monkeypatch):
+    """The two frames and u, v, w of a level held on the device for the whole level beside smaller chunk sets (three fields up per
+    residency instead of eight; SolvePiecemealPlan::constants_on_device): pinned on, pinned off and left to the cost model, with the
+    registration inside the solver and by the operator -- the same flow bit for bit, the caller's frames untouched."""
+    W, H, D = 40, 36, 48
+    f0, _ = f3d.synth_pair(W, H, D)
+    f1 = np.ascontiguousarray(np.roll(f0, 2, axis=0))
+    keep0, keep1 = f0.copy(), f1.copy()
+    kw = dict(warp_levels_count=10, outer_iterations_count=4, inner_iterations_count=5)
+    for planes_total in (5 * 48 + 16 * 20, 5 * 48 + 8 * 16):      # room for two chunk sets beside the constants / for one
+        set_budget(budget_for(planes_total, W, H, 21))
+        runs = {}
+        for constants in ("0", "1", None):
+            for fused_warp in ("1", "0"):
+                if constants is None:
+                    monkeypatch.delenv("F3D_P_CONSTANTS", raising=False)
+                else:
+                    monkeypatch.setenv("F3D_P_CONSTANTS", constants)
+                monkeypatch.setenv("F3D_P_FUSED_WARP", fused_warp)
+                flow = f3d.PiecemealOpticalFlow()
+                flow.initialize(W, H, D)
+                flow.set_resident(False)
+                try:
+                    runs[(constants, fused_warp)] = (flow.compute(f0, f1, silent=True, **kw), flow.levels_with_constants_on_device(), flow.stats())
+                finally:
+                    flow.destroy()
+                assert same(f0, keep0) and same(f1, keep1), "the caller's frames must come back unchanged"
+        ref = runs[("0", "0")]
+        assert ref[1] == 0 and runs[("0", "1")][1] == 0 and ref[2][1] >= 1, (planes_total, ref[1:])
+        assert runs[("1", "1")][1] >= 1 and runs[("1", "0")][1] >= 1, (planes_total, runs[("1", "1")][1:], "no level held its constants")
+        for key, (got, _, _) in runs.items():
+            for a, b, n in zip(got, ref[0], "uvw"):
+                assert same(a, b), f"{planes_total} planes, F3D_P_CONSTANTS={key[0]}, F3D_P_FUSED_WARP={key[1]}, {n} differs"
 
 
 def test_driver_matches_oracle_small(f3d, oracle):

@@ -114,6 +114,26 @@ CASE = textwrap.dedent('''
             assert np.abs(runs["0"][0][2]).max() > 0.3 * shift / 7
             assert all(same(a, b) for a, b in zip(runs["1"][0], runs["0"][0])), (shift, budget, "registration inside the solver differs")
             print(f"piecemeal shift {shift} budget {budget} MB: {runs['1'][1]} level(s) registered inside, stats {runs['1'][2]}")
+            # the two frames and u, v, w held on the device for the whole level beside smaller chunk sets (three fields up per residency
+            # instead of eight): pinned on wherever the budget allows it, pinned off, and left to the cost model -- same bits
+            kept = {}
+            for mode in ("1", "0", None):
+                if mode is None:
+                    os.environ.pop("F3D_P_CONSTANTS", None)
+                else:
+                    os.environ["F3D_P_CONSTANTS"] = mode
+                for fused_warp in ("1", "0"):
+                    os.environ["F3D_P_FUSED_WARP"] = fused_warp
+                    a0, a1 = g0.copy(), g1.copy()
+                    flow = pkg.PiecemealOpticalFlow(); flow.initialize(W2, H2, D2)
+                    got = flow.compute(a0, a1, silent=True, **kw3); kept[(mode, fused_warp)] = flow.levels_with_constants_on_device(); flow.destroy()
+                    assert same(a0, g0) and same(a1, g1), "the out-of-core driver changed the caller's frames"
+                    assert all(same(a, b) for a, b in zip(got, runs["0"][0])), (shift, budget, mode, fused_warp, "constants on the device differ")
+                del os.environ["F3D_P_FUSED_WARP"]
+            os.environ.pop("F3D_P_CONSTANTS", None)
+            assert kept[("0", "1")] == 0 and kept[("0", "0")] == 0, kept
+            assert budget != "2.0" or kept[("1", "1")] >= 1, ("no level could hold its constant fields: the layout was not exercised", kept)
+            print(f"   constants on the device: {kept}")
     elif what == "reinit":
         # a solve operator initialised twice WITHOUT Destroy in between, the second time for a bigger container: the second weight
         # pair of the fused last sweep must follow the container (under the sanitizers a stale, smaller buffer is a heap overflow),

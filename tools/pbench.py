@@ -59,7 +59,7 @@ def main():
     passes, streamed, on_device = flow.stats()
     print(f"piecemeal: {flow.device_seconds:8.3f} s ({wall:.3f} s wall with host allocation and page-locking)  "
           f"{W * H * D / flow.device_seconds / 1e6:7.2f} Mvoxels/s  budget {a.budget_mb or 'auto'} MB  "
-          f"{passes} solver residencies, {streamed} levels in chunks ({flow.levels_registered_inside()} host levels registered inside the solver), {on_device} levels on the device"
+          f"{passes} solver residencies, {streamed} levels in chunks ({flow.levels_registered_inside()} host levels registered inside the solver, {flow.levels_with_constants_on_device()} with the constant fields held on the device), {on_device} levels on the device"
           f"{' with the originals' if flow.originals_on_device() else ''}", flush=True)
     print("           " + "  ".join(f"{k} {v:.3f}s" for k, v in flow.operator_seconds().items()), flush=True)
     flow.destroy()
