@@ -408,27 +408,46 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   cuop_solve_p_.register_frame_1 = false;
   cuop_solve_p_.registered_frame_1 = nullptr;
   // The flow must end in the caller's own buffers.  A trade hands the caller's buffer to the driver's volumes, among which the
-  // solver's pass-to-pass swaps move it on, so after the last level it may sit in any of them: find it, trade it back and copy the
-  // result across (all cores; a fraction of what the saved transfers cost).  Volumes that never left are left alone.
-  for (int c = 0; c < 3; ++c) {
-    if (flow[c]->DataPtr() == callers_storage[c]) continue;
-    Data3D* holder = nullptr;
-    for (Data3D& v : scratch)
-      if (v.DataPtr() == callers_storage[c]) holder = &v;
-    if (!holder) {
-      std::printf("'%s': Error. A caller volume was lost among the host scratch volumes.\n", GetName());
-      break;
-    }
-    flow[c]->Swap(*holder);   // flow[c]: the caller's buffer (stale), *holder: the result
-    const float* from = holder->DataPtr();
-    float* to = flow[c]->DataPtr();
-    const long long count = static_cast<long long>(W0) * static_cast<long long>(H0) * static_cast<long long>(D0);
+  // solver's pass-to-pass swaps and the registration move it on -- also into the volume of ANOTHER component (the registered frame's
+  // volume takes part in u's trades at one level and in w's at another) -- so after the last level a result may sit anywhere.  Two
+  // steps, a copy each (all cores; a fraction of what the saved transfers cost): a result that sits in another component's buffer
+  // moves to a scratch buffer that is nobody's; then every caller volume takes its own buffer back from whichever scratch volume
+  // holds it and the result is copied across.  Volumes that never left are left alone.
+  const long long count = static_cast<long long>(W0) * static_cast<long long>(H0) * static_cast<long long>(D0);
+  auto copy_volume = [&](float* to, const float* from) {
 #pragma omp parallel for schedule(static)
     for (long long block = 0; block < (count + (1 << 20) - 1) / (1 << 20); ++block) {
       const long long lo = block << 20, n = std::min<long long>(1 << 20, count - lo);
       std::memcpy(to + lo, from + lo, static_cast<size_t>(n) * sizeof(float));
     }
+  };
+  auto callers = [&](const float* p) { return p == callers_storage[0] || p == callers_storage[1] || p == callers_storage[2]; };
+  bool restored = true;
+  for (int c = 0; c < 3 && restored; ++c) {
+    if (flow[c]->DataPtr() == callers_storage[c] || !callers(flow[c]->DataPtr())) continue;
+    Data3D* nobodys = nullptr;
+    for (Data3D& v : scratch)
+      if (!callers(v.DataPtr())) nobodys = &v;
+    if (!nobodys) {
+      restored = false;
+      break;
+    }
+    copy_volume(nobodys->DataPtr(), flow[c]->DataPtr());
+    flow[c]->Swap(*nobodys);   // flow[c]: the scratch buffer with the result; *nobodys: the other component's buffer
   }
+  for (int c = 0; c < 3 && restored; ++c) {
+    if (flow[c]->DataPtr() == callers_storage[c]) continue;
+    Data3D* holder = nullptr;
+    for (Data3D& v : scratch)
+      if (v.DataPtr() == callers_storage[c]) holder = &v;
+    if (!holder) {
+      restored = false;
+      break;
+    }
+    flow[c]->Swap(*holder);   // flow[c]: the caller's buffer (stale), *holder: the result
+    copy_volume(flow[c]->DataPtr(), holder->DataPtr());
+  }
+  if (!restored) std::printf("'%s': Error. A caller volume was lost among the host scratch volumes.\n", GetName());
 
   finish();
 }

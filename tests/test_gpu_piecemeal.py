@@ -209,7 +209,11 @@ def oracle_solve(oracle, f0, f1, u, v, w, dims, h, outer, inner, alpha, eps_s, e
     (1000, 0, 3, 5, 1, 27),   # overlap asked for but the level fits: still one residency
     (13, 1, 4, 5, 2, 27),     # overlap asked for on pageable volumes: the solver keeps the serial schedule
 ])
-def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap, D):
+@pytest.mark.parametrize("constants", ["0", "1"])
+def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap, D, constants, monkeypatch):
+    # constants "0": every field in the chunk sets (the plan geometry below is asserted for that layout); "1": the two frames and
+    # u, v, w held on the device for the whole level wherever the budget allows it (same bits, other chunks)
+    monkeypatch.setenv("F3D_P_CONSTANTS", constants)
     rng = np.random.default_rng(planes)
     W, H = 37, 21
     cd = (40, 24, D + 3)
@@ -245,6 +249,8 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
         assert passes == -(-outer // per_pass) and halo == (0 if chunk == D else per_pass * (inner + 1))
     elif planes >= D:
         assert (chunk, per_pass, halo, passes, overlapped) == (D, outer, 0, 1, False)
+    elif constants == "1":
+        assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
     else:
         assert overlapped == pinned
         assert chunk == (planes if pinned or not overlap else 2 * planes) - 2 * halo
