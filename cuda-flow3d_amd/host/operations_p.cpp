@@ -777,7 +777,16 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     SolvePiecemealPlan kept = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, overlap_mode, set_fields, 5);
     if (kept.overlapped && !PipelineReady()) kept = PlanSolvePiecemeal(PiecemealBudgetBytes(), W, H, D, K, outer, forced, 0, set_fields, 5);
     const bool force = kc_env && kc_env[0] == '1';
-    if (kept.chunk >= 1 && kept.halo > 0 && (kept.cost < plan.cost || force) && !(fuse_weights && kept.outer_per_pass < 2)) plan = kept;
+    // Which layout: by the fields each moves over the link in BOTH directions, added up.  The schedule model prices two copy queues
+    // as the slower of the two directions; measured per level (1024^3 on 16 GB, profiles/r04_piecemeal_per_level.txt) a layout that
+    // loads both directions evenly gets no such discount -- 3 up + 3 down per residency beat 8 up + 3 down by what the SUM says (levels of
+    // 590-650 planes: -10 ... -34 %), and lost where the sum said so although the slower direction alone promised -16 %.
+    auto link_fields = [&](const SolvePiecemealPlan& p, double fields_up, double once) {
+      const double passes = std::ceil(static_cast<double>(outer) / p.outer_per_pass);
+      return passes * (fields_up * static_cast<double>(p.chunk + 2 * p.halo) / p.chunk + 3.0) + once;
+    };
+    const bool pays = kept.chunk >= 1 && kept.halo > 0 && link_fields(kept, 3.0, 5.0) < 0.95 * link_fields(plan, 8.0, 0.0);
+    if (kept.chunk >= 1 && kept.halo > 0 && (pays || force) && !(fuse_weights && kept.outer_per_pass < 2)) plan = kept;
   }
   const bool constants = plan.constants_on_device && plan.chunk >= 1;
   last_plan_ = plan;

@@ -378,6 +378,11 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
       if (registration_traded_storage || cuop_solve_p_.LastRegistered()) break;
       register_separately();   // the solver declined (a reach too deep for its buffers) and has done nothing: the classical order
     }
+    if (!silent)
+      std::printf("  solver of level %d: %.3f s so far in all levels, %zu residencies, chunks of %d planes + 2 x %d, %s%s\n", current_warp_level,
+                  op_seconds_[kSolve], cuop_solve_p_.LastPasses(), cuop_solve_p_.LastPlan().chunk, cuop_solve_p_.LastPlan().halo,
+                  cuop_solve_p_.LastPlan().overlapped ? "copies beside the kernels" : "in order",
+                  cuop_solve_p_.LastPlan().constants_on_device ? ", frames and flow held on the device" : "");
     if (cuop_solve_p_.LastRegistered()) ++levels_registered_inside_;
     if (cuop_solve_p_.LastPlan().constants_on_device && cuop_solve_p_.LastPasses() > 0) ++levels_with_constants_;
     solve_passes_ += cuop_solve_p_.LastPasses();
