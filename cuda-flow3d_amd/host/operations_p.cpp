@@ -290,8 +290,9 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
     const size_t held = static_cast<size_t>(constant_fields) * box.FieldBytes(static_cast<size_t>(std::max(depth, 0)));
     if (depth <= 0 || outer_iterations <= 0 || held >= budget_bytes) return plan;
     const size_t nf = static_cast<size_t>(fields), left = budget_bytes - held;
+    const size_t nf2 = nf + static_cast<size_t>(8 - constant_fields);   // two sets: the fields that travel twice, the compute-only ones once
     const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(left, nf) / nf, cap));
-    const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(left, 2 * nf) / (2 * nf), cap));
+    const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(left, nf2) / nf2, cap));
     if (serial_planes >= depth) return plan;   // (a level that fits whole is one residency anyway: nothing to keep)
     const int step = inner_iterations + 1;
     const double up = 8.0 - constant_fields;
@@ -304,9 +305,11 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
     return best;
   }
   // 13 fields per chunk set (eight inputs, phi, ksi, three outputs), 15 with the second weight pair of the fused last sweep
-  const size_t nf = static_cast<size_t>(fields);
+  // Two chunk sets hold the fields that travel (eight inputs, of which three come back) twice and the compute-only ones (phi, ksi, the
+  // sweeps' ping-pong partners) ONCE: the kernels of the two sets run one after the other on one stream, only the copies overlap.
+  const size_t nf = static_cast<size_t>(fields), nf2 = nf + 8;
   const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf) / nf, cap));
-  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, 2 * nf) / (2 * nf), cap));
+  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf2) / nf2, cap));
   plan.max_planes = serial_planes;
   if (depth <= 0 || outer_iterations <= 0) return plan;
   if (serial_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
@@ -814,14 +817,19 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   const ChunkBox box(W, H);
   Carver carve(box);
   const int kConstants = constants ? 5 : 0;   // F0 .. FW hold the whole level (plane z at plane z), once for all chunk sets
+  // what a chunk set owns: the fields that travel, F0 .. DW (DU .. DW with the constants held); phi, ksi and the sweeps' ping-pong
+  // partners are compute-only and carved once, for both sets (kernels of the two sets follow each other on the library stream)
+  const int kOwn = 8 - kConstants, kShared = kFields - 8;
   for (int i = 0; i < kConstants; ++i) carve.Add(static_cast<size_t>(D));
-  for (int i = 0; i < n_sets * (kFields - kConstants); ++i) carve.Add(planes);
+  for (int i = 0; i < n_sets * kOwn + kShared; ++i) carve.Add(planes);
   if (!carve.Commit()) return;
   ContainerScope scope(box, planes);
   if (!scope.ok()) return;
   DevicePtr sets[2][kAllFields] = {};
-  for (int s = 0; s < n_sets; ++s)
-    for (int i = kConstants; i < kFields; ++i) sets[s][i] = carve[kConstants + s * (kFields - kConstants) + (i - kConstants)];
+  for (int s = 0; s < n_sets; ++s) {
+    for (int i = kConstants; i < 8; ++i) sets[s][i] = carve[kConstants + s * kOwn + (i - kConstants)];
+    for (int i = 8; i < kFields; ++i) sets[s][i] = carve[kConstants + n_sets * kOwn + (i - 8)];
+  }
   int constants_up_to = 0, registered_up_to = 0;   // planes of the whole-level fields that have arrived / been registered so far
   // Serial: copies and kernels in order on the library stream.  Overlapped: uploads on one queue, downloads on another,
   // kernels on the library stream; a chunk set is reused once the download of its previous chunk has finished.
@@ -842,7 +850,8 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     for (int z0 = 0; z0 < D; z0 += chunk, ++chunk_counter) {
       const int z1 = std::min(D, z0 + chunk);
       const int set = plan.overlapped ? static_cast<int>(chunk_counter & 1) : 0;
-      DevicePtr* buf = sets[set];
+      DevicePtr buf[kAllFields];   // the buffer names of this residency: the sweeps trade DU .. DW with TDU .. TDW, phi / ksi with their seconds
+      std::copy(sets[set], sets[set] + kAllFields, buf);
       const int base = halo ? z0 - halo : 0;  // global plane held by container plane 0
       const int lo = std::max(0, z0 - reach), hi = std::min(D, z1 + reach);
       auto window = [&](int grow) { return f3d_slab{base, std::max(0, z0 - grow), std::min(D, z1 + grow)}; };
@@ -876,7 +885,9 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
           if (std::min(D, s1 + warp_reach) - in_lo > planes) s1 = in_lo + planes - warp_reach;
           if (s1 <= s0) return LowMemory(GetName());
           const int in_hi = std::min(D, s1 + warp_reach);
-          if (!Upload(buf[TDU + n_pieces], box, 0, *fixed[1], W, H, in_lo, in_hi - in_lo, q_up)) return;
+          // (into the set's own increment buffers: they start at zero in this pass, cleared below once the warp has read the pieces;
+          // the sweeps' partners belong to both chunk sets and may be at work for the other one while this copy runs)
+          if (!Upload(buf[DU + n_pieces], box, 0, *fixed[1], W, H, in_lo, in_hi - in_lo, q_up)) return;
           piece_in[n_pieces] = in_lo;
           piece_s[++n_pieces] = s1;
           s0 = s1;
@@ -884,7 +895,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       }
       for (int i = 0; i < 3; ++i) {
         if (i0 == 0) {
-          if (CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
+          if (!register_here && CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
         } else if (!Upload(buf[DU + i], box, lo - base, *inc[i], W, H, lo, hi - lo, q_up)) {
           return;
         }
@@ -896,10 +907,13 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       // the registered frame of the window: every operand under the chunk's z_base, the piece's buffer rebased to it
       for (int p = 0; p < n_pieces; ++p) {
         const f3d_slab piece = {base, piece_s[p], piece_s[p + 1]};
-        if (CheckDeviceError(f3d_warp(buf[F0], Rebase(buf[TDU + p], box, piece_in[p], base), buf[FU], buf[FV], buf[FW], W, H, D, hx, hy, hz,
+        if (CheckDeviceError(f3d_warp(buf[F0], Rebase(buf[DU + p], box, piece_in[p], base), buf[FU], buf[FV], buf[FW], W, H, D, hx, hy, hz,
                                       buf[F1], &piece)))
           return;
       }
+      if (register_here)
+        for (int i = 0; i < 3; ++i)
+          if (CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
       const DevicePtr registered_planes = buf[F1];   // (the buffer names below trade places with every sweep; F1 does not)
       // Outer iteration j of this pass leaves the increments valid on the chunk widened by g = (n-1-j)(K+1) planes:
       // phi/ksi on g + K, sweep s on g + K-1-s; a fused pair runs on the window of its second sweep.
@@ -956,6 +970,15 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
         if (CheckDeviceError(f3d_add_n(sums, flows, 3, W, H, D, &own))) return;
       }
       if (plan.overlapped) {
+        // an odd number of trades leaves the result in the sweeps' partners, which the next chunk's kernels write while this chunk's
+        // download runs: the planes the chunk owns move into the set's own buffers first (a device copy, on the kernels' stream)
+        for (int i = 0; i < 3; ++i)
+          if (buf[DU + i] != sets[set][DU + i]) {
+            if (CheckDeviceError(f3d_copy_rect_d2d(sets[set][DU + i], box.pitch, box.H, static_cast<size_t>(z0 - base), buf[DU + i], box.pitch, box.H,
+                                                   static_cast<size_t>(z0 - base), W, H, static_cast<size_t>(z1 - z0))))
+              return;
+            buf[DU + i] = sets[set][DU + i];
+          }
         if (CheckDeviceError(f3d_event_record_on(g_pipe.computed[set], nullptr))) return;
         if (CheckDeviceError(f3d_queue_wait_event(q_down, g_pipe.computed[set]))) return;
       }

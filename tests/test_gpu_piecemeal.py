@@ -229,7 +229,8 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
     os.environ["F3D_P_FUSED"] = "1"
     want_fused = inner % 2 == 1 and outer > 1 and forced != 1
     per_set = 15 if want_fused else 13
-    fields = 2 * per_set if overlap and planes < D else per_set
+    # (two chunk sets hold the eight fields that travel twice, the compute-only ones once)
+    fields = per_set + 8 if overlap and planes < D else per_set
     set_budget(budget_for(fields * planes, W, H, fields))
     os.environ["F3D_P_OUTER_PER_PASS"] = str(forced)
     os.environ["F3D_P_OVERLAP"] = str(min(overlap, 1))
@@ -253,7 +254,7 @@ def test_solve_matches_oracle(f3d, oracle, planes, forced, outer, inner, overlap
         assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
     else:
         assert overlapped == pinned
-        assert chunk == (planes if pinned or not overlap else 2 * planes) - 2 * halo
+        assert chunk == (planes if pinned or not overlap else fields * planes // per_set) - 2 * halo
         assert chunk < D and halo == per_pass * (inner + 1) and passes == -(-outer // per_pass)
         if forced:
             assert per_pass == forced
