@@ -35,6 +35,7 @@ size_t g_reserved = 0;
 struct Pipeline {
   f3d_queue up = nullptr, down = nullptr;
   f3d_event uploaded[2] = {nullptr, nullptr}, computed[2] = {nullptr, nullptr}, downloaded[2] = {nullptr, nullptr};
+  f3d_event kept[2] = {nullptr, nullptr};   // the planes a chunk set took over from the other set have been copied (solver)
   bool ready = false;
 } g_pipe;
 
@@ -47,7 +48,7 @@ bool PipelineReady()
   bool ok = !CheckDeviceError(f3d_queue_create(&g_pipe.up)) && !CheckDeviceError(f3d_queue_create(&g_pipe.down));
   for (int i = 0; i < 2 && ok; ++i)
     ok = !CheckDeviceError(f3d_event_create(&g_pipe.uploaded[i])) && !CheckDeviceError(f3d_event_create(&g_pipe.computed[i])) &&
-         !CheckDeviceError(f3d_event_create(&g_pipe.downloaded[i]));
+         !CheckDeviceError(f3d_event_create(&g_pipe.downloaded[i])) && !CheckDeviceError(f3d_event_create(&g_pipe.kept[i]));
   g_pipe.ready = ok;
   return ok;
 }
@@ -58,6 +59,7 @@ void PipelineRelease()
     f3d_event_destroy(g_pipe.uploaded[i]);
     f3d_event_destroy(g_pipe.computed[i]);
     f3d_event_destroy(g_pipe.downloaded[i]);
+    f3d_event_destroy(g_pipe.kept[i]);
   }
   f3d_queue_destroy(g_pipe.up);
   f3d_queue_destroy(g_pipe.down);
@@ -244,8 +246,10 @@ namespace {
 // ~50 GB/s each way (eight fields up with their halos, three down, per pass) and device bytes at ~5 TB/s (300 B per voxel
 // and outer iteration on windows that average chunk + halo planes).  Serial: the three add up.  Overlapped (two chunk
 // sets, half the planes each): the slowest of the three, plus the other two once per level for filling the pipeline.
+// `fields_once`: of the fields_up, those whose halo planes do not travel again with the next chunk (the overlapped schedule hands the
+// planes two neighbouring chunks share from one chunk set to the other on the device: the two frames, u, v, w)
 SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_iterations, int forced, bool overlapped,
-                                double fields_up = 8.0)
+                                double fields_up = 8.0, double fields_once = 0.0)
 {
   SolvePiecemealPlan plan;
   plan.max_planes = max_planes;
@@ -257,7 +261,7 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
     if (chunk < 1) break;
     const double passes = std::ceil(static_cast<double>(outer_iterations) / n);
     const double wide = static_cast<double>(chunk + 2 * halo) / chunk, mid = static_cast<double>(chunk + halo) / chunk;
-    const double up = passes * fields_up * wide * 4.0 / 50e9, down = passes * 3.0 * 4.0 / 50e9;
+    const double up = passes * ((fields_up - fields_once) * wide + fields_once) * 4.0 / 50e9, down = passes * 3.0 * 4.0 / 50e9;
     const double device = outer_iterations * 300.0 * mid / 5e12;
     double cost = up + down + device;
     if (overlapped) {
@@ -321,7 +325,7 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
   }
   const int step = inner_iterations + 1;
   const SolvePiecemealPlan serial = PlanSchedule(serial_planes, depth, step, outer_iterations, forced_outer_per_pass, false);
-  const SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true);
+  const SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true, 8.0, 5.0);
   if (overlap_mode == 0) return serial;
   if (overlap_mode == 1) return overlapped;
   return (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
@@ -784,11 +788,13 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     // as the slower of the two directions; measured per level (1024^3 on 16 GB, profiles/r04_piecemeal_per_level.txt) a layout that
     // loads both directions evenly gets no such discount -- 3 up + 3 down per residency beat 8 up + 3 down by what the SUM says (levels of
     // 590-650 planes: -10 ... -34 %), and lost where the sum said so although the slower direction alone promised -16 %.
-    auto link_fields = [&](const SolvePiecemealPlan& p, double fields_up, double once) {
+    auto link_fields = [&](const SolvePiecemealPlan& p, double fields_up, double once_per_pass, double once) {
       const double passes = std::ceil(static_cast<double>(outer) / p.outer_per_pass);
-      return passes * (fields_up * static_cast<double>(p.chunk + 2 * p.halo) / p.chunk + 3.0) + once;
+      return passes * ((fields_up - once_per_pass) * static_cast<double>(p.chunk + 2 * p.halo) / p.chunk + once_per_pass + 3.0) + once;
     };
-    const bool pays = kept.chunk >= 1 && kept.halo > 0 && link_fields(kept, 3.0, 5.0) < 0.95 * link_fields(plan, 8.0, 0.0);
+    // (the overlapped schedule hands the constants' shared planes from chunk set to chunk set: they travel once per pass there)
+    const bool pays = kept.chunk >= 1 && kept.halo > 0 &&
+                      link_fields(kept, 3.0, 0.0, 5.0) < 0.95 * link_fields(plan, 8.0, plan.overlapped ? 5.0 : 0.0, 0.0);
     if (kept.chunk >= 1 && kept.halo > 0 && (pays || force) && !(fuse_weights && kept.outer_per_pass < 2)) plan = kept;
   }
   const bool constants = plan.constants_on_device && plan.chunk >= 1;
@@ -844,9 +850,17 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   const size_t rows = static_cast<size_t>(planes) * H;
   const bool fused = FusedSweepsEnabled();
   size_t chunk_counter = 0;
+  // Overlapped schedule, every field in the chunk sets: the windows of two neighbouring chunks share 2 x reach planes, and for the five
+  // fields nothing writes -- the two frames, u, v, w -- those planes are in the OTHER chunk set already when a chunk starts: they are
+  // copied across on the device (kernels' stream) and only the planes above them come over the link, so per pass each plane of
+  // those fields travels once instead of (chunk + 2 x halo) / chunk times.  In the first pass the registered frame is handed on the
+  // same way (registered once per plane).  F3D_P_HANDOVER=0 uploads every window whole.
+  const char* ho_env = std::getenv("F3D_P_HANDOVER");
+  const bool handover = plan.overlapped && !constants && halo > 0 && !(ho_env && ho_env[0] == '0');
   for (int i0 = 0; i0 < outer; i0 += plan.outer_per_pass) {
     const int n = std::min(plan.outer_per_pass, outer - i0);
     const int reach = halo ? n * (K + 1) : 0;  // planes of input this pass reads beyond the chunk
+    int prev_set = -1, prev_hi = 0, prev_base = 0;   // the chunk before this one in the pass: its set, the top of its window, its z_base
     for (int z0 = 0; z0 < D; z0 += chunk, ++chunk_counter) {
       const int z1 = std::min(D, z0 + chunk);
       const int set = plan.overlapped ? static_cast<int>(chunk_counter & 1) : 0;
@@ -866,7 +880,20 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       // buffer through a pointer under which its plane z sits at container plane z - base)
       if (constants)
         for (int i = 0; i < 5; ++i) buf[F0 + i] = Rebase(carve[i], box, 0, base);
-      const int c_lo = constants ? std::max(lo, constants_up_to) : lo;
+      // ... or handed over from the chunk before: planes lo .. kept_hi of this window are in the other set (its kernels have read them,
+      // nothing writes them); the copy runs on the kernels' stream, which has waited for this set's last download above
+      int kept_hi = lo;
+      if (handover && prev_set >= 0 && prev_set != set && prev_hi > lo) {
+        kept_hi = std::min(prev_hi, hi);
+        for (int i = 0; i < 5; ++i)
+          if (CheckDeviceError(f3d_copy_rect_d2d(buf[F0 + i], box.pitch, box.H, static_cast<size_t>(lo - base), sets[prev_set][F0 + i], box.pitch,
+                                                 box.H, static_cast<size_t>(lo - prev_base), W, H, static_cast<size_t>(kept_hi - lo))))
+            return;
+        // the other set is uploaded into again by the chunk after this one: not before these copies have read it
+        if (CheckDeviceError(f3d_event_record_on(g_pipe.kept[set], nullptr))) return;
+      }
+      if (handover && prev_set >= 0 && set_used[set] && CheckDeviceError(f3d_queue_wait_event(q_up, g_pipe.kept[prev_set]))) return;
+      const int c_lo = constants ? std::max(lo, constants_up_to) : kept_hi;
       if (!constants || i0 == 0) {
         for (int i = 0; i < 5; ++i)
           if (!(register_here && i == 1) && hi > c_lo && !Upload(buf[F0 + i], box, c_lo - base, *fixed[i], W, H, c_lo, hi - c_lo, q_up)) return;
@@ -874,7 +901,7 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       }
       // the unregistered frame 1 for the window lo .. hi, in pieces: piece p serves the output planes s[p] .. s[p+1] from the frame's
       // planes in_lo[p] .. (at most `planes` of them) held from plane 0 of its buffer
-      const int r_lo = constants ? std::max(lo, registered_up_to) : lo;   // (held for the whole level: only what is not registered yet)
+      const int r_lo = constants ? std::max(lo, registered_up_to) : kept_hi;   // (held or handed over: only what is not registered yet)
       int n_pieces = 0, piece_s[4] = {r_lo, r_lo, r_lo, r_lo}, piece_in[3] = {0, 0, 0};
       if (register_here) {
         if (constants) registered_up_to = std::max(registered_up_to, hi);
@@ -989,6 +1016,9 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
         if (CheckDeviceError(f3d_event_record_on(g_pipe.downloaded[set], q_down))) return;
         set_used[set] = true;
       }
+      prev_set = set;
+      prev_hi = hi;
+      prev_base = base;
     }
     // the pass is complete when its last download is: the next pass reads what this one wrote
     if (plan.overlapped && CheckDeviceError(f3d_queue_sync(q_down))) return;
