@@ -243,21 +243,28 @@ void PiecemealReleaseArena()
 namespace {
 
 // Best number of outer iterations per residency for one schedule.  Cost per owned voxel of one full solve: link bytes at
-// ~50 GB/s each way (eight fields up with their halos, three down, per pass) and device bytes at ~5 TB/s (300 B per voxel
-// and outer iteration on windows that average chunk + halo planes).  Serial: the three add up.  Overlapped (two chunk
-// sets, half the planes each): the slowest of the three, plus the other two once per level for filling the pipeline.
+// ~50 GB/s (eight fields up, three down, per pass) and device bytes at ~5 TB/s (300 B per voxel and outer iteration on windows
+// that average chunk + halo planes).  Serial: the three add up.  Overlapped (two chunk sets): the slower of link and device, plus
+// the other once per level for filling the pipeline -- the LINK being up + down: measured per level, the two directions do not hide
+// each other (LABBOOK, round 4).
+// `total_planes` planes are there for `buffers` chunk buffers and, per plane of halo, `staging_per_halo` planes of staging (the
+// overlapped schedule keeps the increments two neighbouring chunks share: 3 fields x 2 x halo planes).
 // `fields_once`: of the fields_up, those whose halo planes do not travel again with the next chunk (the overlapped schedule hands the
-// planes two neighbouring chunks share from one chunk set to the other on the device: the two frames, u, v, w)
-SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_iterations, int forced, bool overlapped,
-                                double fields_up = 8.0, double fields_once = 0.0)
+// planes two neighbouring chunks share from one chunk set to the other on the device)
+SolvePiecemealPlan PlanSchedule(size_t total_planes, size_t buffers, size_t staging_per_halo, int depth, int step, int outer_iterations,
+                                int forced, bool overlapped, double fields_up = 8.0, double fields_once = 0.0)
 {
   SolvePiecemealPlan plan;
-  plan.max_planes = max_planes;
+  const size_t cap = static_cast<size_t>(std::numeric_limits<int>::max());
+  plan.max_planes = static_cast<int>(std::min(total_planes / buffers, cap));
   plan.overlapped = overlapped;
   for (int n = 1; n <= outer_iterations; ++n) {
     if (forced > 0 && n != std::min(forced, outer_iterations)) continue;
     const int halo = n * step;
-    const int chunk = max_planes - 2 * halo;
+    const size_t staging = staging_per_halo * static_cast<size_t>(halo);
+    if (staging >= total_planes) break;
+    const int planes = static_cast<int>(std::min((total_planes - staging) / buffers, cap));
+    const int chunk = planes - 2 * halo;
     if (chunk < 1) break;
     const double passes = std::ceil(static_cast<double>(outer_iterations) / n);
     const double wide = static_cast<double>(chunk + 2 * halo) / chunk, mid = static_cast<double>(chunk + halo) / chunk;
@@ -265,7 +272,7 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
     const double device = outer_iterations * 300.0 * mid / 5e12;
     double cost = up + down + device;
     if (overlapped) {
-      const double slowest = std::max(up, std::max(down, device));
+      const double slowest = std::max(up + down, device);
       const double chunks = std::ceil(static_cast<double>(depth) / chunk) * passes;
       cost = slowest + (cost - slowest) / std::max(1.0, chunks);
     }
@@ -274,6 +281,7 @@ SolvePiecemealPlan PlanSchedule(int max_planes, int depth, int step, int outer_i
       plan.chunk = chunk;
       plan.outer_per_pass = n;
       plan.halo = halo;
+      plan.max_planes = planes;
     }
   }
   return plan;
@@ -296,12 +304,12 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
     const size_t nf = static_cast<size_t>(fields), left = budget_bytes - held;
     const size_t nf2 = nf + static_cast<size_t>(8 - constant_fields);   // two sets: the fields that travel twice, the compute-only ones once
     const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(left, nf) / nf, cap));
-    const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(left, nf2) / nf2, cap));
     if (serial_planes >= depth) return plan;   // (a level that fits whole is one residency anyway: nothing to keep)
     const int step = inner_iterations + 1;
     const double up = 8.0 - constant_fields;
-    SolvePiecemealPlan serial = PlanSchedule(serial_planes, depth, step, outer_iterations, forced_outer_per_pass, false, up);
-    SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true, up);
+    SolvePiecemealPlan serial = PlanSchedule(box.TotalPlanes(left, nf), nf, 0, depth, step, outer_iterations, forced_outer_per_pass, false, up);
+    SolvePiecemealPlan overlapped =
+        PlanSchedule(box.TotalPlanes(left, nf2 + 3), nf2, 6, depth, step, outer_iterations, forced_outer_per_pass, true, up, up);
     SolvePiecemealPlan best = overlap_mode == 0 ? serial : overlap_mode == 1 ? overlapped
                               : (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
     best.constants_on_device = true;
@@ -311,9 +319,11 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
   // 13 fields per chunk set (eight inputs, phi, ksi, three outputs), 15 with the second weight pair of the fused last sweep
   // Two chunk sets hold the fields that travel (eight inputs, of which three come back) twice and the compute-only ones (phi, ksi, the
   // sweeps' ping-pong partners) ONCE: the kernels of the two sets run one after the other on one stream, only the copies overlap.
+  // The overlapped schedule also keeps, in three staging buffers of 2 x halo planes, the increments two neighbouring chunks share as
+  // they arrived: with the frames' and the flow's shared planes handed on from set to set, every plane of every field then travels
+  // once per pass.
   const size_t nf = static_cast<size_t>(fields), nf2 = nf + 8;
   const int serial_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf) / nf, cap));
-  const int overlap_planes = static_cast<int>(std::min(box.TotalPlanes(budget_bytes, nf2) / nf2, cap));
   plan.max_planes = serial_planes;
   if (depth <= 0 || outer_iterations <= 0) return plan;
   if (serial_planes >= depth) {  // the level fits: one residency for the whole solve, no halo
@@ -324,8 +334,10 @@ SolvePiecemealPlan PlanSolvePiecemeal(size_t budget_bytes, size_t width, size_t 
     return plan;
   }
   const int step = inner_iterations + 1;
-  const SolvePiecemealPlan serial = PlanSchedule(serial_planes, depth, step, outer_iterations, forced_outer_per_pass, false);
-  const SolvePiecemealPlan overlapped = PlanSchedule(overlap_planes, depth, step, outer_iterations, forced_outer_per_pass, true, 8.0, 5.0);
+  const SolvePiecemealPlan serial =
+      PlanSchedule(box.TotalPlanes(budget_bytes, nf), nf, 0, depth, step, outer_iterations, forced_outer_per_pass, false);
+  const SolvePiecemealPlan overlapped =
+      PlanSchedule(box.TotalPlanes(budget_bytes, nf2 + 3), nf2, 6, depth, step, outer_iterations, forced_outer_per_pass, true, 8.0, 8.0);
   if (overlap_mode == 0) return serial;
   if (overlap_mode == 1) return overlapped;
   return (overlapped.chunk > 0 && (serial.chunk == 0 || overlapped.cost < serial.cost)) ? overlapped : serial;
@@ -793,8 +805,8 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
       return passes * ((fields_up - once_per_pass) * static_cast<double>(p.chunk + 2 * p.halo) / p.chunk + once_per_pass + 3.0) + once;
     };
     // (the overlapped schedule hands the constants' shared planes from chunk set to chunk set: they travel once per pass there)
-    const bool pays = kept.chunk >= 1 && kept.halo > 0 &&
-                      link_fields(kept, 3.0, 0.0, 5.0) < 0.95 * link_fields(plan, 8.0, plan.overlapped ? 5.0 : 0.0, 0.0);
+    const bool pays = kept.chunk >= 1 && kept.halo > 0 && link_fields(kept, 3.0, kept.overlapped ? 3.0 : 0.0, 5.0) <
+                                                            0.95 * link_fields(plan, 8.0, plan.overlapped ? 8.0 : 0.0, 0.0);
     if (kept.chunk >= 1 && kept.halo > 0 && (pays || force) && !(fuse_weights && kept.outer_per_pass < 2)) plan = kept;
   }
   const bool constants = plan.constants_on_device && plan.chunk >= 1;
@@ -828,6 +840,8 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   const int kOwn = 8 - kConstants, kShared = kFields - 8;
   for (int i = 0; i < kConstants; ++i) carve.Add(static_cast<size_t>(D));
   for (int i = 0; i < n_sets * kOwn + kShared; ++i) carve.Add(planes);
+  const bool want_staging = plan.overlapped && halo > 0;   // (three buffers of 2 x halo planes: the planner has left room for them)
+  for (int i = 0; i < (want_staging ? 3 : 0); ++i) carve.Add(static_cast<size_t>(2 * halo));
   if (!carve.Commit()) return;
   ContainerScope scope(box, planes);
   if (!scope.ok()) return;
@@ -836,6 +850,8 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
     for (int i = kConstants; i < 8; ++i) sets[s][i] = carve[kConstants + s * kOwn + (i - kConstants)];
     for (int i = 8; i < kFields; ++i) sets[s][i] = carve[kConstants + n_sets * kOwn + (i - 8)];
   }
+  DevicePtr staging_bufs[3] = {0, 0, 0};
+  for (int i = 0; i < (want_staging ? 3 : 0); ++i) staging_bufs[i] = carve[kConstants + n_sets * kOwn + kShared + i];
   int constants_up_to = 0, registered_up_to = 0;   // planes of the whole-level fields that have arrived / been registered so far
   // Serial: copies and kernels in order on the library stream.  Overlapped: uploads on one queue, downloads on another,
   // kernels on the library stream; a chunk set is reused once the download of its previous chunk has finished.
@@ -855,8 +871,12 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
   // copied across on the device (kernels' stream) and only the planes above them come over the link, so per pass each plane of
   // those fields travels once instead of (chunk + 2 x halo) / chunk times.  In the first pass the registered frame is handed on the
   // same way (registered once per plane).  F3D_P_HANDOVER=0 uploads every window whole.
+  // The increments -- which the sweeps overwrite -- are handed on through three staging buffers: the planes the NEXT chunk shares with
+  // this one are put aside as they arrived, before this chunk's first kernel, and the next chunk takes them from there.
   const char* ho_env = std::getenv("F3D_P_HANDOVER");
-  const bool handover = plan.overlapped && !constants && halo > 0 && !(ho_env && ho_env[0] == '0');
+  const bool handover_any = plan.overlapped && halo > 0 && !(ho_env && ho_env[0] == '0');
+  const bool handover = handover_any && !constants;
+  const DevicePtr* staging = handover_any ? &staging_bufs[0] : nullptr;
   for (int i0 = 0; i0 < outer; i0 += plan.outer_per_pass) {
     const int n = std::min(plan.outer_per_pass, outer - i0);
     const int reach = halo ? n * (K + 1) : 0;  // planes of input this pass reads beyond the chunk
@@ -920,16 +940,30 @@ void CudaOperationSolveP::Execute(OperationParameters& params)
           s0 = s1;
         }
       }
+      // the increments as the pass found them: zero in the first pass; afterwards the planes shared with the chunk before come from
+      // the staging buffers (kernels' stream; this set's last download has been waited for above), the rest over the link
+      const int inc_lo = (staging && i0 > 0 && prev_set >= 0 && prev_hi > lo) ? std::min(prev_hi, hi) : lo;
       for (int i = 0; i < 3; ++i) {
         if (i0 == 0) {
           if (!register_here && CheckDeviceError(f3d_memset2d(buf[DU + i], box.pitch, 0, W * sizeof(float), rows))) return;
-        } else if (!Upload(buf[DU + i], box, lo - base, *inc[i], W, H, lo, hi - lo, q_up)) {
-          return;
+          continue;
         }
+        if (inc_lo > lo && CheckDeviceError(f3d_copy_rect_d2d(buf[DU + i], box.pitch, box.H, static_cast<size_t>(lo - base), staging[i], box.pitch,
+                                                              box.H, 0, W, H, static_cast<size_t>(inc_lo - lo))))
+          return;
+        if (hi > inc_lo && !Upload(buf[DU + i], box, inc_lo - base, *inc[i], W, H, inc_lo, hi - inc_lo, q_up)) return;
       }
       if (plan.overlapped) {
         if (CheckDeviceError(f3d_event_record_on(g_pipe.uploaded[set], q_up))) return;
         if (CheckDeviceError(f3d_queue_wait_event(nullptr, g_pipe.uploaded[set]))) return;
+      }
+      // ... and what the NEXT chunk shares of them goes aside before the first kernel of this one writes a partner of theirs
+      if (staging && i0 > 0 && z1 < D) {
+        const int next_lo = std::max(0, z1 - reach);
+        for (int i = 0; i < 3; ++i)
+          if (hi > next_lo && CheckDeviceError(f3d_copy_rect_d2d(staging[i], box.pitch, box.H, 0, buf[DU + i], box.pitch, box.H,
+                                                                 static_cast<size_t>(next_lo - base), W, H, static_cast<size_t>(hi - next_lo))))
+            return;
       }
       // the registered frame of the window: every operand under the chunk's z_base, the piece's buffer rebased to it
       for (int p = 0; p < n_pieces; ++p) {

@@ -237,7 +237,7 @@ def test_piecemeal_solver_plan_properties(f3d):
     assert auto_big[:4] in (big[:4], forced_on[:4])
     # (a budget of 40 planes: two sets of 24 with a one-iteration halo, or one of 40 -- either way a plan that fits)
     auto_small = f3d.plan_solve_piecemeal(planes_budget(40, 2048, 2048), 2048, 2048, 2048, 5, 40, 0, -1)
-    assert auto_small[0] >= 1 and auto_small[0] == auto_small[3] - 2 * auto_small[2] and auto_small[3] in (40, 13 * 40 // 21)
+    assert auto_small[0] >= 1 and auto_small[0] == auto_small[3] - 2 * auto_small[2] and (auto_small[3] == 40 or 20 <= auto_small[3] <= 13 * 40 // 21)
 
 
 @pytest.mark.parametrize("planes,forced,outer,inner", [(20, 1, 3, 5), (28, 2, 5, 5), (17, 0, 4, 3)])
