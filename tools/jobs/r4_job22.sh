@@ -3,7 +3,7 @@
 # 1024^3 on 16 GB per level, with whole windows uploaded (F3D_P_HANDOVER=0) and with the hand-over, result checked against the resident driver
 set -e
 R=$(pwd)
-O=${F3D_OUT:-$R/gpurun_out}/r4/job21
+O=${F3D_OUT:-$R/gpurun_out}/r4/job22
 mkdir -p $O
 timeout -k 10 600 python3 -X faulthandler -m pytest tests/test_gpu_piecemeal.py tests/test_gpu_configs.py -q -m gpu -x > $O/tests.log 2>&1 || { tail -60 $O/tests.log; exit 1; }
 tail -2 $O/tests.log

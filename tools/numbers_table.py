@@ -91,13 +91,22 @@ def rows():
             out.append(("... and with frame 1 registered inside the solver's first residency as well",
                         f"**{float(secs[1]):.2f} s**; with the separate registration operator {float(secs[0]):.2f} s (same call)",
                         os.path.relpath(f, ROOT)))
+    f = P("piecemeal_1024_16gb_handover.txt")
+    if os.path.exists(f):
+        import re
+        secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
+        if len(secs) >= 2:
+            out.append(("out-of-core, final state of round 4: ... and the planes neighbouring chunks share handed on from chunk set to chunk set on "
+                        "the device (every plane of every field over the link once per pass)",
+                        f"**{float(secs[-1]):.2f} s**; with whole windows uploaded {float(secs[0]):.2f} s (same call; `results identical` to the "
+                        f"resident driver; per-level solver seconds in the record)", os.path.relpath(f, ROOT)))
     f = P("piecemeal_1024_16gb_shared_buffers.txt")
     if os.path.exists(f):
         import re
         secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
         if secs:
             out.append(("... with the resample operator on two buffer sets, the host scratch prepared beside the resident levels and the solver's "
-                        "two chunk sets sharing the compute-only fields (final state of round 4)",
+                        "two chunk sets sharing the compute-only fields",
                         f"**{float(secs[-1]):.2f} s** (`results identical` to the resident driver; per-level solver seconds in the record)",
                         os.path.relpath(f, ROOT)))
     f = P("thin_tile_solves.txt")
