@@ -9,9 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "common_utils.h"
 #include "operator_calls.h"
@@ -105,11 +105,9 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   std::vector<void*> pinned;
   const char* pin_env = std::getenv("F3D_P_PIN");
   const bool pin = pin_host_memory && !(pin_env && pin_env[0] == '0');
-  std::mutex pinned_lock;
   auto pin_volume = [&](Data3D* v) {
     if (!pin) return;
     if (f3d_host_register(v->DataPtr(), volume_bytes) == 0) {
-      std::lock_guard<std::mutex> hold(pinned_lock);
       pinned.push_back(v->DataPtr());
     } else if (!silent) {
       std::printf("'%s': host memory could not be page-locked (%s); copies will be staged.\n", GetName(), f3d_last_error());
@@ -138,11 +136,13 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   }
 
   // Host scratch of the levels that go through the host: eight volumes of the original size (the reference keeps ten: phi and ksi stay
-  // on the device here).  Where coarse levels run on the device first, a helper thread allocates and page-locks them MEANWHILE -- 34 GB
-  // at 1024^3, 1.9 s that the host thread otherwise spends between the resident levels and the first host level with the device idle.
+  // on the device here), allocated and page-locked when the first such level is reached.  (Doing that on a helper thread beside the
+  // resident levels was built and measured twice: page-locking stalls the submission of kernels, the resident levels lose what the
+  // thread saves -- 30.57 s in line, 30.70 s beside, profiles/r04_piecemeal_huge_pages.txt -- so it is done in line.)
   Data3D scratch[8];
   bool scratch_ok = true;
-  std::thread scratch_thread;
+  const char* hp_env = std::getenv("F3D_P_HUGE_PAGES");
+  const bool huge_pages = !(hp_env && hp_env[0] == '0');
   auto prepare_scratch = [&]() {
     std::vector<Data3D*> all;
     for (Data3D& v : scratch) {
@@ -150,6 +150,11 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
         scratch_ok = false;
         return;
       }
+      // 4 KiB pages make page-locking 34 GB a walk over nine million pages; where the kernel grants transparent huge pages on request,
+      // the volume asks for them before anything touches it (a hint: ignored where the mode is `never`)
+      const uintptr_t first = (reinterpret_cast<uintptr_t>(v.DataPtr()) + (2u << 20) - 1) & ~static_cast<uintptr_t>((2u << 20) - 1);
+      const uintptr_t last = (reinterpret_cast<uintptr_t>(v.DataPtr()) + volume_bytes) & ~static_cast<uintptr_t>((2u << 20) - 1);
+      if (huge_pages && last > first) madvise(reinterpret_cast<void*>(first), last - first, MADV_HUGEPAGE);
       all.push_back(&v);
     }
     pin_volumes(all);
@@ -167,7 +172,6 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   resident_levels_ = 0;
   for (double& t : op_seconds_) t = 0.0;
   auto finish = [&]() {
-    if (scratch_thread.joinable()) scratch_thread.join();   // (it appends to `pinned`)
     float elapsed_time = 0.f;
     CheckDeviceError(f3d_event_record(ev_stop));
     CheckDeviceError(f3d_event_sync(ev_stop));
@@ -234,12 +238,6 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     const int last = last_plain;
     originals_on_device_ = false;
     if (last <= current_warp_level) {
-      const char* bg_env = std::getenv("F3D_P_SCRATCH_THREAD");
-      if (last > 0 && !(bg_env && bg_env[0] == '0'))   // host levels will follow: their scratch gets ready beside these
-        scratch_thread = std::thread([&]() {
-          f3d_lane_make_current(nullptr);   // (binds the library's device to this thread; registration itself is lane-agnostic)
-          prepare_scratch();
-        });
       const auto t0 = std::chrono::steady_clock::now();
       bool ok = true;
       DataSize4 carried = {0, 0, 0, 0};
@@ -275,8 +273,7 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
     std::printf("Allocating additional memory on the host...\n");
     std::printf("Total RAM memory usage: %.0fMB\n", (5 + 8) * volume_bytes / (1024.f * 1024.f));
   }
-  if (scratch_thread.joinable()) scratch_thread.join();
-  else prepare_scratch();
+  prepare_scratch();
   if (!scratch_ok) {
     finish();
     return;

@@ -91,12 +91,20 @@ def rows():
             out.append(("... and with frame 1 registered inside the solver's first residency as well",
                         f"**{float(secs[1]):.2f} s**; with the separate registration operator {float(secs[0]):.2f} s (same call)",
                         os.path.relpath(f, ROOT)))
+    f = P("piecemeal_huge_pages.txt")
+    if os.path.exists(f):
+        import re
+        secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
+        if len(secs) >= 2:
+            out.append(("out-of-core `OpticalFlowP`, 1024³ on a 16 GB budget, FINAL state of round 4 (round 3: 46.8 s; same bits as the resident driver)",
+                        f"**{float(secs[1]):.2f} s** (host scratch on transparent huge pages, prepared in line); {float(secs[0]):.2f} s on 4 KiB pages",
+                        os.path.relpath(f, ROOT)))
     f = P("piecemeal_1024_16gb_handover.txt")
     if os.path.exists(f):
         import re
         secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
         if len(secs) >= 2:
-            out.append(("out-of-core, final state of round 4: ... and the planes neighbouring chunks share handed on from chunk set to chunk set on "
+            out.append(("... and the planes neighbouring chunks share handed on from chunk set to chunk set on "
                         "the device (every plane of every field over the link once per pass)",
                         f"**{float(secs[-1]):.2f} s**; with whole windows uploaded {float(secs[0]):.2f} s (same call; `results identical` to the "
                         f"resident driver; per-level solver seconds in the record)", os.path.relpath(f, ROOT)))
