@@ -11,8 +11,6 @@
 #include <cstring>
 #include <vector>
 
-#include <sys/mman.h>
-
 #include "common_utils.h"
 #include "operator_calls.h"
 #include "hip_utils.h"
@@ -138,11 +136,11 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
   // Host scratch of the levels that go through the host: eight volumes of the original size (the reference keeps ten: phi and ksi stay
   // on the device here), allocated and page-locked when the first such level is reached.  (Doing that on a helper thread beside the
   // resident levels was built and measured twice: page-locking stalls the submission of kernels, the resident levels lose what the
-  // thread saves -- 30.57 s in line, 30.70 s beside, profiles/r04_piecemeal_huge_pages.txt -- so it is done in line.)
+  // thread saves -- 30.57 s in line, 30.70 s beside, profiles/r04_piecemeal_huge_pages.txt -- so it is done in line.  Asking for
+  // transparent huge pages before page-locking saved 0.4 s of the 1.9 s and was taken out as well: a ten-minute soak of this path died of
+  // a GPU memory access fault on a host address after 3 000 runs with it in, LABBOOK.)
   Data3D scratch[8];
   bool scratch_ok = true;
-  const char* hp_env = std::getenv("F3D_P_HUGE_PAGES");
-  const bool huge_pages = !(hp_env && hp_env[0] == '0');
   auto prepare_scratch = [&]() {
     std::vector<Data3D*> all;
     for (Data3D& v : scratch) {
@@ -150,11 +148,6 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
         scratch_ok = false;
         return;
       }
-      // 4 KiB pages make page-locking 34 GB a walk over nine million pages; where the kernel grants transparent huge pages on request,
-      // the volume asks for them before anything touches it (a hint: ignored where the mode is `never`)
-      const uintptr_t first = (reinterpret_cast<uintptr_t>(v.DataPtr()) + (2u << 20) - 1) & ~static_cast<uintptr_t>((2u << 20) - 1);
-      const uintptr_t last = (reinterpret_cast<uintptr_t>(v.DataPtr()) + volume_bytes) & ~static_cast<uintptr_t>((2u << 20) - 1);
-      if (huge_pages && last > first) madvise(reinterpret_cast<void*>(first), last - first, MADV_HUGEPAGE);
       all.push_back(&v);
     }
     pin_volumes(all);
