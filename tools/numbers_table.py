@@ -97,7 +97,7 @@ def rows():
         secs = re.findall(r"piecemeal:\s+([\d.]+) s", open(f).read())
         if len(secs) >= 2:
             out.append(("out-of-core `OpticalFlowP`, 1024³ on a 16 GB budget, FINAL state of round 4 (round 3: 46.8 s; same bits as the resident driver)",
-                        f"**{float(secs[1]):.2f} s** (host scratch on transparent huge pages, prepared in line); {float(secs[0]):.2f} s on 4 KiB pages",
+                        f"**{float(secs[0]):.2f} s** ({float(secs[1]):.2f} s with transparent huge pages for the host scratch -- taken out again, LABBOOK)",
                         os.path.relpath(f, ROOT)))
     f = P("piecemeal_1024_16gb_handover.txt")
     if os.path.exists(f):
