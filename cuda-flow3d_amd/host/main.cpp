@@ -270,8 +270,10 @@ int main(int argc, char** argv)
     const DataSize4& c = optical_flow_e.ContainerSize();
     Data3D host_frame[3], host_flow[2][3];
     std::vector<void*> pinned;
+    // (volumes of 32 MiB and more only: smaller ones live in the allocator's shared heap, see OpticalFlowP::ComputeFlow)
     auto pin = [&](Data3D& v) {
-      if (f3d_host_register(v.DataPtr(), width * height * depth * sizeof(float)) == 0) pinned.push_back(v.DataPtr());
+      const size_t bytes = width * height * depth * sizeof(float);
+      if (bytes >= (static_cast<size_t>(32) << 20) && f3d_host_register(v.DataPtr(), bytes) == 0) pinned.push_back(v.DataPtr());
     };
     for (Data3D& f : host_frame)
       if (!f.Allocate(width, height, depth)) return 2;

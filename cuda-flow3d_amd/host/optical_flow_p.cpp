@@ -100,9 +100,16 @@ void OpticalFlowP::ComputeFlow(Data3D& frame_0, Data3D& frame_1, Data3D& flow_u,
 
   // Page-lock what the copies touch.  Data3D::Swap exchanges storage between volumes of this set only, so the pointers
   // registered here are the ones to release at the end.
+  // Only volumes of 32 MiB and more: an allocator serves smaller requests from its shared heap (glibc: below its mmap threshold, which
+  // adapts up to 32 MiB), where a volume shares its first and last page with its neighbours and the heap's top is unmapped and mapped
+  // again as it shrinks and grows -- and a ten-minute soak of small runs with page-locked heap volumes ended in a GPU memory access
+  // fault on a heap address once in ~4 000 runs, not once in 11 000 with every volume in a mapping of its own (LABBOOK, round 4).
+  // Copies of small volumes are staged by the runtime, which is what they cost anyway.  F3D_P_PIN=0: never; =2: every size (the tests
+  // of the overlapped schedule on small volumes; run them with MALLOC_MMAP_THRESHOLD_=131072).
   std::vector<void*> pinned;
   const char* pin_env = std::getenv("F3D_P_PIN");
-  const bool pin = pin_host_memory && !(pin_env && pin_env[0] == '0');
+  const int pin_mode = pin_env ? std::atoi(pin_env) : 1;
+  const bool pin = pin_host_memory && pin_mode != 0 && (pin_mode == 2 || volume_bytes >= (static_cast<size_t>(32) << 20));
   auto pin_volume = [&](Data3D* v) {
     if (!pin) return;
     if (f3d_host_register(v->DataPtr(), volume_bytes) == 0) {

@@ -83,6 +83,7 @@ CASE = textwrap.dedent('''
             assert gathered >= 1, "the reach never exceeded the halo room: the case does not test the gather"
             assert all(same(g, e) for g, e in zip(got, (xu, xv, xw))), f"{ranks} slabs with a gathered frame differ from the oracle"
     elif what == "piecemeal":
+        os.environ["F3D_P_PIN"] = "2"                     # (the driver page-locks only volumes of 32 MiB and more by itself: here every size, so that the two-set schedule runs)
         os.environ["F3D_P_BUDGET_MB"] = "1.3"             # the finest levels go through the "device" in chunks
         flow = pkg.PiecemealOpticalFlow(); flow.initialize(W, H, D); flow.set_full_pipeline(True)
         got = flow.compute(f0, f1, silent=True, **kw); passes, streamed, resident = flow.stats(); flow.destroy()
@@ -291,7 +292,7 @@ def test_out_of_core_operator_tests_on_the_cpu_backend():
     where a caller volume lost among the scratch volumes was found in round 4.  (Copy queues are synchronous here: orderings between
     queues are the GPU run's to check.)"""
     libdir = build("all")
-    env = dict(os.environ, F3D_LIBDIR=libdir, OMP_NUM_THREADS="4")
+    env = dict(os.environ, F3D_LIBDIR=libdir, OMP_NUM_THREADS="4", F3D_P_PIN="2")
     pick = "test_solve_matches_oracle or test_resample_matches_oracle or test_registration_inside or test_constant_fields_held"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_piecemeal.py"), "-q", "-x", "-m", "gpu", "-k", pick,
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
