@@ -520,6 +520,14 @@ class HostVolume:
         a = np.ascontiguousarray(array, dtype=np.float32)
         if a.ndim != 3:
             raise ValueError("volume must be [z, y, x]")
+        if pin and a.nbytes < (32 << 20):
+            # A small array lives in the allocator's shared heap: page-locked there it shares pages with its neighbours and sits under
+            # a heap top that moves (a GPU memory access fault once in ~4 000 small runs, LABBOOK round 4).  The volume gets a mapping of
+            # its own instead and the values are copied in; `.array` is that storage.
+            import mmap
+            own = np.frombuffer(mmap.mmap(-1, max(a.nbytes, mmap.PAGESIZE)), dtype=np.float32, count=a.size).reshape(a.shape)
+            own[...] = a
+            a = own
         if a.ctypes.data in HostVolume._storage:
             raise ValueError("this array is already wrapped by another HostVolume")
         self._h = C.c_void_p()
