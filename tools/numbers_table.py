@@ -145,7 +145,7 @@ def rows():
 
 def table():
     lines = ["<!-- numbers:begin (generated by tools/numbers_table.py from profiles/; do not edit by hand) -->",
-             "| what | measured (one MI355X; boxes of the pool differ by ±3 %) | record |", "|---|---|---|"]
+             "| what | measured (one MI355X; boxes of the pool differ by ±3 %: the bench line and the kernel statistics of this table are of ONE box, `tools/jobs/r4_job36.sh`; another box gave 71.33 Mvoxels/s and 0.927 for the same kernels, `profiles/r04_bench_steps20_warmup5_other_box.json`) | record |", "|---|---|---|"]
     for what, value, src in rows():
         lines.append(f"| {what} | {value} | `{src}` |")
     lines.append("<!-- numbers:end -->")
